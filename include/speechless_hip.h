@@ -1,0 +1,154 @@
+/*
+ * speechless_hip.h -- C-ABI of the MI355X (gfx950) implementation of the speechless Wav2Letter hot path.
+ *
+ * The reference (juliuskunze/speechless) exposes NO native / FFI interface for this path: every operator below
+ * replaces an *implicit* third-party op that speechless/net.py reaches through Keras/TensorFlow.  Each entry
+ * point cites the reference call site it stands in for (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; device pointers are raw HBM addresses (e.g. tensor.data_ptr()).
+ *   - return 0 on success, a negative sl_status on error; never throw, never abort, never allocate.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no hidden synchronisation.
+ *   - no global mutable state; sl_last_error() is thread-local.
+ *
+ * Data layout in HBM ("halo'd channels-last"): an activation tensor is [batch][rows][channels] with
+ *   rows     = halo_top + padded_time + halo_bottom   (halo rows and rows >= valid time are ZERO, always)
+ *   channels = channel count padded to a multiple of 128 (padded lanes are ZERO, always)
+ * so a SAME-padded conv tap is a plain row-shifted view and no kernel needs bounds checks on reads.
+ */
+#ifndef SPEECHLESS_HIP_H
+#define SPEECHLESS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL_VERSION 1
+
+typedef enum sl_status {
+    SL_OK = 0,
+    SL_ERR_INVALID_ARGUMENT = -1,
+    SL_ERR_UNSUPPORTED = -2,
+    SL_ERR_WORKSPACE_TOO_SMALL = -3,
+    SL_ERR_LAUNCH_FAILED = -4
+} sl_status;
+
+typedef enum sl_dtype { SL_BF16 = 0, SL_F32 = 1 } sl_dtype;
+
+/* epilogue of sl_conv1d_nt */
+typedef enum sl_epilogue {
+    SL_EPI_NONE = 0,      /* y = acc                                  (dgrad into a linear layer)              */
+    SL_EPI_BIAS = 1,      /* y = acc + bias[co]                       (output_conv logits, net.py:328-330)     */
+    SL_EPI_BIAS_RELU = 2, /* y = max(acc + bias[co], 0)               (Conv1D(activation="relu"), net.py:304)  */
+    SL_EPI_RELU_MASK = 3  /* y = acc * (mask[b,t,co] > 0)             (autodiff through relu, net.py:389,550)  */
+} sl_epilogue;
+
+/*
+ * Geometry of one stride-1 "row-shifted GEMM" convolution.  A stride-2 layer (striding_conv, net.py:317-319) is
+ * presented in its PAIR VIEW: two consecutive input frames form one row of 2*Cin channels, which turns the
+ * k=48/stride-2 conv into a k=24/stride-1 conv over the same memory (no padding waste, no strided loads).
+ *
+ *   out[b][y_row0 + t][co] = epi( sum_{tap < taps} sum_{c < cin} x[b][x_row0 + t + tap][c] * w[co][tap][c] )
+ *   for t in [0, t_out), co in [0, cout)
+ */
+typedef struct sl_conv_geom {
+    int32_t batch;          /* B                                                                        */
+    int32_t t_out;          /* valid output rows per utterance (T'); rows >= t_out are never written     */
+    int32_t taps;           /* taps of the (pair-)view                                                   */
+    int32_t cin;            /* contraction channels per tap, multiple of 64                              */
+    int32_t cout;           /* output channels, multiple of 128                                          */
+    int32_t x_row0;         /* first input row read by (t = 0, tap = 0)                                  */
+    int32_t x_row_stride;   /* elements between input rows (>= cin)                                      */
+    int64_t x_batch_stride; /* elements between utterances in x                                          */
+    int32_t y_row0;         /* output row of t = 0                                                       */
+    int32_t y_row_stride;   /* elements between output rows (>= cout)                                    */
+    int64_t y_batch_stride; /* elements between utterances in y (and in mask)                            */
+} sl_conv_geom;
+
+int sl_version(void);
+const char* sl_last_error(void);
+
+/* ---- conv forward and input-gradient (both are the same row-shifted NT GEMM) ---------------------------------
+ * Replaces: Keras Conv1D forward (net.py:304-305 -> TF conv2d/bias_add/relu) and, with flipped/transposed packed
+ * weights, TF Conv2DBackpropInput reached by autodiff from net.py:389,550.
+ *   x      : [B][rows][x_row_stride]  dtype
+ *   w      : packed weights [cout][taps][cin] dtype (see sl_pack_weights)
+ *   bias   : float[cout] or NULL (SL_EPI_BIAS*)
+ *   mask   : same geometry as y, dtype (SL_EPI_RELU_MASK) or NULL
+ *   y      : [B][rows][y_row_stride]; dtype, or float when out_f32 != 0
+ */
+int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* mask, void* y,
+                 const sl_conv_geom* geom, int epilogue, int dtype, int out_f32, void* stream);
+
+/* ---- conv weight gradient -------------------------------------------------------------------------------------
+ * Replaces: TF Conv2DBackpropFilter reached by autodiff from net.py:389,550.
+ *   dw[tap][c][co] = sum_b sum_{t < t_pad} x[b][x_row0 + t + tap][c] * g[b][g_row0 + t][co]     (fp32 out)
+ * geom: batch,taps,cin,cout,x_* as above; y_* describe g (y_row0 = g_row0, ...); t_out = valid rows of g
+ * (rows >= t_out of g are zero by the layout invariant, so the kernel sums whole 64-row chunks).
+ * Deterministic: split-K partials go to `workspace` and are reduced in a fixed order.
+ */
+size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype);
+int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* bias gradient db[co] = sum_{b,t} g[b][g_row0+t][co] (fp32 out, deterministic two-stage).  Same autodiff site. */
+size_t sl_bias_grad_workspace_bytes(const sl_conv_geom* geom);
+int sl_bias_grad(const void* g, float* db, const sl_conv_geom* geom, int dtype, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* ---- weight packing -------------------------------------------------------------------------------------------
+ * master weights are fp32 in the Keras kernel layout [k][cin_pad][cout_pad] (net.py:251-255 evidence for
+ * (kernel_size, in_channels, filters)).  Produces
+ *   w_fwd [cout_pad][k][cin_pad]            (forward operand)      and, if w_dgrad != NULL,
+ *   w_dgrad[cin_pad][k][cout_pad]  with taps flipped: w_dgrad[ci][j][co] = w[k-1-j][ci][co]
+ */
+int sl_pack_weights(const float* w_master, void* w_fwd, void* w_dgrad, int k, int cin_pad, int cout_pad,
+                    int dtype, void* stream);
+
+/* ---- input packing  (net.py:578-587 zero-pad + cast; rows offset by the SAME left pad) -------------------------
+ * src: float[B][t_in][f] (dense, host-packed batch already resident in HBM)
+ * dst: [B][dst_rows][dst_row_stride] dtype, PRE-ZEROED; frame t lands in row dst_row0 + t.
+ */
+int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,
+                  int64_t dst_batch_stride, int dtype, void* stream);
+
+/* ---- output softmax (net.py:131,328-330) + the Keras ctc_batch_cost prologue log(p+eps) re-normalised -----------
+ * logits: float[B][t_out][logit_stride] (first k valid).  probs,logq: float[B][t_out][k] dense.
+ * logq = log_softmax(log(probs + eps)) = what tf.nn.ctc_loss sees after its own softmax (net.py:405-406).
+ */
+int sl_softmax_logq(const float* logits, float* probs, float* logq, int batch, int t_out, int k, int logit_stride,
+                    float eps, void* stream);
+
+/* ---- CTC loss and gradient (net.py:402-406: keras.backend.ctc_batch_cost -> tf.nn.ctc_loss) --------------------
+ * labels: int32[B][l_max] (padding ignored, grapheme_enconding.py:28 uses -1); blank = k-1 (grapheme_enconding.py:125).
+ * loss:   float[B]  (-log p(label | x); +inf when no valid alignment exists)
+ * dlogits: gradient of  grad_scale * sum_b loss[b]  w.r.t. the PRE-softmax logits of output_conv, written into the
+ *          halo'd tensor described by (g_row0, g_row_stride, g_batch_stride), dtype `dtype`; frames >=
+ *          input_len[b] get zeros.  grad_scale = 1/B realises Keras' mean over the batch (net.py:389).
+ * workspace: sl_ctc_workspace_bytes(...) bytes (alpha/beta lattices, fp32 log-space).
+ */
+size_t sl_ctc_workspace_bytes(int batch, int t_out, int l_max);
+int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* labels, const int32_t* label_len,
+                     const int32_t* input_len, float* loss, void* dlogits, int batch, int t_out, int k, int l_max,
+                     int g_row0, int g_row_stride, int64_t g_batch_stride, int dtype, float eps, float grad_scale,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- greedy decode (net.py:452-454 tf.nn.ctc_greedy_decoder, merge_repeated=True; numpy twin
+ *      grapheme_enconding.py:34-57): per-frame argmax (first max wins) for t < input_len, merge repeats, drop blank.
+ * out: int32[B][t_out] filled with -1 past out_len[b] (sparse_to_dense default, net.py:436). frame_argmax: optional
+ * int32[B][t_out] raw per-frame argmax (for parity attribution), or NULL.
+ */
+int sl_greedy_decode(const float* probs, const int32_t* input_len, int32_t* out, int32_t* out_len,
+                     int32_t* frame_argmax, int batch, int t_out, int k, int blank, void* stream);
+
+/* ---- Keras-2.0 Adam (net.py:132): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps) ------------------- */
+int sl_adam_step(float* param, const float* grad, float* m, float* v, size_t n, int step, float lr, float beta1,
+                 float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEECHLESS_HIP_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of include/speechless_hip.h.  There is NO fallback: if the HIP library is missing or a call
+fails, this raises -- the product path never computes on the CPU."""
+import ctypes
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libspeechless_hip.so"
+
+SL_BF16 = 0
+SL_F32 = 1
+
+EPI_NONE = 0
+EPI_BIAS = 1
+EPI_BIAS_RELU = 2
+EPI_RELU_MASK = 3
+
+
+class ConvGeom(ctypes.Structure):
+    """Mirror of sl_conv_geom (include/speechless_hip.h)."""
+    _fields_ = [
+        ("batch", c_int32),
+        ("t_out", c_int32),
+        ("taps", c_int32),
+        ("cin", c_int32),
+        ("cout", c_int32),
+        ("x_row0", c_int32),
+        ("x_row_stride", c_int32),
+        ("x_batch_stride", c_int64),
+        ("y_row0", c_int32),
+        ("y_row_stride", c_int32),
+        ("y_batch_stride", c_int64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/speechless_hip.h declares
+SIGNATURES = {
+    "sl_version": (c_int, []),
+    "sl_last_error": (c_char_p, []),
+    "sl_conv1d_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int, c_int,
+                             c_void_p]),
+    "sl_conv1d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int]),
+    "sl_conv1d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_void_p, c_size_t, c_void_p]),
+    "sl_bias_grad_workspace_bytes": (c_size_t, [POINTER(ConvGeom)]),
+    "sl_bias_grad": (c_int, [c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_void_p, c_size_t, c_void_p]),
+    "sl_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sl_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "sl_softmax_logq": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "sl_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sl_ctc_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_float, c_void_p, c_size_t,
+                                 c_void_p]),
+    "sl_greedy_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                 c_void_p]),
+    "sl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_float,
+                             c_float, c_void_p]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class HipLibrary:
+    """Loaded libspeechless_hip.so with typed entry points.  `call(name, *args)` raises on a non-zero status."""
+
+    def __init__(self, path=LIB_PATH):
+        path = Path(path)
+        if not path.exists():
+            raise HipLibraryError(
+                "{} not found: build it with `python -m speechless_amd.build` (or __graft_entry__.build()). "
+                "The speechless_amd hot path has no CPU fallback.".format(path))
+        self.path = path
+        self._dll = ctypes.CDLL(str(path))
+        self._fn = {}
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(self._dll, name)  # AttributeError if the symbol is missing -> loud
+            fn.restype = restype
+            fn.argtypes = argtypes
+            self._fn[name] = fn
+        if self._fn["sl_version"]() != 1:
+            raise HipLibraryError("libspeechless_hip.so version mismatch")
+
+    def raw(self, name):
+        return self._fn[name]
+
+    def last_error(self):
+        msg = self._fn["sl_last_error"]()
+        return msg.decode("utf8", "replace") if msg else ""
+
+    def call(self, name, *args):
+        rc = self._fn[name](*args)
+        if rc != 0:
+            raise HipLibraryError("{} failed with status {}: {}".format(name, rc, self.last_error()))
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLibrary()
+    return _LIB

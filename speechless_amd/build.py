@@ -1,0 +1,48 @@
+"""Builds speechless_amd/libspeechless_hip.so (gfx950) in-tree with hipcc.  No GPU needed (cross-compile)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PACKAGE_DIR = Path(__file__).resolve().parent
+CSRC = PACKAGE_DIR / "csrc"
+LIB_PATH = PACKAGE_DIR / "libspeechless_hip.so"
+SOURCES = ["capi.hip", "conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_f32.hip", "ctc.hip", "misc.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newest_source_mtime():
+    files = [CSRC / s for s in SOURCES] + [CSRC / "common.h", PACKAGE_DIR.parent / "include" / "speechless_hip.h"]
+    return max(f.stat().st_mtime for f in files)
+
+
+def _compile(src):
+    obj = CSRC / (src.replace(".hip", ".o"))
+    cmd = [HIPCC] + FLAGS + ["-c", str(CSRC / src), "-o", str(obj)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed for {}:\n{}\n{}".format(src, res.stdout, res.stderr))
+    return obj, res.stderr
+
+
+def build(force=False, verbose=False):
+    if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= _newest_source_mtime():
+        return LIB_PATH
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        results = list(pool.map(_compile, SOURCES))
+    objs = [str(o) for o, _ in results]
+    if verbose:
+        for (_, err), src in zip(results, SOURCES):
+            if err.strip():
+                print("[{}]\n{}".format(src, err), file=sys.stderr)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + objs
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n{}\n{}".format(res.stdout, res.stderr))
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

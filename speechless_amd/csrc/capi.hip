@@ -1,0 +1,70 @@
+// capi.hip -- extern "C" boundary (include/speechless_hip.h): argument validation + dispatch to the gfx950 kernels.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_last_error[512] = "";
+
+void sl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int sl_version(void) { return SL_VERSION; }
+extern "C" const char* sl_last_error(void) { return g_last_error; }
+
+static int check_geom(const sl_conv_geom* g, const char* who, int cin_mult, int cout_mult) {
+    SL_CHECK_ARG(g != nullptr, "%s: geom is null", who);
+    SL_CHECK_ARG(g->batch > 0 && g->t_out > 0 && g->taps > 0, "%s: batch/t_out/taps must be positive", who);
+    SL_CHECK_ARG(g->cin > 0 && g->cin % cin_mult == 0, "%s: cin=%d must be a positive multiple of %d", who, g->cin,
+                 cin_mult);
+    SL_CHECK_ARG(g->cout > 0 && g->cout % cout_mult == 0, "%s: cout=%d must be a positive multiple of %d", who,
+                 g->cout, cout_mult);
+    SL_CHECK_ARG(g->x_row0 >= 0 && g->y_row0 >= 0, "%s: negative row offset", who);
+    SL_CHECK_ARG(g->x_row_stride >= g->cin && g->x_row_stride % 8 == 0, "%s: bad x_row_stride", who);
+    SL_CHECK_ARG(g->y_row_stride >= g->cout && g->y_row_stride % 8 == 0, "%s: bad y_row_stride", who);
+    return SL_OK;
+}
+
+extern "C" int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* mask, void* y,
+                            const sl_conv_geom* geom, int epilogue, int dtype, int out_f32, void* stream) {
+    int rc = check_geom(geom, "sl_conv1d_nt", 64, 128);
+    if (rc != SL_OK) return rc;
+    SL_CHECK_ARG(x && w && y, "sl_conv1d_nt: null tensor pointer");
+    SL_CHECK_ARG(epilogue >= SL_EPI_NONE && epilogue <= SL_EPI_RELU_MASK, "sl_conv1d_nt: unknown epilogue %d", epilogue);
+    if (epilogue == SL_EPI_BIAS || epilogue == SL_EPI_BIAS_RELU) SL_CHECK_ARG(bias, "sl_conv1d_nt: bias is null");
+    if (epilogue == SL_EPI_RELU_MASK) SL_CHECK_ARG(mask, "sl_conv1d_nt: mask is null");
+    if (dtype == SL_BF16) return conv_nt_bf16(x, w, bias, mask, y, geom, epilogue, out_f32, (hipStream_t)stream);
+    if (dtype == SL_F32) return conv_nt_f32(x, w, bias, mask, y, geom, epilogue, (hipStream_t)stream);
+    sl_set_error("sl_conv1d_nt: unknown dtype %d", dtype);
+    return SL_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype) {
+    if (!geom || geom->taps <= 0 || geom->cin <= 0 || geom->cout <= 0 || geom->batch <= 0) return 0;
+    const int tile = dtype == SL_BF16 ? 128 : 64;
+    if (geom->cin % tile || geom->cout % tile) return 0;
+    const int splits = wgrad_split_count(geom, tile);
+    if (splits <= 1) return 0;
+    return (size_t)splits * geom->taps * geom->cin * geom->cout * sizeof(float);
+}
+
+extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32, "sl_conv1d_wgrad: unknown dtype %d", dtype);
+    const int tile = dtype == SL_BF16 ? 128 : 64;
+    int rc = check_geom(geom, "sl_conv1d_wgrad", tile, tile);
+    if (rc != SL_OK) return rc;
+    SL_CHECK_ARG(x && g && dw, "sl_conv1d_wgrad: null tensor pointer");
+    const int splits = wgrad_split_count(geom, tile);
+    const size_t need = sl_conv1d_wgrad_workspace_bytes(geom, dtype);
+    if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+        sl_set_error("sl_conv1d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return SL_ERR_WORKSPACE_TOO_SMALL;
+    }
+    if (dtype == SL_BF16) return wgrad_tn_bf16(x, g, dw, geom, (float*)workspace, splits, (hipStream_t)stream);
+    return wgrad_tn_f32(x, g, dw, geom, (float*)workspace, splits, (hipStream_t)stream);
+}

@@ -1,0 +1,66 @@
+// common.h -- shared device/host helpers for the gfx950 kernels of the speechless hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/speechless_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define SL_LDS __attribute__((address_space(3)))
+#define SL_GLOBAL __attribute__((address_space(1)))
+
+// thread-local error string, set by sl_set_error (capi.hip)
+void sl_set_error(const char* fmt, ...);
+
+#define SL_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            sl_set_error(__VA_ARGS__);          \
+            return SL_ERR_INVALID_ARGUMENT;     \
+        }                                       \
+    } while (0)
+
+static inline int sl_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        sl_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return SL_ERR_LAUNCH_FAILED;
+    }
+    return SL_OK;
+}
+
+// fp32 -> bf16 round-to-nearest-even (bit pattern), matches oracle round_to_bf16
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+
+// XCD-aware work-group remap: the dispatcher places block b on XCD b % 8 (speed only, never correctness).
+// Gives each XCD a contiguous range of logical ids so that neighbouring tiles share the XCD's private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+    if ((total & 7) != 0) return bid;
+    return (bid & 7) * (total >> 3) + (bid >> 3);
+}
+
+// kernels' C++ entry points (called from capi.hip)
+int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
+                 int epilogue, int out_f32, hipStream_t s);
+int conv_nt_f32(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
+                int epilogue, hipStream_t s);
+int wgrad_split_count(const sl_conv_geom* g, int tile);
+int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits,
+                  hipStream_t s);
+int wgrad_tn_f32(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits, hipStream_t s);

@@ -1,0 +1,405 @@
+// ctc.hip -- output softmax, Keras/TF CTC loss + gradient, greedy decode for gfx950.
+//
+// Reference call sites (speechless/net.py): output softmax :131,:328-330; _ctc_lambda -> keras ctc_batch_cost ->
+// tf.nn.ctc_loss :402-406 (the op sees log(p + 1e-8) and applies its own softmax, so the effective distribution is
+// q = (p + eps) / sum(p + eps)); greedy decode :417-436,:452-454 and grapheme_enconding.py:34-57.
+//
+// Kernels:
+//   softmax_logq_kernel : one thread per (b,t) frame: p = softmax(logits), logq = log q.            (HBM-bound, tiny)
+//   ctc_lattice_kernel  : grid (B, 2).  Work-group (b,0) runs the alpha recursion t = 0..T-1, work-group (b,1) the
+//                         beta recursion t = T-1..0, concurrently.  One thread per extended-label state
+//                         (S = 2L+1 <= 1024), log-space fp32, previous row double-buffered in LDS (one barrier per
+//                         frame), emission log-probs prefetched 8 frames ahead into registers.  The recursion is
+//                         sequential in t -> latency-bound by construction; running alpha and beta in separate
+//                         work-groups halves the critical path.
+//   ctc_grad_kernel     : one wave per frame.  occupancy gamma_t(k) = sum_{s: l'_s = k} exp(alpha+beta-logq-logP) is
+//                         reduced in a FIXED order (blank: wave butterfly; graphemes: per-class position lists built
+//                         once per work-group) -> deterministic.  Chains through log(p+eps) and the output softmax and
+//                         writes d(loss)/d(logits) straight into the halo'd gradient tensor of output_conv.
+//   greedy_decode_kernel: one work-group per utterance: argmax (first max wins), merge repeats, drop blank, compact.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+__global__ void softmax_logq_kernel(const float* __restrict__ logits, float* __restrict__ probs,
+                                    float* __restrict__ logq, long frames, int k, int logit_stride, float eps) {
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    const float* z = logits + f * logit_stride;
+    float m = -INFINITY;
+    for (int i = 0; i < k; ++i) m = fmaxf(m, z[i]);
+    float sum = 0.f;
+    for (int i = 0; i < k; ++i) sum += expf(z[i] - m);
+    float* p = probs + f * k;
+    float* lq = logq + f * k;
+    // q = (p + eps) / sum_j (p_j + eps); computed the way TF does: log-softmax of u = log(p + eps)
+    float um = -INFINITY;
+    for (int i = 0; i < k; ++i) {
+        const float pi = expf(z[i] - m) / sum;
+        p[i] = pi;
+        const float u = logf(pi + eps);
+        lq[i] = u;
+        um = fmaxf(um, u);
+    }
+    float usum = 0.f;
+    for (int i = 0; i < k; ++i) usum += expf(lq[i] - um);
+    const float lz = um + logf(usum);
+    for (int i = 0; i < k; ++i) lq[i] -= lz;
+}
+
+// workspace layout: alpha [B][T][SP], beta [B][T][SP]  (SP = S rounded up to 64)
+__global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restrict__ logq,
+                                                           const int32_t* __restrict__ labels,
+                                                           const int32_t* __restrict__ label_len,
+                                                           const int32_t* __restrict__ input_len,
+                                                           float* __restrict__ alpha, float* __restrict__ beta,
+                                                           float* __restrict__ loss, int t_out, int k, int l_max,
+                                                           int sp, int blank) {
+    extern __shared__ float rowbuf[];  // 2 x (blockDim + 4)
+    const int b = blockIdx.x;
+    const int dir = blockIdx.y;
+    const int s = threadIdx.x;
+    const int L = label_len[b];
+    const int S = 2 * L + 1;
+    int T = input_len[b];
+    if (T > t_out) T = t_out;
+    const int stride = blockDim.x + 4;
+    float* buf0 = rowbuf;
+    float* buf1 = rowbuf + stride;
+    const int32_t* lab = labels + (long)b * l_max;
+
+    // extended label of this state and whether the skip transition INTO (alpha) / OUT OF (beta) it is allowed
+    const bool live = s < S;
+    int my = blank;
+    bool skip = false;
+    if (live && (s & 1)) {
+        my = lab[s >> 1];
+        if (dir == 0) {
+            skip = (s >= 3) && (lab[(s >> 1) - 1] != my);
+        } else {
+            skip = (s + 2 < S) && (lab[(s >> 1) + 1] != my);
+        }
+    }
+    if (T <= 0) {
+        if (dir == 0 && s == 0) loss[b] = INFINITY;
+        return;
+    }
+    float* out = (dir == 0 ? alpha : beta) + (long)b * t_out * sp;
+    const float* lq = logq + (long)b * t_out * k + my;
+
+    // pads: alpha reads s-1, s-2 (index s+1, s in a buffer shifted by 2); beta reads s+1, s+2
+    if (s < 2) {
+        buf0[s] = -INFINITY;
+        buf1[s] = -INFINITY;
+        buf0[blockDim.x + 2 + s] = -INFINITY;
+        buf1[blockDim.x + 2 + s] = -INFINITY;
+    }
+    const int tstart = dir == 0 ? 0 : T - 1;
+    const int tstep = dir == 0 ? 1 : -1;
+
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = tstart + tstep * j;
+        e[j] = (live && j < T) ? lq[(long)t * k] : 0.f;
+    }
+    // t = tstart
+    float a = -INFINITY;
+    if (live) {
+        const bool init = dir == 0 ? (s <= 1) : (s >= S - 2);
+        if (init) a = e[0];
+    }
+    buf0[s + 2] = a;
+    if (live) out[(long)tstart * sp + s] = a;
+    if (8 < T) e[0] = live ? lq[(long)(tstart + tstep * 8) * k] : 0.f;  // slot 0 next serves frame-step 8
+    float* prev = buf0;
+    float* cur = buf1;
+    const int nb = dir == 0 ? -1 : 1;  // neighbour direction
+    for (int base = 1; base < T; base += 8) {
+        // frames base .. base+7 use e[(base+j) & 7]; ring slot j below is refilled for frame base+j+7 ... keep simple:
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int step = base + j;           // 1-based distance from tstart
+            if (step < T) {
+                const int slot = (j + 1) & 7;     // e[] slot holding frame `step` (step = 8q + 1 + j)
+                const int t = tstart + tstep * step;
+                __syncthreads();
+                const float a0 = prev[s + 2];
+                const float a1 = prev[s + 2 + nb];
+                const float a2 = skip ? prev[s + 2 + 2 * nb] : -INFINITY;
+                float v = lse3(a0, a1, a2) + e[slot];
+                if (!live) v = -INFINITY;
+                cur[s + 2] = v;
+                if (live) out[(long)t * sp + s] = v;
+                // refill this slot with the emission 8 frames ahead
+                const int ahead = step + 8;
+                if (ahead < T) e[slot] = live ? lq[(long)(tstart + tstep * ahead) * k] : 0.f;
+                float* tmp = prev;
+                prev = cur;
+                cur = tmp;
+            }
+        }
+    }
+    if (dir == 0) {
+        __syncthreads();
+        if (s == 0) {
+            const float last = prev[S - 1 + 2];
+            const float last2 = S >= 2 ? prev[S - 2 + 2] : -INFINITY;
+            const float m = fmaxf(last, last2);
+            const float lp = (m == -INFINITY) ? -INFINITY : m + logf(expf(last - m) + expf(last2 - m));
+            loss[b] = -lp;
+        }
+    }
+}
+
+// one wave per frame; block = 256 threads = 4 frames per iteration
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ probs, const float* __restrict__ logq,
+                                                       const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ label_len,
+                                                       const int32_t* __restrict__ input_len,
+                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                       const float* __restrict__ loss, void* __restrict__ dlogits,
+                                                       int t_out, int k, int l_max, int sp, int blank, int frames_per_wg,
+                                                       int g_row0, int g_rs, long g_bs, int out_f32, float eps,
+                                                       float grad_scale) {
+    // LDS: labels[l_max] | class_start[k+1] | class_pos[l_max] | gamma[4][l_max]
+    extern __shared__ int lds_i[];
+    int* s_lab = lds_i;
+    int* s_start = s_lab + l_max;
+    int* s_pos = s_start + (k + 1);
+    float* s_gam = (float*)(s_pos + l_max);
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int L = label_len[b];
+    const int S = 2 * L + 1;
+    int T = input_len[b];
+    if (T > t_out) T = t_out;
+    const int32_t* lab = labels + (long)b * l_max;
+    for (int i = tid; i < L; i += 256) s_lab[i] = lab[i];
+    __syncthreads();
+    // per-class position lists in label order (counting sort, fixed order -> deterministic sums)
+    if (tid < k) {
+        int c = 0;
+        for (int i = 0; i < L; ++i) c += (s_lab[i] == tid);
+        s_start[tid + 1] = c;
+    }
+    if (tid == 0) s_start[0] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int c = 0; c < k; ++c) s_start[c + 1] += s_start[c];
+    }
+    __syncthreads();
+    if (tid < k) {
+        int w = s_start[tid];
+        for (int i = 0; i < L; ++i)
+            if (s_lab[i] == tid) s_pos[w++] = i;
+    }
+    __syncthreads();
+
+    const float nll = loss[b];
+    const bool feasible = nll < INFINITY;
+    const float log_p = -nll;
+    float* gam = s_gam + wave * l_max;
+    const int t_begin = blockIdx.x * frames_per_wg;
+    for (int tt = wave; tt < frames_per_wg; tt += 4) {
+        const int t = t_begin + tt;
+        if (t >= t_out) break;
+        const long fidx = (long)b * t_out + t;
+        float dz = 0.f;
+        if (t < T) {
+            const float* lq = logq + fidx * k;
+            const float* pr = probs + fidx * k;
+            float occ = 0.f;
+            if (feasible) {
+                const float* al = alpha + fidx * sp;
+                const float* be = beta + fidx * sp;
+                const float lq_blank = lq[blank];
+                // blank states (even s) -> butterfly sum; grapheme states (odd s) -> gamma[] in LDS
+                float blank_part = 0.f;
+                for (int s = lane; s < S; s += 64) {
+                    const float ab = al[s] + be[s];
+                    if (s & 1) {
+                        const int pos = s >> 1;
+                        const float lg = ab - lq[s_lab[pos]] - log_p;
+                        gam[pos] = (ab == -INFINITY) ? 0.f : expf(lg);
+                    } else {
+                        const float lg = ab - lq_blank - log_p;
+                        blank_part += (ab == -INFINITY) ? 0.f : expf(lg);
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) blank_part += __shfl_xor(blank_part, off);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (lane < k) {
+                    if (lane == blank) {
+                        occ = blank_part;
+                    } else {
+                        const int e0 = s_start[lane], e1 = s_start[lane + 1];
+                        for (int i = e0; i < e1; ++i) occ += gam[s_pos[i]];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // du_k = q_k - occ_k ; dp_k = du_k / (p_k + eps) ; dz_k = p_k * (dp_k - sum_j p_j dp_j)
+            float pk = 0.f, dp = 0.f;
+            if (lane < k) {
+                pk = pr[lane];
+                const float qk = expf(lq[lane]);
+                dp = (qk - occ) / (pk + eps);
+            }
+            float inner = pk * dp;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) inner += __shfl_xor(inner, off);
+            dz = pk * (dp - inner) * grad_scale;
+        }
+        if (lane < k) {
+            const long gi = (long)b * g_bs + (long)(g_row0 + t) * g_rs + lane;
+            if (out_f32)
+                ((float*)dlogits)[gi] = dz;
+            else
+                ((unsigned short*)dlogits)[gi] = f32_to_bf16_bits(dz);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void greedy_decode_kernel(const float* __restrict__ probs,
+                                                            const int32_t* __restrict__ input_len,
+                                                            int32_t* __restrict__ out, int32_t* __restrict__ out_len,
+                                                            int32_t* __restrict__ frame_argmax, int t_out, int k,
+                                                            int blank) {
+    extern __shared__ int s_idx[];  // t_out ints + 256 scan slots
+    int* s_scan = s_idx + t_out;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    int T = input_len[b];
+    if (T > t_out) T = t_out;
+    if (T < 0) T = 0;
+    for (int t = tid; t < t_out; t += 256) {
+        int best = -1;
+        if (t < T) {
+            const float* p = probs + ((long)b * t_out + t) * k;
+            float bv = p[0];
+            best = 0;
+            for (int i = 1; i < k; ++i) {
+                const float v = p[i];
+                if (v > bv) {
+                    bv = v;
+                    best = i;
+                }
+            }
+        }
+        s_idx[t] = best;
+        if (frame_argmax) frame_argmax[(long)b * t_out + t] = best;
+    }
+    __syncthreads();
+    // each thread owns a contiguous slice of frames
+    const int per = (T + 255) / 256;
+    const int t0 = tid * per;
+    int t1 = t0 + per;
+    if (t1 > T) t1 = T;
+    int cnt = 0;
+    for (int t = t0; t < t1; ++t) {
+        const int c = s_idx[t];
+        const int pv = t > 0 ? s_idx[t - 1] : -1;
+        cnt += (c != blank && c != pv);
+    }
+    s_scan[tid] = cnt;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over 256 entries
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int pos = s_scan[tid] - cnt;
+    const int total = s_scan[255];
+    int32_t* o = out + (long)b * t_out;
+    for (int t = t0; t < t1; ++t) {
+        const int c = s_idx[t];
+        const int pv = t > 0 ? s_idx[t - 1] : -1;
+        if (c != blank && c != pv) o[pos++] = c;
+    }
+    for (int t = total + tid; t < t_out; t += 256) o[t] = -1;
+    if (tid == 0) out_len[b] = total;
+}
+
+__host__ int lattice_sp(int l_max) { return ((2 * l_max + 1) + 63) / 64 * 64; }
+
+}  // namespace
+
+extern "C" int sl_softmax_logq(const float* logits, float* probs, float* logq, int batch, int t_out, int k,
+                               int logit_stride, float eps, void* stream) {
+    SL_CHECK_ARG(batch > 0 && t_out > 0 && k > 0 && logit_stride >= k, "sl_softmax_logq: bad sizes");
+    const long frames = (long)batch * t_out;
+    hipLaunchKernelGGL(softmax_logq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, probs, logq, frames, k, logit_stride, eps);
+    return sl_check_launch("sl_softmax_logq");
+}
+
+extern "C" size_t sl_ctc_workspace_bytes(int batch, int t_out, int l_max) {
+    if (batch <= 0 || t_out <= 0 || l_max < 0) return 0;
+    return (size_t)2 * batch * t_out * lattice_sp(l_max) * sizeof(float);
+}
+
+extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* labels, const int32_t* label_len,
+                                const int32_t* input_len, float* loss, void* dlogits, int batch, int t_out, int k,
+                                int l_max, int g_row0, int g_row_stride, int64_t g_batch_stride, int dtype, float eps,
+                                float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    SL_CHECK_ARG(batch > 0 && t_out > 0 && k > 1 && k <= 64, "sl_ctc_loss_grad: need batch,t_out > 0 and 1 < k <= 64");
+    SL_CHECK_ARG(l_max >= 1, "sl_ctc_loss_grad: l_max must be >= 1 (pad the label batch to width 1 for empty labels)");
+    const int sp = lattice_sp(l_max);
+    if (2 * l_max + 1 > 1024) {
+        sl_set_error("sl_ctc_loss_grad: label length %d > 511 unsupported (one lattice state per thread)", l_max);
+        return SL_ERR_UNSUPPORTED;
+    }
+    if (workspace_bytes < sl_ctc_workspace_bytes(batch, t_out, l_max)) {
+        sl_set_error("sl_ctc_loss_grad: workspace too small");
+        return SL_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* alpha = (float*)workspace;
+    float* beta = alpha + (size_t)batch * t_out * sp;
+    const int threads = sp;  // multiple of 64, >= S
+    const size_t lds = 2 * (threads + 4) * sizeof(float);
+    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(batch, 2), dim3(threads), lds, s, logq, labels, label_len, input_len,
+                       alpha, beta, loss, t_out, k, l_max, sp, k - 1);
+    int rc = sl_check_launch("sl_ctc_loss_grad(lattice)");
+    if (rc != SL_OK) return rc;
+    const int frames_per_wg = 32;
+    const size_t lds2 = (size_t)(l_max + (k + 1) + l_max) * sizeof(int) + (size_t)4 * l_max * sizeof(float);
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3((t_out + frames_per_wg - 1) / frames_per_wg, batch), dim3(256), lds2, s,
+                       probs, logq, labels, label_len, input_len, alpha, beta, loss, dlogits, t_out, k, l_max, sp,
+                       k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, dtype == SL_F32 ? 1 : 0, eps,
+                       grad_scale);
+    return sl_check_launch("sl_ctc_loss_grad(grad)");
+}
+
+extern "C" int sl_greedy_decode(const float* probs, const int32_t* input_len, int32_t* out, int32_t* out_len,
+                                int32_t* frame_argmax, int batch, int t_out, int k, int blank, void* stream) {
+    SL_CHECK_ARG(batch > 0 && t_out > 0 && k > 0, "sl_greedy_decode: bad sizes");
+    const size_t lds = (size_t)(t_out + 256) * sizeof(int);
+    if (lds > 150 * 1024) {
+        sl_set_error("sl_greedy_decode: t_out %d too large for the LDS-resident decoder", t_out);
+        return SL_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)greedy_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(greedy_decode_kernel, dim3(batch), dim3(256), lds, (hipStream_t)stream, probs, input_len, out,
+                       out_len, frame_argmax, t_out, k, blank);
+    return sl_check_launch("sl_greedy_decode");
+}

@@ -1,0 +1,188 @@
+// misc.hip -- HBM-bound helpers of the hot path: weight packing, input packing, bias gradient, Keras-2.0 Adam.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T cvt_out(float v);
+template <>
+__device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ unsigned short cvt_out<unsigned short>(float v) { return f32_to_bf16_bits(v); }
+
+// master [k][cin][cout] fp32 -> w_fwd [cout][k][cin] (32x32 LDS transpose per tap) and w_dgrad [cin][k-1-tap][cout]
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ wm, T* __restrict__ wf,
+                                                           T* __restrict__ wd, int k, int cin, int cout) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.y * 32;
+    const int co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + ty + r * 8;
+        const float v = wm[((long)tap * cin + ci) * cout + co0 + tx];
+        tile[ty + r * 8][tx] = v;
+        if (wd) wd[((long)ci * k + (k - 1 - tap)) * cout + co0 + tx] = cvt_out<T>(v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co0 + ty + r * 8;
+        wf[((long)co * k + tap) * cin + ci0 + tx] = cvt_out<T>(tile[tx][ty + r * 8]);
+    }
+}
+
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ src, T* __restrict__ dst, int t_in, int f, int dst_row0,
+                                  int dst_rs, long dst_bs, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % f);
+    const long r = i / f;
+    const int t = (int)(r % t_in);
+    const long b = r / t_in;
+    dst[b * dst_bs + (long)(dst_row0 + t) * dst_rs + c] = cvt_out<T>(src[i]);
+}
+
+// stage 1: partial[b][co] = sum_t g[b][row0+t][co]; block = 256 threads = 16 column-groups(8 ch) x 16 row lanes
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const T* __restrict__ g, float* __restrict__ partial,
+                                                                int t_out, int cout, int g_row0, int g_rs, long g_bs) {
+    __shared__ float red[16][129];
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * 128;
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    const T* base = g + (long)b * g_bs + (long)g_row0 * g_rs + c0 + cg * 8;
+    for (int t = rl; t < t_out; t += 16) {
+        const T* p = base + (long)t * g_rs;
+        if (sizeof(T) == 2) {
+            const u32x4 v = *(const u32x4*)p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * i] += __uint_as_float(v[i] << 16);
+                acc[2 * i + 1] += __uint_as_float(v[i] & 0xFFFF0000u);
+            }
+        } else {
+            const f32x4 v0 = *(const f32x4*)p;
+            const f32x4 v1 = *(const f32x4*)((const float*)p + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i] += v0[i];
+                acc[4 + i] += v1[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[rl][cg * 8 + i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+        partial[(long)b * cout + c0 + threadIdx.x] = s;
+    }
+}
+
+__global__ void bias_grad_final_kernel(const float* __restrict__ partial, float* __restrict__ db, int batch, int cout) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cout) return;
+    float s = 0.f;
+    for (int b = 0; b < batch; ++b) s += partial[(long)b * cout + c];
+    db[c] = s;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n4, float lr_t, float b1, float b2, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 gv = ((const f32x4*)g)[i];
+    f32x4 mv = ((f32x4*)m)[i];
+    f32x4 vv = ((f32x4*)v)[i];
+    f32x4 pv = ((f32x4*)p)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mv[j] = b1 * mv[j] + (1.f - b1) * gv[j];
+        vv[j] = b2 * vv[j] + (1.f - b2) * gv[j] * gv[j];
+        pv[j] = pv[j] - lr_t * mv[j] / (sqrtf(vv[j]) + eps);
+    }
+    ((f32x4*)m)[i] = mv;
+    ((f32x4*)v)[i] = vv;
+    ((f32x4*)p)[i] = pv;
+}
+
+}  // namespace
+
+extern "C" int sl_pack_weights(const float* w_master, void* w_fwd, void* w_dgrad, int k, int cin_pad, int cout_pad,
+                               int dtype, void* stream) {
+    SL_CHECK_ARG(k > 0 && cin_pad > 0 && cout_pad > 0 && cin_pad % 32 == 0 && cout_pad % 32 == 0,
+                 "sl_pack_weights: channel counts must be multiples of 32");
+    SL_CHECK_ARG(w_master && w_fwd, "sl_pack_weights: null pointer");
+    dim3 grid(cout_pad / 32, cin_pad / 32, k);
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL((pack_weights_kernel<unsigned short>), grid, dim3(256), 0, (hipStream_t)stream, w_master,
+                           (unsigned short*)w_fwd, (unsigned short*)w_dgrad, k, cin_pad, cout_pad);
+    else
+        hipLaunchKernelGGL((pack_weights_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, w_master,
+                           (float*)w_fwd, (float*)w_dgrad, k, cin_pad, cout_pad);
+    return sl_check_launch("sl_pack_weights");
+}
+
+extern "C" int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,
+                             int64_t dst_batch_stride, int dtype, void* stream) {
+    SL_CHECK_ARG(batch > 0 && t_in > 0 && f > 0 && dst_row_stride >= f, "sl_pack_input: bad sizes");
+    const long total = (long)batch * t_in * f;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL((pack_input_kernel<unsigned short>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src,
+                           (unsigned short*)dst, t_in, f, dst_row0, dst_row_stride, (long)dst_batch_stride, total);
+    else
+        hipLaunchKernelGGL((pack_input_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
+                           t_in, f, dst_row0, dst_row_stride, (long)dst_batch_stride, total);
+    return sl_check_launch("sl_pack_input");
+}
+
+extern "C" size_t sl_bias_grad_workspace_bytes(const sl_conv_geom* g) {
+    if (!g) return 0;
+    return (size_t)g->batch * g->cout * sizeof(float);
+}
+
+extern "C" int sl_bias_grad(const void* g, float* db, const sl_conv_geom* geom, int dtype, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    SL_CHECK_ARG(g && db && geom && workspace, "sl_bias_grad: null pointer");
+    SL_CHECK_ARG(geom->cout % 128 == 0, "sl_bias_grad: cout must be a multiple of 128");
+    if (workspace_bytes < sl_bias_grad_workspace_bytes(geom)) {
+        sl_set_error("sl_bias_grad: workspace too small");
+        return SL_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(geom->cout / 128, geom->batch);
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL((bias_grad_partial_kernel<unsigned short>), grid, dim3(256), 0, s, (const unsigned short*)g,
+                           (float*)workspace, geom->t_out, geom->cout, geom->y_row0, geom->y_row_stride,
+                           (long)geom->y_batch_stride);
+    else
+        hipLaunchKernelGGL((bias_grad_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)g,
+                           (float*)workspace, geom->t_out, geom->cout, geom->y_row0, geom->y_row_stride,
+                           (long)geom->y_batch_stride);
+    int rc = sl_check_launch("sl_bias_grad(partial)");
+    if (rc != SL_OK) return rc;
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((geom->cout + 255) / 256), dim3(256), 0, s,
+                       (const float*)workspace, db, geom->batch, geom->cout);
+    return sl_check_launch("sl_bias_grad(final)");
+}
+
+extern "C" int sl_adam_step(float* param, const float* grad, float* m, float* v, size_t n, int step, float lr,
+                            float beta1, float beta2, float eps, void* stream) {
+    SL_CHECK_ARG(param && grad && m && v, "sl_adam_step: null pointer");
+    SL_CHECK_ARG(n % 4 == 0 && step >= 1, "sl_adam_step: n must be a multiple of 4 and step >= 1");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    const long n4 = (long)(n / 4);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       m, v, n4, (float)lr_t, beta1, beta2, eps);
+    return sl_check_launch("sl_adam_step");
+}

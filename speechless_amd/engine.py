@@ -1,0 +1,471 @@
+"""Device-side engine of the Wav2Letter hot path: owns HBM buffers (torch tensors = plumbing only) and sequences the
+hand-written gfx950 kernels of libspeechless_hip.so for forward, CTC, backward, Adam.
+
+Reference path being replaced (paths relative to the reference root): the Keras graph built by
+speechless/net.py:291-341 (11 x Conv1D), :359-390 (loss_net, mean CTC loss, Adam 1e-4) and the two backend functions
+:350-357 / :456-459.
+
+HBM layout (see include/speechless_hip.h): every activation / gradient tensor is [B][HALO + Tt_pad + HALO][C_pad]
+channels-last with zero halo rows, zero rows beyond the valid time and zero padded channels, so that a SAME-padded
+conv tap is a row-shifted view.  The stride-2 first layer reads its input in the PAIR VIEW ([rows/2][2*C]).
+Master weights / gradients / Adam moments live in ONE flat fp32 buffer each (layer order), in the Keras kernel layout
+(k, Cin_pad, Cout_pad); the gradient buffer is what the data-parallel all-reduce operates on.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, lib
+
+HALO = 16
+TIME_TILE = 128
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class LayerSpec:
+    def __init__(self, name, kernel_size, stride, cin, cout, activation):
+        self.name = name
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.cin = cin
+        self.cout = cout
+        self.activation = activation
+
+
+def wav2letter_layer_specs(input_size_per_time_step, grapheme_set_size, activation="relu",
+                           output_activation="softmax", main_filter_count=250, out_filter_count=2000, inner_count=7,
+                           striding_kernel=48, inner_kernel=7, big_kernel=32):
+    """Topology of reference net.py:307-330 (spectrogram input).  Sizes are parameters only so that tests can build
+    shrunken stacks of the same structure."""
+    specs = [LayerSpec("striding_conv", striding_kernel, 2, input_size_per_time_step, main_filter_count, activation)]
+    for i in range(1, inner_count + 1):
+        specs.append(LayerSpec("inner_conv_{}".format(i), inner_kernel, 1, main_filter_count, main_filter_count,
+                               activation))
+    specs.append(LayerSpec("big_conv_1", big_kernel, 1, main_filter_count, out_filter_count, activation))
+    specs.append(LayerSpec("big_conv_2", 1, 1, out_filter_count, out_filter_count, activation))
+    specs.append(LayerSpec("output_conv", 1, 1, out_filter_count, grapheme_set_size, output_activation))
+    return specs
+
+
+def same_padding(t_in, kernel_size, stride):
+    """TF 'SAME': T_out = ceil(T/s); pad_total = max((T_out-1)*s + k - T, 0); extra padding goes right."""
+    t_out = -(-t_in // stride)
+    pad_total = max((t_out - 1) * stride + kernel_size - t_in, 0)
+    return t_out, pad_total // 2, pad_total - pad_total // 2
+
+
+class LayerPlan:
+    def __init__(self, index, spec, cin_pad, cout_pad, w_off, b_off):
+        self.index = index
+        self.spec = spec
+        self.cin_pad = cin_pad
+        self.cout_pad = cout_pad
+        k = spec.kernel_size
+        if spec.stride == 2:
+            if k % 2:
+                raise NotImplementedError("stride-2 layers need an even kernel size (pair view)")
+            self.taps_view = k // 2
+            self.cin_view = 2 * cin_pad
+            # pair view needs pad_left odd/even consistent with row offset; pad_left of SAME stride 2, even k is k/2-1
+            self.pad_left = (k - 2) // 2 if k >= 2 else 0
+            self.pad_right = None  # depends on T parity, not needed in the pair view
+        else:
+            self.taps_view = k
+            self.cin_view = cin_pad
+            self.pad_left = (k - 1) // 2
+            self.pad_right = (k - 1) - self.pad_left
+        self.w_off = w_off
+        self.w_numel = k * cin_pad * cout_pad
+        self.b_off = b_off
+
+
+class _Buffers:
+    """All HBM tensors of one (batch, frames) geometry."""
+
+    def __init__(self, eng, batch, t_in):
+        dev = eng.device
+        dt = eng.torch_dtype
+        p0 = eng.plans[0]
+        self.batch = batch
+        self.t_in = t_in
+        self.t_out, pad_l, _ = same_padding(t_in, p0.spec.kernel_size, p0.spec.stride)
+        assert pad_l == p0.pad_left
+        self.tt_pad = _round_up(self.t_out, TIME_TILE)
+        self.rows = HALO + self.tt_pad + HALO
+        self.rows0 = 2 * (self.tt_pad + p0.taps_view)
+        self.x0 = torch.zeros((batch, self.rows0, p0.cin_pad), dtype=dt, device=dev)
+        n = len(eng.plans)
+        self.y = [torch.zeros((batch, self.rows, p.cout_pad), dtype=dt, device=dev) for p in eng.plans[:-1]]
+        self.logits = torch.zeros((batch, self.tt_pad, eng.plans[-1].cout_pad), dtype=torch.float32, device=dev)
+        k = eng.grapheme_set_size
+        self.probs = torch.zeros((batch, self.t_out, k), dtype=torch.float32, device=dev)
+        self.logq = torch.zeros((batch, self.t_out, k), dtype=torch.float32, device=dev)
+        self.g = [None] * n  # allocated lazily by ensure_backward()
+        self.decoded = torch.zeros((batch, self.t_out), dtype=torch.int32, device=dev)
+        self.decoded_len = torch.zeros((batch,), dtype=torch.int32, device=dev)
+        self.frame_argmax = torch.zeros((batch, self.t_out), dtype=torch.int32, device=dev)
+        self.input_len = torch.zeros((batch,), dtype=torch.int32, device=dev)
+        self.loss = torch.zeros((batch,), dtype=torch.float32, device=dev)
+        self.fwd_geom = []
+        for p in eng.plans:
+            g = ConvGeom()
+            g.batch = batch
+            g.t_out = self.t_out
+            g.taps = p.taps_view
+            g.cin = p.cin_view
+            g.cout = p.cout_pad
+            if p.index == 0:
+                g.x_row0 = 0
+                g.x_row_stride = p.cin_view
+                g.x_batch_stride = self.rows0 * p.cin_pad
+            else:
+                g.x_row0 = HALO - p.pad_left
+                g.x_row_stride = p.cin_pad
+                g.x_batch_stride = self.rows * p.cin_pad
+            if p.index == n - 1:
+                g.y_row0 = 0
+                g.y_row_stride = p.cout_pad
+                g.y_batch_stride = self.tt_pad * p.cout_pad
+            else:
+                g.y_row0 = HALO
+                g.y_row_stride = p.cout_pad
+                g.y_batch_stride = self.rows * p.cout_pad
+            self.fwd_geom.append(g)
+        self.bwd_ready = False
+
+    def ensure_backward(self, eng):
+        if self.bwd_ready:
+            return
+        dev, dt = eng.device, eng.torch_dtype
+        L = lib()
+        n = len(eng.plans)
+        first = eng.frozen_layer_count
+        self.wgrad_geom = [None] * n
+        self.dgrad_geom = [None] * n
+        ws_bytes = 0
+        bias_ws = 0
+        for p in eng.plans[first:]:
+            self.g[p.index] = torch.zeros((self.batch, self.rows, p.cout_pad), dtype=dt, device=dev)
+            wg = ConvGeom()
+            f = self.fwd_geom[p.index]
+            for name, _ in ConvGeom._fields_:
+                setattr(wg, name, getattr(f, name))
+            wg.y_row0 = HALO
+            wg.y_row_stride = p.cout_pad
+            wg.y_batch_stride = self.rows * p.cout_pad
+            self.wgrad_geom[p.index] = wg
+            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(ctypes.byref(wg), eng.dtype_code))
+            bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
+            if p.index > first:
+                dg = ConvGeom()
+                dg.batch = self.batch
+                dg.t_out = self.t_out
+                dg.taps = p.spec.kernel_size
+                dg.cin = p.cout_pad
+                dg.cout = p.cin_pad
+                dg.x_row0 = HALO - p.pad_right
+                dg.x_row_stride = p.cout_pad
+                dg.x_batch_stride = self.rows * p.cout_pad
+                dg.y_row0 = HALO
+                dg.y_row_stride = p.cin_pad
+                dg.y_batch_stride = self.rows * p.cin_pad
+                self.dgrad_geom[p.index] = dg
+        self.wgrad_ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+        self.bias_ws = torch.empty((max(bias_ws, 16),), dtype=torch.uint8, device=dev)
+        self.ctc_ws = None
+        self.ctc_ws_lmax = -1
+        self.labels = None
+        self.label_len = torch.zeros((self.batch,), dtype=torch.int32, device=dev)
+        self.bwd_ready = True
+
+    def ensure_ctc(self, eng, l_max):
+        if self.ctc_ws is not None and l_max <= self.ctc_ws_lmax:
+            return
+        need = lib().raw("sl_ctc_workspace_bytes")(self.batch, self.t_out, l_max)
+        self.ctc_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=eng.device)
+        self.ctc_ws_lmax = l_max
+        self.labels = torch.zeros((self.batch, l_max), dtype=torch.int32, device=eng.device)
+
+
+class Engine:
+    """Forward / CTC / backward / Adam on one MI355X.  dtype 'bf16' (bf16 storage, fp32 accumulate, fp32 CTC) or
+    'f32' (parity path)."""
+
+    def __init__(self, specs, grapheme_set_size, dtype="bf16", device="cuda:0", ctc_epsilon=1e-8,
+                 frozen_layer_count=0, lr=1e-4, beta_1=0.9, beta_2=0.999, adam_epsilon=1e-8):
+        if not torch.cuda.is_available():
+            raise _lib.HipLibraryError("speechless_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                       "there is no CPU fallback for the hot path")
+        self.lib = lib()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        if dtype == "bf16":
+            self.torch_dtype, self.dtype_code = torch.bfloat16, _lib.SL_BF16
+        elif dtype == "f32":
+            self.torch_dtype, self.dtype_code = torch.float32, _lib.SL_F32
+        else:
+            raise ValueError("dtype must be 'bf16' or 'f32'")
+        self.specs = specs
+        self.grapheme_set_size = grapheme_set_size
+        self.ctc_epsilon = ctc_epsilon
+        self.frozen_layer_count = frozen_layer_count
+        self.lr, self.beta_1, self.beta_2, self.adam_epsilon = lr, beta_1, beta_2, adam_epsilon
+        self.adam_iterations = 0
+        for i, s in enumerate(specs):
+            if s.stride not in (1, 2) or (s.stride == 2 and i != 0):
+                raise NotImplementedError("only the first layer may stride (spectrogram-input stack, net.py:317)")
+            hidden_ok = s.activation == "relu" if i < len(specs) - 1 else s.activation == "softmax"
+            if not hidden_ok:
+                raise NotImplementedError(
+                    "HIP path supports relu hidden layers and a softmax output layer (got {!r} on {})".format(
+                        s.activation, s.name))
+        if specs[-1].cout != grapheme_set_size:
+            raise ValueError("output layer width must equal the grapheme set size")
+        self.plans = []
+        off = 0
+        cin_pad = _round_up(specs[0].cin, 32)
+        for i, s in enumerate(specs):
+            cout_pad = _round_up(s.cout, 128)
+            w_off = off
+            off += s.kernel_size * cin_pad * cout_pad
+            b_off = off
+            off += cout_pad
+            self.plans.append(LayerPlan(i, s, cin_pad, cout_pad, w_off, b_off))
+            cin_pad = cout_pad
+        self.param_numel = off
+        dev = self.device
+        self.params = torch.zeros((off,), dtype=torch.float32, device=dev)
+        self.grads = torch.zeros((off,), dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros((off,), dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros((off,), dtype=torch.float32, device=dev)
+        self.w_fwd = [torch.zeros((p.cout_pad, p.spec.kernel_size, p.cin_pad), dtype=self.torch_dtype, device=dev)
+                      for p in self.plans]
+        self.w_dgrad = [torch.zeros((p.cin_pad, p.spec.kernel_size, p.cout_pad), dtype=self.torch_dtype, device=dev)
+                        if p.index > 0 else None for p in self.plans]
+        self._packed_dirty = True
+        self._buffers = {}
+        self.cur = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def buffers(self, batch, t_in):
+        key = (batch, t_in)
+        buf = self._buffers.get(key)
+        if buf is None:
+            if len(self._buffers) >= 4:  # bound HBM use when many batch shapes are seen
+                self._buffers.pop(next(iter(self._buffers)))
+            buf = _Buffers(self, batch, t_in)
+            self._buffers[key] = buf
+        return buf
+
+    def layer_param_views(self, tensor, plan):
+        k = plan.spec.kernel_size
+        w = tensor[plan.w_off: plan.w_off + plan.w_numel].view(k, plan.cin_pad, plan.cout_pad)
+        b = tensor[plan.b_off: plan.b_off + plan.cout_pad]
+        return w, b
+
+    def bucket_ranges(self):
+        """Flat-gradient ranges in the order they become ready during backward: the three output layers first
+        (81 % of the bytes), then the rest."""
+        n = len(self.plans)
+        split = max(n - 3, self.frozen_layer_count)
+        ranges = [(self.plans[split].w_off, self.param_numel)]
+        if split > self.frozen_layer_count:
+            ranges.append((self.plans[self.frozen_layer_count].w_off, self.plans[split].w_off))
+        return ranges, split
+
+    # ------------------------------------------------------------------ weights
+    def set_weights(self, weights):
+        """weights: [(W (k,Cin,Cout), b (Cout,))] numpy, Keras layout."""
+        assert len(weights) == len(self.plans)
+        self.params.zero_()
+        for p, (w, b) in zip(self.plans, weights):
+            s = p.spec
+            if tuple(w.shape) != (s.kernel_size, s.cin, s.cout) or tuple(b.shape) != (s.cout,):
+                raise ValueError("weights of layer {} have shape {} / {}".format(s.name, w.shape, b.shape))
+            wv, bv = self.layer_param_views(self.params, p)
+            wv[:, :s.cin, :s.cout] = torch.as_tensor(np.ascontiguousarray(w, dtype=np.float32)).to(self.device)
+            bv[:s.cout] = torch.as_tensor(np.ascontiguousarray(b, dtype=np.float32)).to(self.device)
+        self._packed_dirty = True
+
+    def _unpad(self, tensor):
+        out = []
+        for p in self.plans:
+            s = p.spec
+            wv, bv = self.layer_param_views(tensor, p)
+            out.append((wv[:, :s.cin, :s.cout].contiguous().cpu().numpy(), bv[:s.cout].contiguous().cpu().numpy()))
+        return out
+
+    def get_weights(self):
+        return self._unpad(self.params)
+
+    def get_gradients(self):
+        return self._unpad(self.grads)
+
+    def repack_weights(self):
+        st = self._stream()
+        for p in self.plans:
+            wv, _ = self.layer_param_views(self.params, p)
+            wd = self.w_dgrad[p.index]
+            self.lib.call("sl_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
+                          wd.data_ptr() if wd is not None else None, p.spec.kernel_size, p.cin_pad, p.cout_pad,
+                          self.dtype_code, st)
+        self._packed_dirty = False
+
+    # ------------------------------------------------------------------ forward
+    def load_input(self, input_batch):
+        """input_batch: (B,T,F) numpy (any float dtype; the reference packs float64, net.py:583) or a float32 torch
+        tensor already resident in HBM."""
+        if isinstance(input_batch, np.ndarray):
+            src = torch.from_numpy(np.ascontiguousarray(input_batch, dtype=np.float32)).to(self.device,
+                                                                                            non_blocking=True)
+        else:
+            src = input_batch.to(device=self.device, dtype=torch.float32).contiguous()
+        batch, t_in, f = src.shape
+        if f != self.specs[0].cin:
+            raise ValueError("input has {} bins per frame, the net expects {}".format(f, self.specs[0].cin))
+        buf = self.buffers(batch, t_in)
+        p0 = self.plans[0]
+        self.lib.call("sl_pack_input", src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.pad_left, p0.cin_pad,
+                      buf.rows0 * p0.cin_pad, self.dtype_code, self._stream())
+        self.cur = buf
+        self._src_keepalive = src
+        return buf
+
+    def forward(self, input_batch=None):
+        """Runs the 11 conv layers + softmax.  Returns the probability tensor (B,T',K) fp32 in HBM."""
+        buf = self.load_input(input_batch) if input_batch is not None else self.cur
+        if self._packed_dirty:
+            self.repack_weights()
+        st = self._stream()
+        n = len(self.plans)
+        x = buf.x0
+        for p in self.plans:
+            last = p.index == n - 1
+            y = buf.logits if last else buf.y[p.index]
+            _, bias = self.layer_param_views(self.params, p)
+            self.lib.call("sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(), None,
+                          y.data_ptr(), ctypes.byref(buf.fwd_geom[p.index]),
+                          _lib.EPI_BIAS if last else _lib.EPI_BIAS_RELU, self.dtype_code, 1 if last else 0, st)
+            x = y
+        self.lib.call("sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
+                      buf.t_out, self.grapheme_set_size, self.plans[-1].cout_pad, self.ctc_epsilon, st)
+        return buf.probs
+
+    def set_input_lengths(self, prediction_lengths):
+        buf = self.cur
+        buf.input_len.copy_(torch.as_tensor(np.asarray(prediction_lengths, dtype=np.int32).reshape(-1)),
+                            non_blocking=True)
+
+    def greedy_decode(self, prediction_lengths=None):
+        """Greedy CTC decode of the current probabilities.  Returns (list of index lists, frame argmax (B,T') numpy)."""
+        buf = self.cur
+        if prediction_lengths is not None:
+            self.set_input_lengths(prediction_lengths)
+        k = self.grapheme_set_size
+        self.lib.call("sl_greedy_decode", buf.probs.data_ptr(), buf.input_len.data_ptr(), buf.decoded.data_ptr(),
+                      buf.decoded_len.data_ptr(), buf.frame_argmax.data_ptr(), buf.batch, buf.t_out, k, k - 1,
+                      self._stream())
+        dec = buf.decoded.cpu().numpy()
+        lens = buf.decoded_len.cpu().numpy()
+        return [list(map(int, dec[i, :lens[i]])) for i in range(buf.batch)], buf.frame_argmax.cpu().numpy()
+
+    # ------------------------------------------------------------------ loss + backward
+    def set_labels(self, label_batch, label_lengths, prediction_lengths):
+        """label_batch: int (B,Lmax) padded with anything (reference pads -1); lengths: (B,) or (B,1)."""
+        buf = self.cur
+        buf.ensure_backward(self)
+        labels = np.asarray(label_batch, dtype=np.int32)
+        lab_len = np.asarray(label_lengths, dtype=np.int32).reshape(-1)
+        if labels.ndim != 2 or labels.shape[0] != buf.batch:
+            raise ValueError("label batch must be (B, Lmax)")
+        k = self.grapheme_set_size
+        for i in range(buf.batch):
+            row = labels[i, :lab_len[i]]
+            if row.size and (row.min() < 0 or row.max() >= k - 1):
+                raise ValueError("label {} holds an index outside [0, {}) (blank is {})".format(i, k - 1, k - 1))
+        l_max = max(int(labels.shape[1]), 1)
+        if labels.shape[1] == 0:
+            labels = np.zeros((buf.batch, 1), dtype=np.int32)
+        buf.ensure_ctc(self, l_max)
+        if buf.labels.shape[1] != labels.shape[1]:
+            buf.labels = torch.zeros((buf.batch, labels.shape[1]), dtype=torch.int32, device=self.device)
+        buf.labels.copy_(torch.from_numpy(np.ascontiguousarray(labels)), non_blocking=True)
+        buf.label_len.copy_(torch.from_numpy(lab_len), non_blocking=True)
+        self.set_input_lengths(prediction_lengths)
+
+    def ctc(self, grad_scale=None, with_grad=True):
+        """Per-utterance CTC loss of the current probabilities (tensor (B,) in HBM) and, into g[last], the gradient
+        w.r.t. the output_conv logits of grad_scale * sum_b loss_b (default 1/B: Keras' mean, net.py:389)."""
+        buf = self.cur
+        buf.ensure_backward(self)
+        last = len(self.plans) - 1
+        if grad_scale is None:
+            grad_scale = 1.0 / buf.batch
+        l_max = buf.labels.shape[1]
+        self.lib.call("sl_ctc_loss_grad", buf.probs.data_ptr(), buf.logq.data_ptr(), buf.labels.data_ptr(),
+                      buf.label_len.data_ptr(), buf.input_len.data_ptr(), buf.loss.data_ptr(), buf.g[last].data_ptr(),
+                      buf.batch, buf.t_out, self.grapheme_set_size, l_max, HALO, self.plans[last].cout_pad,
+                      buf.rows * self.plans[last].cout_pad, self.dtype_code, self.ctc_epsilon, grad_scale,
+                      buf.ctc_ws.data_ptr(), buf.ctc_ws.numel(), self._stream())
+        return buf.loss
+
+    def backward(self, on_bucket_ready=None):
+        """wgrad / bias-grad / dgrad for every trainable layer, output layer first.  on_bucket_ready(i) is called
+        after the launches that complete gradient bucket i (see bucket_ranges) have been enqueued."""
+        buf = self.cur
+        st = self._stream()
+        first = self.frozen_layer_count
+        _, split = self.bucket_ranges()
+        for p in reversed(self.plans[first:]):
+            i = p.index
+            x = buf.x0 if i == 0 else buf.y[i - 1]
+            dw, db = self.layer_param_views(self.grads, p)
+            self.lib.call("sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), dw.data_ptr(),
+                          ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, buf.wgrad_ws.data_ptr(),
+                          buf.wgrad_ws.numel(), st)
+            self.lib.call("sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), ctypes.byref(buf.wgrad_geom[i]),
+                          self.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
+            if on_bucket_ready is not None and i == split:
+                on_bucket_ready(0)
+            if i > first:
+                self.lib.call("sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
+                              buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
+                              _lib.EPI_RELU_MASK, self.dtype_code, 0, st)
+        if on_bucket_ready is not None and split > first:
+            on_bucket_ready(1)
+
+    def adam_step(self):
+        self.adam_iterations += 1
+        self.lib.call("sl_adam_step", self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                      self.adam_v.data_ptr(), self.param_numel, self.adam_iterations, self.lr, self.beta_1,
+                      self.beta_2, self.adam_epsilon, self._stream())
+        self._packed_dirty = True
+
+    def train_step(self, input_batch, label_batch, label_lengths, prediction_lengths, reducer=None):
+        """One full optimisation step (forward, CTC, backward, [gradient all-reduce], Adam, weight repack).
+        Returns the per-utterance loss tensor (B,) in HBM (not synchronised)."""
+        self.load_input(input_batch)
+        self.set_labels(label_batch, label_lengths, prediction_lengths)
+        return self.train_step_resident(reducer)
+
+    def train_step_resident(self, reducer=None):
+        """Same, with input / labels / lengths already resident in HBM (bench.py's timed region)."""
+        self.forward()
+        world = reducer.world_size if reducer is not None else 1
+        loss = self.ctc(grad_scale=1.0 / (self.cur.batch * world))
+        if reducer is None:
+            self.backward()
+        else:
+            self.backward(on_bucket_ready=reducer.reduce_bucket)
+            reducer.wait_all()
+        self.adam_step()
+        self.repack_weights()
+        return loss

@@ -1,0 +1,475 @@
+"""Drop-in `Wav2Letter` for speechless.configuration, backed by the MI355X engine.
+
+Mirrors the API surface of the reference's speechless/net.py:117-607 as consumed by speechless/configuration.py
+(:96-139,:159-215), main.py (:121,:144,:202) and README.md (:85,:119): same constructor signature, `predict`,
+`test_and_predict`, `test_and_predict_batch(es)`, `test_and_predict_grouped_batches`, `predict_batch_greedily`,
+`prediction_batch`, `train`, `load_weights`, attributes `predictive_net`, `grapheme_encoding`,
+`input_to_prediction_length_ratio`, and the result types `ExpectationVsPrediction*` (net.py:22-114).
+
+All arithmetic (11 x Conv1D, softmax, CTC loss/gradient, greedy decode, Adam) runs in hand-written gfx950 kernels via
+speechless_amd.engine; this file is host plumbing (batch packing net.py:578-607, result objects, epoch loop).
+"""
+import logging
+import sys
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+
+from .engine import Engine, wav2letter_layer_specs
+from .grapheme_encoding import CtcGraphemeEncoding
+
+logger = logging.getLogger("results")
+if not logger.handlers:
+    logger.setLevel(logging.INFO)
+    _handler = logging.StreamHandler(sys.stdout)
+    _handler.setLevel(logging.INFO)
+    logger.addHandler(_handler)
+
+
+def log(obj):
+    logger.info(str(obj))
+
+
+def _average_or_nan(numbers):
+    return sum(numbers) / len(numbers) if len(numbers) else float("nan")
+
+
+def edit_distance(a, b):
+    """Levenshtein distance between two sequences (the reference uses the `editdistance` package, net.py:31-37)."""
+    a, b = list(a), list(b)
+    if len(a) < len(b):
+        a, b = b, a
+    previous = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        current = [i]
+        for j, y in enumerate(b, 1):
+            current.append(min(previous[j] + 1, current[j - 1] + 1, previous[j - 1] + (x != y)))
+        previous = current
+    return previous[-1]
+
+
+class Adam:
+    """Hyper-parameters of keras.optimizers.Adam as the reference constructs it (net.py:132: Adam(1e-4))."""
+
+    def __init__(self, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8):
+        self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
+
+
+class LabeledSpectrogram:
+    """Duck type of speechless.labeled_example.LabeledSpectrogram (labeled_example.py:63-71)."""
+
+    def __init__(self, id, label, spectrogram=None):
+        self.id = id
+        self.label = label
+        self._spectrogram = spectrogram
+
+    def z_normalized_transposed_spectrogram(self):
+        return self._spectrogram
+
+
+class ExpectationVsPrediction:
+    def __init__(self, expected, predicted, loss):
+        self.expected = expected
+        self.predicted = predicted
+        self.loss = loss
+        self.expected_letter_count = len(expected)
+        self.expected_words = expected.split()
+        self.expected_word_count = len(self.expected_words)
+        self.letter_error_count = edit_distance(expected, predicted)
+        self.word_error_count = edit_distance(self.expected_words, predicted.split())
+
+    @property
+    def letter_error_rate(self):
+        return self.letter_error_count / self.expected_letter_count
+
+    @property
+    def word_error_rate(self):
+        return self.word_error_count / self.expected_word_count
+
+    def __str__(self):
+        return 'Expected:  "{}"\nPredicted: "{}"\nErrors: {} letters ({}%), {} words ({}%), loss: {:.2f}.'.format(
+            self.expected, self.predicted, self.letter_error_count, round(self.letter_error_rate * 100),
+            self.word_error_count, round(self.word_error_rate * 100), self.loss)
+
+
+class ExpectationsVsPredictions:
+    def __init__(self, results):
+        self.results = results
+
+    @property
+    def average_letter_error_count(self):
+        return _average_or_nan([r.letter_error_count for r in self.results])
+
+    @property
+    def average_word_error_count(self):
+        return _average_or_nan([r.word_error_count for r in self.results])
+
+    @property
+    def average_letter_error_rate(self):
+        return _average_or_nan([r.letter_error_rate for r in self.results])
+
+    @property
+    def average_word_error_rate(self):
+        return _average_or_nan([r.word_error_rate for r in self.results])
+
+    @property
+    def average_loss(self):
+        return _average_or_nan([r.loss for r in self.results])
+
+    def summary_line(self):
+        return ("Average over {} examples: {:.1f} letter errors ({:.2f}%), {:.1f} word errors ({:.2f}%), "
+                "loss {:.2f}.").format(len(self.results), self.average_letter_error_count,
+                                       self.average_letter_error_rate * 100, self.average_word_error_count,
+                                       self.average_word_error_rate * 100, self.average_loss)
+
+    def __str__(self):
+        return "\n\n".join(str(r) for r in self.results) + "\n\n" + self.summary_line() + "\n\n"
+
+
+class ExpectationsVsPredictionsInBatches(ExpectationsVsPredictions):
+    def __init__(self, result_batches):
+        self.result_batches = result_batches
+        super().__init__([r for batch in result_batches for r in batch.results])
+
+    def __str__(self):
+        return "All batches: {}".format(self.summary_line())
+
+
+class ExpectationsVsPredictionsInGroupedBatches(ExpectationsVsPredictions):
+    def __init__(self, results_by_group_name):
+        self.result_batches_by_group_name = results_by_group_name
+        super().__init__([r for batches in results_by_group_name.values() for r in batches.results])
+
+    def __str__(self):
+        groups = "\n".join("{}: {}".format(name, batches)
+                           for name, batches in self.result_batches_by_group_name.items())
+        return "\n\n{}\n\nAll corpora: {}\n\n".format(groups, self.summary_line())
+
+
+class _ConvLayerHandle:
+    """What `predictive_net.layers[i]` needs to offer for net.py:237-269 style weight surgery."""
+
+    def __init__(self, net, index, name):
+        self._net, self._index, self.name = net, index, name
+        self.trainable = True
+
+    def get_weights(self):
+        return list(self._net.get_weights()[self._index])
+
+    def set_weights(self, kernel_and_bias):
+        weights = self._net.get_weights()
+        weights[self._index] = (np.asarray(kernel_and_bias[0], dtype=np.float32),
+                                np.asarray(kernel_and_bias[1], dtype=np.float32))
+        self._net.set_weights(weights)
+
+
+class PredictiveNet:
+    """Stand-in for the Keras Sequential the reference exposes as `Wav2Letter.predictive_net` (net.py:168)."""
+
+    def __init__(self, engine):
+        self._engine = engine
+        self.layers = [_ConvLayerHandle(self, i, s.name) for i, s in enumerate(engine.specs)]
+
+    def get_weights(self):
+        return self._engine.get_weights()
+
+    def set_weights(self, weights):
+        self._engine.set_weights(weights)
+
+    def save_weights(self, path):
+        """Keras writes HDF5 (net.py:572).  h5py is used when importable; otherwise the same per-layer
+        kernel/bias arrays go to an .npz next to the requested name."""
+        path = Path(path)
+        weights = self.get_weights()
+        try:
+            import h5py
+        except ImportError:
+            arrays = {}
+            for layer, (w, b) in zip(self.layers, weights):
+                arrays[layer.name + "/kernel"] = w
+                arrays[layer.name + "/bias"] = b
+            np.savez(str(path.with_suffix(".npz")), **arrays)
+            return
+        with h5py.File(str(path), "w") as f:
+            f.attrs["layer_names"] = [layer.name.encode("utf8") for layer in self.layers]
+            for layer, (w, b) in zip(self.layers, weights):
+                group = f.create_group(layer.name)
+                names = ["{}/kernel:0".format(layer.name), "{}/bias:0".format(layer.name)]
+                group.attrs["weight_names"] = [n.encode("utf8") for n in names]
+                group.create_dataset(names[0], data=w)
+                group.create_dataset(names[1], data=b)
+
+    def load_weights(self, path):
+        path = Path(path)
+        npz = path.with_suffix(".npz")
+        if npz.exists():
+            data = np.load(str(npz))
+            self.set_weights([(data[layer.name + "/kernel"], data[layer.name + "/bias"]) for layer in self.layers])
+            return
+        import h5py  # Keras HDF5 checkpoint (weights-epoch{N}.h5)
+        with h5py.File(str(path), "r") as f:
+            root = f["model_weights"] if "model_weights" in f else f
+            weights = []
+            for layer in self.layers:
+                group = root[layer.name]
+                names = [n.decode("utf8") if isinstance(n, bytes) else n for n in group.attrs["weight_names"]]
+                kernel = np.asarray(group[[n for n in names if "kernel" in n][0]])
+                bias = np.asarray(group[[n for n in names if "bias" in n][0]])
+                weights.append((kernel, bias))
+        self.set_weights(weights)
+
+
+class Wav2Letter:
+    """Speech-recognition network based on wav2letter (https://arxiv.org/pdf/1609.03193v2.pdf), MI355X engine."""
+
+    class InputNames:
+        input_batch = "input_batch"
+        label_batch = "label_batch"
+        prediction_lengths = "prediction_lenghts"  # (sic) reference net.py:123
+        label_lengths = "label_lenghts"  # (sic) reference net.py:124
+
+    def __init__(self, input_size_per_time_step, allowed_characters, use_raw_wave_input=False, activation="relu",
+                 output_activation="softmax", optimizer=None, dropout=None, load_model_from_directory=None,
+                 load_epoch=None, allowed_characters_for_loaded_model=None, frozen_layer_count=0,
+                 reinitialize_trainable_loaded_layers=False, use_asg=False, asg_transition_probabilities=None,
+                 asg_initial_probabilities=None, kenlm_directory=None,
+                 # --- extensions of this implementation (keyword-only in spirit) ---
+                 compute_dtype="bf16", device="cuda:0", seed=None, ctc_epsilon=1e-8, layer_sizes=None):
+        if frozen_layer_count > 0 and load_model_from_directory is None:
+            raise ValueError("Layers cannot be frozen if model is trained from scratch.")
+        if use_asg:
+            raise NotImplementedError("ASG is not yet implemented.")  # as reference net.py:396-399
+        if use_raw_wave_input:
+            raise NotImplementedError("raw-wave input (wave_conv, net.py:310-312) is outside the MI355X hot path")
+        if kenlm_directory is not None:
+            raise NotImplementedError("KenLM beam-search decoding (net.py:444-451) is outside the MI355X hot path")
+        if dropout is not None:
+            raise NotImplementedError("dropout (net.py:301-303) is not implemented on the HIP path yet")
+        self.kenlm_directory = kenlm_directory
+        self.grapheme_encoding = CtcGraphemeEncoding(allowed_characters=allowed_characters)
+        self.use_asg = use_asg
+        self.frozen_layer_count = frozen_layer_count
+        self.output_activation = output_activation
+        self.activation = activation
+        self.use_raw_wave_input = use_raw_wave_input
+        self.input_size_per_time_step = input_size_per_time_step
+        self.optimizer = optimizer if optimizer is not None else Adam(1e-4)
+        self.load_epoch = load_epoch
+        self.dropout = dropout
+        self.compute_dtype = compute_dtype
+        self.device = device
+        self.ctc_epsilon = ctc_epsilon
+        self._layer_sizes = dict(layer_sizes or {})
+        specs = wav2letter_layer_specs(input_size_per_time_step, self.grapheme_encoding.grapheme_set_size,
+                                       activation=activation, output_activation=output_activation,
+                                       **self._layer_sizes)
+        self.engine = Engine(specs, self.grapheme_encoding.grapheme_set_size, dtype=compute_dtype, device=device,
+                             ctc_epsilon=ctc_epsilon, frozen_layer_count=frozen_layer_count, lr=self.optimizer.lr,
+                             beta_1=self.optimizer.beta_1, beta_2=self.optimizer.beta_2,
+                             adam_epsilon=self.optimizer.epsilon)
+        self.engine.set_weights(self._glorot_uniform(specs, seed))
+        self.predictive_net = PredictiveNet(self.engine)
+        for layer in self.predictive_net.layers[:frozen_layer_count]:
+            layer.trainable = False
+        if frozen_layer_count > 0:
+            log("All but {} layers frozen.".format(len(specs) - frozen_layer_count))
+        self.prediction_phase_flag = 0.
+        if load_model_from_directory is not None:
+            self.load_weights(allowed_characters_for_loaded_model, load_epoch, load_model_from_directory,
+                              loaded_first_layers_count=frozen_layer_count if reinitialize_trainable_loaded_layers
+                              else None)
+
+    @staticmethod
+    def _glorot_uniform(specs, seed):
+        """Keras default initialisers: glorot_uniform kernels (limit sqrt(6/(fan_in+fan_out))), zero biases."""
+        rng = np.random.RandomState(seed)
+        weights = []
+        for s in specs:
+            limit = np.sqrt(6.0 / (s.kernel_size * s.cin + s.kernel_size * s.cout))
+            weights.append((rng.uniform(-limit, limit, size=(s.kernel_size, s.cin, s.cout)).astype(np.float32),
+                            np.zeros((s.cout,), dtype=np.float32)))
+        return weights
+
+    # ------------------------------------------------------------------ weights (net.py:184-269, 558-560)
+    @staticmethod
+    def model_file_name(epoch):
+        return "weights-epoch{}.h5".format(epoch)
+
+    @staticmethod
+    def indices_to_load_by_target_index(allowed_characters_for_loaded_model, allowed_characters):
+        ignored = set(allowed_characters_for_loaded_model) - set(allowed_characters)
+        if ignored:
+            log("Ignoring characters {} from loaded model.".format(sorted(ignored)))
+        extra = set(allowed_characters) - set(allowed_characters_for_loaded_model)
+        if extra:
+            log("Initializing extra characters {} not found in model.".format(sorted(extra)))
+        mapping = []
+        for character in allowed_characters:
+            hits = [i for i, c in enumerate(allowed_characters_for_loaded_model) if c == character]
+            assert len(hits) <= 1
+            mapping.append(hits[0] if hits else None)
+        log("Character mapping: {}".format(mapping))
+        return mapping
+
+    def load_weights(self, allowed_characters_for_loaded_model, load_epoch, load_model_from_directory,
+                     loaded_first_layers_count=None):
+        path = Path(load_model_from_directory) / self.model_file_name(load_epoch)
+        if allowed_characters_for_loaded_model is None:
+            self.predictive_net.load_weights(path)
+            return
+        layer_count = len(self.predictive_net.layers)
+        if loaded_first_layers_count is None:
+            loaded_first_layers_count = layer_count
+        original = Wav2Letter(self.input_size_per_time_step, allowed_characters_for_loaded_model,
+                              activation=self.activation, output_activation=self.output_activation,
+                              optimizer=self.optimizer, load_model_from_directory=load_model_from_directory,
+                              load_epoch=load_epoch, frozen_layer_count=self.frozen_layer_count,
+                              compute_dtype=self.compute_dtype, device=self.device, layer_sizes=self._layer_sizes)
+        log("Loading first {} layers of {}, epoch {}, reinitializing the last {}.".format(
+            loaded_first_layers_count, load_model_from_directory, load_epoch, layer_count - loaded_first_layers_count))
+        source = original.predictive_net.get_weights()
+        target = self.predictive_net.get_weights()
+        for index in range(loaded_first_layers_count):
+            kernel, bias = source[index]
+            if index == layer_count - 1:
+                mapping = self.indices_to_load_by_target_index(allowed_characters_for_loaded_model,
+                                                               self.grapheme_encoding.allowed_characters)
+                columns, biases = [], []
+                for target_index in range(self.grapheme_encoding.grapheme_set_size):
+                    source_index = original.grapheme_encoding.ctc_blank \
+                        if target_index == self.grapheme_encoding.ctc_blank else mapping[target_index]
+                    # reference quirk kept on purpose (net.py:254,258): `if index` also treats index 0 as missing
+                    if source_index:
+                        columns.append(kernel[:, :, source_index:source_index + 1])
+                        biases.append(bias[source_index])
+                    else:
+                        columns.append(np.zeros((kernel.shape[0], kernel.shape[1], 1), dtype=kernel.dtype))
+                        biases.append(0)
+                kernel = np.concatenate(columns, axis=2)
+                bias = np.array(biases, dtype=np.float32)
+            target[index] = (kernel, bias)
+        self.predictive_net.set_weights(target)
+
+    # ------------------------------------------------------------------ packing (net.py:343-348, 578-607)
+    @property
+    def input_to_prediction_length_ratio(self):
+        ratio = 1
+        for s in self.engine.specs:
+            ratio *= s.stride
+        return ratio
+
+    def _input_batch_and_prediction_lengths(self, spectrograms):
+        input_lengths = [s.shape[0] for s in spectrograms]
+        prediction_lengths = [n // self.input_to_prediction_length_ratio for n in input_lengths]
+        input_batch = np.zeros((len(spectrograms), max(input_lengths), spectrograms[0].shape[1]), dtype=np.float32)
+        for row, s in zip(input_batch, spectrograms):
+            row[:s.shape[0], :s.shape[1]] = s
+        return input_batch, prediction_lengths
+
+    def _input_dictionary_for_loss_net(self, labeled_spectrogram_batch):
+        spectrograms = [x.z_normalized_transposed_spectrogram() for x in labeled_spectrogram_batch]
+        labels = [x.label for x in labeled_spectrogram_batch]
+        input_batch, prediction_lengths = self._input_batch_and_prediction_lengths(spectrograms)
+        n = len(labeled_spectrogram_batch)
+        return {
+            Wav2Letter.InputNames.input_batch: input_batch,
+            Wav2Letter.InputNames.prediction_lengths: np.reshape(np.array(prediction_lengths), (n, 1)),
+            Wav2Letter.InputNames.label_batch: self.grapheme_encoding.encode_label_batch(labels),
+            Wav2Letter.InputNames.label_lengths: np.reshape(np.array([len(l) for l in labels]), (n, 1)),
+        }
+
+    # ------------------------------------------------------------------ inference (net.py:350-357, 461-498)
+    def prediction_batch(self, input_batch):
+        """Grapheme probabilities (B, T', K) for a (B, T, F) spectrogram batch."""
+        return self.engine.forward(np.asarray(input_batch)).cpu().numpy()
+
+    def predict_batch_greedily(self, spectrograms):
+        input_batch, prediction_lengths = self._input_batch_and_prediction_lengths(spectrograms)
+        self.engine.forward(input_batch)
+        decoded, _ = self.engine.greedy_decode(prediction_lengths)
+        return [self.grapheme_encoding.decode_graphemes(d, merge_repeated=False) for d in decoded]
+
+    def test_and_predict_batch(self, labeled_spectrogram_batch):
+        """ONE forward pass yields both the greedy transcription and the per-utterance CTC loss."""
+        inputs = self._input_dictionary_for_loss_net(labeled_spectrogram_batch)
+        names = Wav2Letter.InputNames
+        self.engine.forward(inputs[names.input_batch])
+        self.engine.set_labels(inputs[names.label_batch], inputs[names.label_lengths],
+                               inputs[names.prediction_lengths])
+        losses = self.engine.ctc().cpu().numpy()
+        decoded, _ = self.engine.greedy_decode()
+        predictions = [self.grapheme_encoding.decode_graphemes(d, merge_repeated=False) for d in decoded]
+        return ExpectationsVsPredictions(
+            [ExpectationVsPrediction(predicted=p, expected=x.label, loss=float(l))
+             for p, x, l in zip(predictions, labeled_spectrogram_batch, losses)])
+
+    def test_and_predict(self, labeled_spectrogram):
+        # the reference duplicates the example because TF fails on batches of one (net.py:491-495); kept for parity
+        return self.test_and_predict_batch([labeled_spectrogram, labeled_spectrogram]).results[0]
+
+    def predict(self, labeled_spectrogram):
+        return self.test_and_predict(labeled_spectrogram).predicted
+
+    def test_and_predict_batch_with_log(self, index, batch):
+        result = self.test_and_predict_batch(batch)
+        log(str(result) + " (batch {})".format(index))
+        return result
+
+    def test_and_predict_batches(self, labeled_spectrogram_batches):
+        return ExpectationsVsPredictionsInBatches(
+            [self.test_and_predict_batch_with_log(i, batch) for i, batch in enumerate(labeled_spectrogram_batches)])
+
+    def test_and_predict_batches_with_log(self, corpus_name, batches):
+        result = self.test_and_predict_batches(batches)
+        log("{}: {}".format(corpus_name, result))
+        return result
+
+    def test_and_predict_grouped_batches(self, grouped_labeled_spectrogram_batches):
+        return ExpectationsVsPredictionsInGroupedBatches(OrderedDict(
+            (name, self.test_and_predict_batches_with_log(corpus_name=name, batches=batches))
+            for name, batches in grouped_labeled_spectrogram_batches.items()))
+
+    # ------------------------------------------------------------------ training (net.py:541-576)
+    def train_on_batch(self, labeled_spectrogram_batch, reducer=None):
+        """One optimisation step; returns the mean CTC loss of the batch (what Keras' progress bar shows)."""
+        inputs = self._input_dictionary_for_loss_net(labeled_spectrogram_batch)
+        names = Wav2Letter.InputNames
+        losses = self.engine.train_step(inputs[names.input_batch], inputs[names.label_batch],
+                                        inputs[names.label_lengths], inputs[names.prediction_lengths],
+                                        reducer=reducer)
+        return float(losses.mean().item())
+
+    def train(self, labeled_spectrogram_batches, preview_labeled_spectrogram_batch, tensor_board_log_directory,
+              net_directory, batches_per_epoch, max_epochs=100000000, reducer=None):
+        """Epoch loop of reference net.py:541-576: preview, then epochs of `batches_per_epoch` steps starting at
+        `load_epoch or 0`; after every epoch the preview is logged and (epoch > 0) the weights are saved as
+        weights-epoch{N}.  Ends when the batch iterable is exhausted or after max_epochs (Keras: 1e8)."""
+        def print_preview_batch():
+            log(self.test_and_predict_batch(preview_labeled_spectrogram_batch))
+
+        print_preview_batch()
+        batches = iter(labeled_spectrogram_batches)
+        epoch = self.load_epoch if self.load_epoch is not None else 0
+        log_path = None
+        if tensor_board_log_directory is not None:
+            Path(tensor_board_log_directory).mkdir(parents=True, exist_ok=True)
+            log_path = Path(tensor_board_log_directory) / "loss.csv"
+        while epoch < max_epochs:
+            epoch_losses = []
+            for _ in range(batches_per_epoch):
+                batch = next(batches, None)
+                if batch is None:
+                    break
+                epoch_losses.append(self.train_on_batch(batch, reducer=reducer))
+            if len(epoch_losses) < batches_per_epoch:
+                break
+            if log_path is not None:
+                with log_path.open("a") as f:
+                    f.write("{},{}\n".format(epoch, _average_or_nan(epoch_losses)))
+            log("Epoch {}: loss {:.4f}".format(epoch, _average_or_nan(epoch_losses)))
+            print_preview_batch()
+            if epoch > 0:
+                Path(net_directory).mkdir(parents=True, exist_ok=True)
+                self.predictive_net.save_weights(Path(net_directory) / self.model_file_name(epoch))
+            epoch += 1

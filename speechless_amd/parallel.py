@@ -1,0 +1,64 @@
+"""Data-parallel gradient exchange: one process per GPU, utterances sharded across ranks, ONE exchange step per
+optimisation step -- a sum all-reduce of the flat fp32 gradient buffer (RCCL over xGMI when the tensors live in HBM;
+`torch.distributed` backend "nccl" IS RCCL on ROCm).
+
+The reference (juliuskunze/speechless) has no distributed code at all (single TF session, main.py:14-24); this is new.
+Utterances are independent through forward, CTC and backward and the loss is a mean over the batch (net.py:389), so
+gradients add: rank r computes d(sum_b loss_b)/dW scaled by 1/(B_local * world) and the all-reduce sums the ranks.
+
+xGMI is point-to-point, so one big ring all-reduce is per-link bound: the exchange is split into the buckets of
+Engine.bucket_ranges() and bucket 0 (output layers, 81 % of the bytes, ready first in backward) is reduced on a side
+stream while the remaining layers are still in backward.
+
+Device-agnostic on purpose: the same class runs over gloo on CPU tensors in tests/test_parallel.py.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucketReducer:
+    def __init__(self, flat_grads, ranges, process_group=None, overlap=True):
+        self.flat = flat_grads
+        self.ranges = list(ranges)
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.cuda = flat_grads.is_cuda
+        self.overlap = overlap and self.cuda
+        self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if self.overlap else None
+        self._pending = []
+
+    def reduce_bucket(self, index):
+        """Called when every kernel writing bucket `index` has been enqueued on the current stream."""
+        if self.world_size == 1:
+            return
+        lo, hi = self.ranges[index]
+        view = self.flat[lo:hi]
+        if self.overlap:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+            self._pending.append(done)
+        else:
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append(work)
+
+    def wait_all(self):
+        """Makes the current stream (or the host, on CPU) wait for every outstanding bucket."""
+        for p in self._pending:
+            if self.overlap:
+                torch.cuda.current_stream(self.flat.device).wait_event(p)
+            else:
+                p.wait()
+        self._pending = []
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous utterance shard of rank `rank` (rank r takes utterances [r*n/world, (r+1)*n/world))."""
+    per = total // world_size
+    rem = total % world_size
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)

@@ -1,0 +1,95 @@
+"""CPU tests of the host logic at the boundary: label codec (pinned by the REFERENCE's own module/tests through
+tests/golden/codec_golden.json), result objects, batch packing, C-ABI surface."""
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from speechless_amd.grapheme_encoding import (CtcGraphemeEncoding, english_frequent_characters,
+                                              german_frequent_characters)
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = json.loads((ROOT / "tests" / "golden" / "codec_golden.json").read_text(encoding="utf8"))
+
+
+def test_alphabets_match_reference():
+    assert english_frequent_characters == GOLDEN["english_frequent_characters"]
+    assert german_frequent_characters == GOLDEN["german_frequent_characters"]
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: c["alphabet"])
+def test_codec_matches_reference_outputs(case):
+    chars = GOLDEN[case["alphabet"] + "_frequent_characters"]
+    g = CtcGraphemeEncoding(chars)
+    assert g.grapheme_set_size == case["grapheme_set_size"]
+    assert g.ctc_blank == case["ctc_blank"]
+    for label, encoded in case["encode"].items():
+        assert g.encode(label) == encoded
+        assert g.decode_graphemes(g.encode(label), merge_repeated=False) == label  # test_grapheme_encoding.py:10-13
+    batch = g.encode_label_batch(case["encode_label_batch"]["labels"])
+    assert batch.dtype == np.int32 and batch.tolist() == case["encode_label_batch"]["result"]
+    for d in case["decode_graphemes"]:
+        assert g.decode_graphemes(d["graphemes"], merge_repeated=d["merge_repeated"]) == d["result"]
+    d = case["decode_prediction_batch"]
+    assert g.decode_prediction_batch(np.array(d["predictions"]), d["prediction_lengths"]) == d["result"]
+    assert case["test_encode_batch"]["result"] == ["abc", "ab"]  # test_grapheme_encoding.py:20-31
+
+
+def test_reference_collapse_example():
+    g = CtcGraphemeEncoding(english_frequent_characters)
+    graphemes = g.encode("sssshhhheeeee      wasn't thre") + [g.ctc_blank] + g.encode("eeeeee")
+    assert g.decode_graphemes(graphemes) == "she wasn't three"  # test_grapheme_encoding.py:15-18
+
+
+def test_unknown_character_raises_value_error():
+    with pytest.raises(ValueError):
+        CtcGraphemeEncoding(english_frequent_characters).encode("ä")
+
+
+def test_edit_distance_and_result_objects():
+    from speechless_amd.net import ExpectationVsPrediction, ExpectationsVsPredictions, edit_distance
+    assert edit_distance("kitten", "sitting") == 3
+    assert edit_distance([], ["a"]) == 1
+    assert edit_distance("abc", "abc") == 0
+    r = ExpectationVsPrediction(expected="she wasn't three", predicted="she wasnt tree", loss=1.5)
+    assert r.letter_error_count == 2 and r.word_error_count == 2
+    assert abs(r.letter_error_rate - 2 / 16) < 1e-12 and abs(r.word_error_rate - 2 / 3) < 1e-12
+    assert "loss: 1.50" in str(r)
+    rs = ExpectationsVsPredictions([r, ExpectationVsPrediction("a b", "a b", 0.5)])
+    assert rs.average_loss == 1.0 and "Average over 2 examples" in rs.summary_line()
+
+
+def test_same_padding_and_plan_geometry():
+    from speechless_amd.engine import LayerPlan, same_padding, wav2letter_layer_specs
+    assert same_padding(1000, 48, 2) == (500, 23, 23)
+    assert same_padding(999, 48, 2) == (500, 23, 24)
+    specs = wav2letter_layer_specs(128, 29)
+    p0 = LayerPlan(0, specs[0], 128, 256, 0, 0)
+    assert (p0.taps_view, p0.cin_view, p0.pad_left) == (24, 256, 23)
+    p9 = LayerPlan(8, specs[8], 256, 2048, 0, 0)
+    assert (p9.taps_view, p9.pad_left, p9.pad_right) == (32, 15, 16)
+
+
+def test_header_symbols_are_exported_and_bound():
+    """The C-ABI library loads and exports every symbol include/speechless_hip.h declares (no compute calls)."""
+    from speechless_amd import _lib
+    from speechless_amd.build import build
+    build()
+    header = (ROOT / "include" / "speechless_hip.h").read_text()
+    declared = set(re.findall(r"\b(sl_[a-z0-9_]+)\s*\(", header))
+    declared -= {"sl_status", "sl_dtype", "sl_epilogue", "sl_conv_geom"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    library = _lib.HipLibrary()
+    assert library.raw("sl_version")() == 1
+    # argument validation works without a GPU: a bad geometry is rejected before any launch
+    geom = _lib.ConvGeom()
+    rc = library.raw("sl_conv1d_nt")(1, 1, None, None, 1, geom, 0, 0, 0, None)
+    assert rc == -1 and "must be positive" in library.last_error()
+
+
+def test_product_code_never_imports_the_oracle():
+    for path in (ROOT / "speechless_amd").rglob("*.py"):
+        text = path.read_text()
+        assert "import oracle" not in text and "from oracle" not in text, path

@@ -1,0 +1,157 @@
+"""CPU tests of the oracle (oracle/w2l_oracle.py): golden vectors, independent cross-checks, finite differences."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import w2l_oracle as o
+from oracle import w2l_torch_cpu as tc
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def toy_specs():
+    return o.layer_specs(4, 5, main_filter_count=6, out_filter_count=8, striding_kernel=6, inner_kernel=3,
+                         big_kernel=4, inner_count=2)
+
+
+def rebuild_case(name):
+    g = np.load(str(GOLDEN / "stack_golden.npz"))
+    specs = toy_specs() if name == "toy" else o.layer_specs(128, 29)
+    weights = o.glorot_uniform_weights(specs, seed=2, dtype=np.float64)
+    weights = [(w, g["{}/bias{}".format(name, i)]) for i, (w, _) in enumerate(weights)]
+    return g, specs, weights
+
+
+@pytest.mark.parametrize("name", ["toy", "real"])
+def test_oracle_matches_committed_golden(name):
+    g, specs, weights = rebuild_case(name)
+    r = o.loss_and_gradients(specs, weights, g[name + "/x"].astype(np.float64), g[name + "/labels"],
+                             g[name + "/prediction_lengths"], g[name + "/label_lengths"])
+    np.testing.assert_allclose(r["probs"], g[name + "/probs"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(r["losses"], g[name + "/losses"], rtol=1e-9)
+    for i, (dw, db) in enumerate(r["grads"]):
+        np.testing.assert_allclose(np.linalg.norm(dw), g["{}/dw_norm{}".format(name, i)], rtol=1e-8)
+        np.testing.assert_allclose(db, g["{}/db{}".format(name, i)], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(dw[0, :4, :4], g["{}/dw_slice{}".format(name, i)], rtol=1e-7, atol=1e-12)
+    dec = o.greedy_decode_indices(r["probs"], g[name + "/prediction_lengths"])
+    for i, d in enumerate(dec):
+        assert d == list(g[name + "/decoded"][i][:g[name + "/decoded_lengths"][i]])
+
+
+def test_same_padding_rule():
+    assert o.same_padding(1000, 48, 2) == (500, 23, 23)
+    assert o.same_padding(999, 48, 2) == (500, 23, 24)
+    assert o.same_padding(500, 32, 1) == (500, 15, 16)
+    assert o.same_padding(500, 7, 1) == (500, 3, 3)
+    assert o.same_padding(500, 1, 1) == (500, 0, 0)
+
+
+def test_real_topology_counts():
+    specs = o.layer_specs(128, 29)
+    assert [s.name for s in specs] == ["striding_conv"] + ["inner_conv_%d" % i for i in range(1, 8)] + [
+        "big_conv_1", "big_conv_2", "output_conv"]
+    params = sum(s.kernel_size * s.cin * s.cout + s.cout for s in specs)
+    assert params == 24662529
+    flops = 2 * 500 * sum(s.kernel_size * s.cin * s.cout for s in specs)
+    assert abs(flops / 1e9 - 24.6565) < 1e-3
+
+
+def test_against_torch_autograd():
+    specs = toy_specs()
+    weights = o.glorot_uniform_weights(specs, 2, np.float64)
+    weights = [(w, np.random.RandomState(5 + i).randn(*b.shape) * 0.1) for i, (w, b) in enumerate(weights)]
+    x = np.random.RandomState(0).randn(3, 17, 4)
+    labels = np.array([[0, 1, 2], [3, 3, -1], [-1, -1, -1]])
+    pl, ll = [8, 7, 5], [3, 2, 0]
+    r = o.loss_and_gradients(specs, weights, x, labels, pl, ll)
+    t = tc.loss_and_gradients(specs, weights, x, labels, pl, ll)
+    np.testing.assert_allclose(r["losses"], t["losses"], rtol=2e-6)
+    for (dw, db), (tw, tb) in zip(r["grads"], t["grads"]):
+        assert np.abs(dw - tw).max() <= 5e-6 * np.abs(dw).max()
+        assert np.abs(db - tb).max() <= 5e-6 * np.abs(db).max()
+
+
+def test_ctc_against_brute_force_enumeration():
+    rng = np.random.RandomState(3)
+    k, blank = 4, 3
+    for t_len, label in [(4, [0, 1]), (5, [2, 2]), (5, [0, 1, 0]), (3, []), (6, [1, 1, 1]), (2, [0, 1, 2])]:
+        probs = rng.dirichlet(np.ones(k), size=t_len)
+        loss, _ = o.ctc_single(o.ctc_log_q(probs), label, blank)
+        bf = o.ctc_brute_force(probs, label, blank)
+        if np.isinf(bf):
+            assert np.isinf(loss)
+        else:
+            assert abs(loss - bf) < 1e-10
+
+
+def test_ctc_gradient_by_finite_differences():
+    rng = np.random.RandomState(4)
+    probs = rng.dirichlet(np.ones(5), size=(1, 7))
+    labels = np.array([[1, 1, 2]])
+    losses, dprobs = o.ctc_batch_cost(probs, labels, [6], [3])
+    h = 1e-6
+    for (t, c) in [(0, 1), (3, 4), (5, 2), (6, 0)]:
+        p2 = probs.copy()
+        p2[0, t, c] += h
+        l2, _ = o.ctc_batch_cost(p2, labels, [6], [3])
+        p3 = probs.copy()
+        p3[0, t, c] -= h
+        l3, _ = o.ctc_batch_cost(p3, labels, [6], [3])
+        fd = (l2[0] - l3[0]) / (2 * h)
+        assert abs(fd - dprobs[0, t, c]) < 1e-5 * max(1.0, abs(fd))
+    assert np.all(dprobs[0, 6:] == 0)  # frames >= prediction_length are never scored
+
+
+def test_weight_gradient_by_finite_differences():
+    specs = toy_specs()
+    weights = o.glorot_uniform_weights(specs, 2, np.float64)
+    x = np.random.RandomState(0).randn(2, 12, 4)
+    labels = np.array([[0, 1], [2, -1]])
+    args = (labels, [6, 5], [2, 1])
+    r = o.loss_and_gradients(specs, weights, x, *args)
+    h = 1e-6
+    for li, idx in [(0, (2, 1, 3)), (2, (1, 0, 5)), (3, (3, 2, 1)), (5, (0, 7, 4))]:
+        def loss_at(delta):
+            w2 = [(w.copy(), b.copy()) for w, b in weights]
+            w2[li][0][idx] += delta
+            return o.loss_and_gradients(specs, w2, x, *args)["mean_loss"]
+        fd = (loss_at(h) - loss_at(-h)) / (2 * h)
+        assert abs(fd - r["grads"][li][0][idx]) < 1e-6 + 1e-5 * abs(fd)
+
+
+def test_frozen_layers_get_no_gradient():
+    specs = toy_specs()
+    weights = o.glorot_uniform_weights(specs, 2, np.float64)
+    x = np.random.RandomState(0).randn(2, 12, 4)
+    full = o.loss_and_gradients(specs, weights, x, np.array([[0, 1], [2, -1]]), [6, 5], [2, 1])
+    r = o.loss_and_gradients(specs, weights, x, np.array([[0, 1], [2, -1]]), [6, 5], [2, 1], frozen_layer_count=3)
+    for li in range(3):
+        assert not r["grads"][li][0].any() and not r["grads"][li][1].any()
+    for li in range(3, len(specs)):
+        np.testing.assert_allclose(r["grads"][li][0], full["grads"][li][0])
+
+
+def test_bf16_rounding_is_round_to_nearest_even():
+    x = np.array([1.0, 1.00390625, 1.01171875, -2.5, 3.1415927, 1e-40, 65504.0], dtype=np.float32)
+    r = o.round_to_bf16(x)
+    import torch
+    np.testing.assert_array_equal(r, torch.tensor(x).to(torch.bfloat16).to(torch.float32).numpy())
+
+
+def test_greedy_decode_known_answers():
+    import json
+    kat = json.loads((GOLDEN / "codec_golden.json").read_text(encoding="utf8"))["tf_greedy_kat"]
+    logits = np.array(kat["logits_t_k"])[None]  # (1,T,K); argmax of logits == argmax of softmax
+    assert o.greedy_decode_indices(logits, [5], blank=1) == [kat["greedy_merge_repeated"]]
+    assert o.greedy_decode_indices(logits, [5], blank=1, merge_repeated=False) == [kat["greedy_no_merge"]]
+
+
+def test_keras_adam_first_steps():
+    p = np.array([1.0, -2.0])
+    g = np.array([0.5, -0.25])
+    m = np.zeros(2)
+    v = np.zeros(2)
+    p1, m1, v1 = o.keras_adam_step(p, g, m, v, 1)
+    # at step 1 the bias-corrected update is lr * sign(g) (up to epsilon)
+    np.testing.assert_allclose(p - p1, 1e-4 * np.sign(g), rtol=1e-5)
