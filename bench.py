@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py -- utterances/sec of the Wav2Letter training hot path (fwd + CTC + bwd + Adam) on N MI355X.
+
+Workload = BASELINE.json config 3 per GPU: synthetic 128-mel x 1000-frame batch of 32 utterances, labels
+L_i ~ U{20..200} over the 28 graphemes, random-init (glorot) Wav2Letter, bf16 activations/weights with fp32 accumulate
+and fp32 CTC.  A "step" = one full optimisation step over one batch: 11 conv layers forward, softmax, CTC loss and
+gradient, 10 dgrads + 11 wgrads + 11 bias grads, [gradient all-reduce over RCCL when N > 1], Adam, weight repack.
+Inputs, labels and lengths are resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+
+Rank 0 prints ONE JSON line (see the contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MEL, FRAMES, BATCH_PER_GPU, K_CLASSES = 128, 1000, 32, 29
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def layer_flops_per_utt(specs, t_out):
+    """Algorithmic (unpadded) forward FLOPs per utterance and layer: 2 * T' * k * Cin * Cout."""
+    return [2.0 * t_out * s.kernel_size * s.cin * s.cout for s in specs]
+
+
+def synthetic_batch(rank, batch):
+    """Config 3/4 generator: rank r takes utterances [32r, 32r+32) of the global stream."""
+    x = np.random.RandomState(1000 + rank).randn(batch, FRAMES, MEL).astype(np.float32)
+    rng = np.random.RandomState(2000 + rank)
+    lab_len = rng.randint(20, 201, size=batch)
+    labels = -np.ones((batch, int(lab_len.max())), dtype=np.int32)
+    for i, n in enumerate(lab_len):
+        labels[i, :n] = rng.randint(0, K_CLASSES - 1, size=n)
+    return x, labels, lab_len.astype(np.int32), np.full((batch,), FRAMES // 2, dtype=np.int32)
+
+
+def cpu_baseline(specs_oracle, weights, sample_utts=4, steps=2):
+    """The torch-CPU fp32 port of the same step (oracle/w2l_torch_cpu.py) timed on this node's host cores."""
+    import torch
+    from oracle import w2l_torch_cpu as tc
+    x, labels, lab_len, pred_len = synthetic_batch(0, sample_utts)
+    times = tc.timed_training_steps(specs_oracle, weights, x, labels, pred_len, lab_len, steps=steps, warmup=1)
+    best = min(times)
+    return {"value": sample_utts / best, "unit": "utterances/sec", "cores": int(torch.get_num_threads()),
+            "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": "{} utterances x {} frames, 1 warm-up + {} timed fwd+CTC+bwd+Adam steps (torch-CPU fp32, "
+                      "best step {:.2f} s)".format(sample_utts, FRAMES, steps, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra event-instrumented steps for the roofline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from oracle import w2l_oracle as o
+    from speechless_amd.engine import Engine, wav2letter_layer_specs
+    from speechless_amd.parallel import GradBucketReducer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node {} for --gpus {}".format(
+                args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = "cuda:{}".format(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    specs = wav2letter_layer_specs(MEL, K_CLASSES)
+    ospecs = o.layer_specs(MEL, K_CLASSES)
+    weights = o.glorot_uniform_weights(ospecs, seed=2, dtype=np.float32)  # same init on every rank
+    eng = Engine(specs, K_CLASSES, dtype="bf16", device=device)
+    eng.set_weights(weights)
+    x, labels, lab_len, pred_len = synthetic_batch(rank, BATCH_PER_GPU)
+    eng.load_input(torch.from_numpy(x).to(device))
+    eng.set_labels(labels, lab_len, pred_len)
+    reducer = None
+    if world > 1:
+        ranges, _ = eng.bucket_ranges()
+        reducer = GradBucketReducer(eng.grads, ranges)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = eng.train_step_resident(reducer)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.train_step_resident(reducer)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.mean().item())
+
+    # ---- roofline leg: a few more steps with HIP events around every launch (same stream as the kernels)
+    t_out = FRAMES // 2
+    fl = layer_flops_per_utt(specs, t_out)
+    eng.timeline = []
+    for _ in range(args.profile_steps):
+        eng.train_step_resident(reducer)
+    torch.cuda.synchronize()
+    per_tag = {}
+    for tag, start, stop in eng.timeline:
+        per_tag.setdefault(tag, []).append(start.elapsed_time(stop))
+    eng.timeline = None
+    avg_ms = {tag: float(np.mean(v)) for tag, v in per_tag.items()}
+    names = [s.name for s in specs]
+    # dominant kernel = conv_nt_bf16_kernel<BIAS_RELU, bf16 out>: the forward of the 10 hidden layers
+    fwd_tags = ["fwd:" + n for n in names[:-1]]
+    fwd_flops = sum(fl[:-1]) * BATCH_PER_GPU / len(fwd_tags)           # algorithmic FLOPs per launch (average)
+    fwd_ms = sum(avg_ms[t] for t in fwd_tags) / len(fwd_tags)            # average launch duration
+    achieved = fwd_flops / (fwd_ms * 1e-3) / 1e12
+    groups = {}
+    for prefix, flops_of in (("fwd", lambda i: fl[i]), ("dgrad", lambda i: fl[i]), ("wgrad", lambda i: fl[i])):
+        tags = [(i, prefix + ":" + n) for i, n in enumerate(names) if prefix + ":" + n in avg_ms]
+        ms = sum(avg_ms[t] for _, t in tags)
+        groups[prefix] = {"ms_per_step": ms, "tflops": sum(flops_of(i) for i, _ in tags) * BATCH_PER_GPU / (ms * 1e-3) / 1e12}
+    for other in ("ctc", "softmax", "adam"):
+        groups[other] = {"ms_per_step": avg_ms.get(other, 0.0)}
+    groups["bias_grad"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("bgrad:"))}
+    groups["pack_weights"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("pack:"))}
+    groups["big_conv_1"] = {k: avg_ms.get(k + ":big_conv_1") for k in ("fwd", "dgrad", "wgrad")}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    utt_per_s = BATCH_PER_GPU * world * args.steps / elapsed
+    fwdbwd_flops_per_utt = 3 * sum(fl) - fl[0]
+    result = {
+        "metric": "utterances/sec (fwd+bwd+CTC), 128-mel x 1000-frame batch",
+        "value": utt_per_s,
+        "unit": "utterances/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: Wav2Letter fwd+CTC+bwd+Adam step, random-init, 128-mel x 1000 "
+                               "frames, 32 utterances/GPU, labels U{20..200}, bf16 storage / fp32 accumulate / fp32 CTC",
+                   "global_batch": BATCH_PER_GPU * world, "frames": FRAMES, "mel": MEL,
+                   "parallelism": "dp{}".format(world)},
+        "final_mean_loss": final_loss,
+        "step_mfma_frac": utt_per_s * fwdbwd_flops_per_utt / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world),
+        "roofline": {"bound": "mfma", "kernel": "conv_nt_bf16_kernel<SL_EPI_BIAS_RELU,bf16-out> (forward of the 10 "
+                                                "hidden conv layers; average over its launches in a step)",
+                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                     "flops_per_launch": fwd_flops, "avg_launch_ms": fwd_ms},
+        "kernels": groups,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(ospecs, weights)
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,11 +116,12 @@ int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int d
                   int64_t dst_batch_stride, int dtype, void* stream);
 
 /* ---- output softmax (net.py:131,328-330) + the Keras ctc_batch_cost prologue log(p+eps) re-normalised -----------
- * logits: float[B][t_out][logit_stride] (first k valid).  probs,logq: float[B][t_out][k] dense.
+ * logits: float, row t of utterance b at logits + b*logit_batch_stride + t*logit_stride (first k valid).
+ * probs,logq: float[B][t_out][k] dense.
  * logq = log_softmax(log(probs + eps)) = what tf.nn.ctc_loss sees after its own softmax (net.py:405-406).
  */
 int sl_softmax_logq(const float* logits, float* probs, float* logq, int batch, int t_out, int k, int logit_stride,
-                    float eps, void* stream);
+                    int64_t logit_batch_stride, float eps, void* stream);
 
 /* ---- CTC loss and gradient (net.py:402-406: keras.backend.ctc_batch_cost -> tf.nn.ctc_loss) --------------------
  * labels: int32[B][l_max] (padding ignored, grapheme_enconding.py:28 uses -1); blank = k-1 (grapheme_enconding.py:125).

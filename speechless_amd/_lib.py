@@ -4,6 +4,11 @@ import ctypes
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
+# torch FIRST: its wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.  libspeechless_hip.so needs the same
+# SONAME, and a process must hold exactly ONE HIP runtime -- the one that owns the tensors' memory and streams.
+# Loading ours first would pull /opt/rocm's runtime in and torch would then find "no ROCm-capable device".
+import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+
 LIB_PATH = Path(__file__).resolve().parent / "libspeechless_hip.so"
 
 SL_BF16 = 0
@@ -44,7 +49,8 @@ SIGNATURES = {
     "sl_bias_grad": (c_int, [c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_void_p, c_size_t, c_void_p]),
     "sl_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sl_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
-    "sl_softmax_logq": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "sl_softmax_logq": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float,
+                                c_void_p]),
     "sl_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sl_ctc_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_float, c_void_p, c_size_t,

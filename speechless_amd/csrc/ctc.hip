@@ -28,10 +28,12 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 }
 
 __global__ void softmax_logq_kernel(const float* __restrict__ logits, float* __restrict__ probs,
-                                    float* __restrict__ logq, long frames, int k, int logit_stride, float eps) {
+                                    float* __restrict__ logq, long frames, int t_out, int k, int logit_stride,
+                                    long logit_batch_stride, float eps) {
     const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= frames) return;
-    const float* z = logits + f * logit_stride;
+    const long b = f / t_out;
+    const float* z = logits + b * logit_batch_stride + (f - b * t_out) * logit_stride;
     float m = -INFINITY;
     for (int i = 0; i < k; ++i) m = fmaxf(m, z[i]);
     float sum = 0.f;
@@ -340,11 +342,11 @@ __host__ int lattice_sp(int l_max) { return ((2 * l_max + 1) + 63) / 64 * 64; }
 }  // namespace
 
 extern "C" int sl_softmax_logq(const float* logits, float* probs, float* logq, int batch, int t_out, int k,
-                               int logit_stride, float eps, void* stream) {
+                               int logit_stride, int64_t logit_batch_stride, float eps, void* stream) {
     SL_CHECK_ARG(batch > 0 && t_out > 0 && k > 0 && logit_stride >= k, "sl_softmax_logq: bad sizes");
     const long frames = (long)batch * t_out;
     hipLaunchKernelGGL(softmax_logq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       logits, probs, logq, frames, k, logit_stride, eps);
+                       logits, probs, logq, frames, t_out, k, logit_stride, (long)logit_batch_stride, eps);
     return sl_check_launch("sl_softmax_logq");
 }
 

@@ -250,10 +250,24 @@ class Engine:
         self._packed_dirty = True
         self._buffers = {}
         self.cur = None
+        self.timeline = None
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _launch(self, tag, name, *args):
+        """One C-ABI call.  With self.timeline set (a list), brackets it with HIP events on the launch stream so
+        that bench.py can read per-kernel durations live (tag = logical kernel instance, e.g. 'fwd:big_conv_1')."""
+        if self.timeline is None:
+            self.lib.call(name, *args)
+            return
+        start = torch.cuda.Event(enable_timing=True)
+        stop = torch.cuda.Event(enable_timing=True)
+        start.record()
+        self.lib.call(name, *args)
+        stop.record()
+        self.timeline.append((tag, start, stop))
 
     def buffers(self, batch, t_in):
         key = (batch, t_in)
@@ -314,7 +328,7 @@ class Engine:
         for p in self.plans:
             wv, _ = self.layer_param_views(self.params, p)
             wd = self.w_dgrad[p.index]
-            self.lib.call("sl_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
+            self._launch("pack:" + p.spec.name, "sl_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
                           wd.data_ptr() if wd is not None else None, p.spec.kernel_size, p.cin_pad, p.cout_pad,
                           self.dtype_code, st)
         self._packed_dirty = False
@@ -333,7 +347,7 @@ class Engine:
             raise ValueError("input has {} bins per frame, the net expects {}".format(f, self.specs[0].cin))
         buf = self.buffers(batch, t_in)
         p0 = self.plans[0]
-        self.lib.call("sl_pack_input", src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.pad_left, p0.cin_pad,
+        self._launch("pack_input", "sl_pack_input", src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.pad_left, p0.cin_pad,
                       buf.rows0 * p0.cin_pad, self.dtype_code, self._stream())
         self.cur = buf
         self._src_keepalive = src
@@ -351,12 +365,13 @@ class Engine:
             last = p.index == n - 1
             y = buf.logits if last else buf.y[p.index]
             _, bias = self.layer_param_views(self.params, p)
-            self.lib.call("sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(), None,
+            self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(), None,
                           y.data_ptr(), ctypes.byref(buf.fwd_geom[p.index]),
                           _lib.EPI_BIAS if last else _lib.EPI_BIAS_RELU, self.dtype_code, 1 if last else 0, st)
             x = y
-        self.lib.call("sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
-                      buf.t_out, self.grapheme_set_size, self.plans[-1].cout_pad, self.ctc_epsilon, st)
+        self._launch("softmax", "sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
+                      buf.t_out, self.grapheme_set_size, self.plans[-1].cout_pad, buf.tt_pad * self.plans[-1].cout_pad,
+                      self.ctc_epsilon, st)
         return buf.probs
 
     def set_input_lengths(self, prediction_lengths):
@@ -370,7 +385,7 @@ class Engine:
         if prediction_lengths is not None:
             self.set_input_lengths(prediction_lengths)
         k = self.grapheme_set_size
-        self.lib.call("sl_greedy_decode", buf.probs.data_ptr(), buf.input_len.data_ptr(), buf.decoded.data_ptr(),
+        self._launch("decode", "sl_greedy_decode", buf.probs.data_ptr(), buf.input_len.data_ptr(), buf.decoded.data_ptr(),
                       buf.decoded_len.data_ptr(), buf.frame_argmax.data_ptr(), buf.batch, buf.t_out, k, k - 1,
                       self._stream())
         dec = buf.decoded.cpu().numpy()
@@ -410,7 +425,7 @@ class Engine:
         if grad_scale is None:
             grad_scale = 1.0 / buf.batch
         l_max = buf.labels.shape[1]
-        self.lib.call("sl_ctc_loss_grad", buf.probs.data_ptr(), buf.logq.data_ptr(), buf.labels.data_ptr(),
+        self._launch("ctc", "sl_ctc_loss_grad", buf.probs.data_ptr(), buf.logq.data_ptr(), buf.labels.data_ptr(),
                       buf.label_len.data_ptr(), buf.input_len.data_ptr(), buf.loss.data_ptr(), buf.g[last].data_ptr(),
                       buf.batch, buf.t_out, self.grapheme_set_size, l_max, HALO, self.plans[last].cout_pad,
                       buf.rows * self.plans[last].cout_pad, self.dtype_code, self.ctc_epsilon, grad_scale,
@@ -428,15 +443,15 @@ class Engine:
             i = p.index
             x = buf.x0 if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
-            self.lib.call("sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), dw.data_ptr(),
+            self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), dw.data_ptr(),
                           ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, buf.wgrad_ws.data_ptr(),
                           buf.wgrad_ws.numel(), st)
-            self.lib.call("sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), ctypes.byref(buf.wgrad_geom[i]),
+            self._launch("bgrad:" + p.spec.name, "sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), ctypes.byref(buf.wgrad_geom[i]),
                           self.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
             if on_bucket_ready is not None and i == split:
                 on_bucket_ready(0)
             if i > first:
-                self.lib.call("sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
+                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
                               buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
                               _lib.EPI_RELU_MASK, self.dtype_code, 0, st)
         if on_bucket_ready is not None and split > first:
@@ -444,7 +459,7 @@ class Engine:
 
     def adam_step(self):
         self.adam_iterations += 1
-        self.lib.call("sl_adam_step", self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+        self._launch("adam", "sl_adam_step", self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                       self.adam_v.data_ptr(), self.param_numel, self.adam_iterations, self.lr, self.beta_1,
                       self.beta_2, self.adam_epsilon, self._stream())
         self._packed_dirty = True

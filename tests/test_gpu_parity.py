@@ -1,0 +1,513 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the CPU oracle on
+the same seeded inputs; bit-exact for integer outputs (decoded indices), stated tolerances for floating point.
+
+Tolerances (relative to the oracle, fp32 reference semantics of Keras/TF):
+  f32 path : activations 1e-4 of layer max; loss 1e-5; gradients 1e-4 rel-L2                (north_star: 1e-3)
+  bf16 path: vs the oracle run with the SAME storage rounding points (bf16_mirror): loss 1e-3, gradients 2e-2 rel-L2;
+             vs the pure fp32 oracle: loss 1e-3 (north_star config 3), gradients reported in gpurun_out/parity.json.
+"""
+import ctypes
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import w2l_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+REPORT = {}
+
+
+def _report(key, value):
+    REPORT[key] = value
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    (out / "parity.json").write_text(json.dumps(REPORT, indent=1, sort_keys=True, default=float))
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def make_case(b=2, t=64, f=128, k=29, seed=0, sizes=None, bias_scale=0.05):
+    from speechless_amd.engine import wav2letter_layer_specs
+    sizes = sizes or {}
+    specs = wav2letter_layer_specs(f, k, **sizes)
+    ospecs = o.layer_specs(f, k, **sizes)
+    weights = o.glorot_uniform_weights(ospecs, seed=2, dtype=np.float32)
+    rng = np.random.RandomState(100 + seed)
+    weights = [(w, rng.uniform(-bias_scale, bias_scale, size=bb.shape).astype(np.float32)) for (w, bb) in weights]
+    x = np.random.RandomState(seed).randn(b, t, f).astype(np.float32)
+    t_out = -(-t // 2)
+    lrng = np.random.RandomState(seed + 1)
+    lab_len = [int(lrng.randint(1, max(2, min(t_out // 3, 200)))) for _ in range(b)]
+    labels = [list(lrng.randint(0, k - 1, size=n)) for n in lab_len]
+    pred_len = [t // 2 - (i % 3) for i in range(b)]
+    return dict(specs=specs, ospecs=ospecs, weights=weights, x=x, labels=o.pack_label_batch(labels),
+                label_lengths=lab_len, prediction_lengths=pred_len, k=k, t_out=t_out)
+
+
+def make_engine(case, dtype, **kw):
+    from speechless_amd.engine import Engine
+    eng = Engine(case["specs"], case["k"], dtype=dtype, **kw)
+    eng.set_weights(case["weights"])
+    return eng
+
+
+def layer_activation(eng, buf, index):
+    from speechless_amd.engine import HALO
+    s = eng.specs[index]
+    y = buf.y[index].float().cpu().numpy()
+    return y[:, HALO:HALO + buf.t_out, :s.cout], y
+
+
+def weights64(case):
+    return [(w.astype(np.float64), b.astype(np.float64)) for w, b in case["weights"]]
+
+
+# ------------------------------------------------------------------------------------------ forward
+@pytest.mark.parametrize("t", [64, 77])
+def test_forward_f32_layer_by_layer(t):
+    import torch
+    from speechless_amd.engine import HALO
+    case = make_case(b=3, t=t)
+    eng = make_engine(case, "f32")
+    probs = eng.forward(case["x"]).cpu().numpy()
+    torch.cuda.synchronize()
+    buf = eng.cur
+    ref_probs, xs, zs = o.forward_stack(case["ospecs"], weights64(case), case["x"].astype(np.float64), keep=True)
+    for i in range(len(case["specs"]) - 1):
+        got, raw = layer_activation(eng, buf, i)
+        want = np.maximum(zs[i], 0)
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err < 1e-4, "layer {} ({}) activation error {}".format(i, case["specs"][i].name, err)
+        # layout invariants: halo rows, rows past the valid time and padded channels stay zero
+        assert not raw[:, :HALO].any() and not raw[:, HALO + buf.t_out:].any()
+        assert not raw[:, :, case["specs"][i].cout:].any()
+    assert np.abs(probs - ref_probs).max() < 1e-5
+    np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
+
+
+def test_forward_bf16_matches_mirrored_oracle():
+    import torch
+    case = make_case(b=3, t=64)
+    eng = make_engine(case, "bf16")
+    probs = eng.forward(case["x"]).cpu().numpy()
+    torch.cuda.synchronize()
+    w32 = case["weights"]
+    ref_probs, xs, zs = o.forward_stack(case["ospecs"], w32, case["x"], bf16_mirror=True, keep=True)
+    worst = 0.0
+    for i in range(len(case["specs"]) - 1):
+        got, _ = layer_activation(eng, eng.cur, i)
+        want = o.round_to_bf16(np.maximum(zs[i], 0))
+        err = np.abs(got - want).max() / np.abs(want).max()
+        worst = max(worst, err)
+        assert err < 2e-2, "layer {} bf16 activation error {}".format(i, err)  # 1-2 bf16 ulps of the layer max
+    _report("fwd_bf16_vs_mirror_worst_layer_err", worst)
+    assert np.abs(probs - ref_probs).max() < 2e-3
+    exact = o.forward_stack(case["ospecs"], weights64(case), case["x"].astype(np.float64))
+    _report("fwd_bf16_vs_fp32_oracle_max_prob_err", float(np.abs(probs - exact).max()))
+
+
+def test_greedy_decode_bit_exact_f32_full_length():
+    """BASELINE config 2 semantics at 1000 frames (smaller batch so the float64 oracle finishes in seconds):
+    frame argmax and decoded label indices must equal the CPU oracle's exactly."""
+    case = make_case(b=2, t=1000, seed=3)
+    eng = make_engine(case, "f32")
+    probs = eng.forward(case["x"]).cpu().numpy()
+    pred_len = [500, 497]
+    decoded, frame_argmax = eng.greedy_decode(pred_len)
+    ref = o.forward_stack(case["ospecs"], weights64(case), case["x"].astype(np.float64))
+    ref_idx, margin = o.frame_argmax_and_margin(ref)
+    _report("config2_min_top1_top2_margin", float(margin.min()))
+    for i, n in enumerate(pred_len):
+        mism = np.nonzero(frame_argmax[i, :n] != ref_idx[i, :n])[0]
+        assert mism.size == 0, "argmax differs at frames {} (margins {})".format(mism[:5], margin[i, mism[:5]])
+        assert (frame_argmax[i, n:] == -1).all()
+    assert decoded == o.greedy_decode_indices(ref, pred_len)
+    # and the GPU decoder on the GPU's own probabilities agrees with the numpy twin on them
+    assert decoded == o.greedy_decode_indices(probs, pred_len)
+
+
+# ------------------------------------------------------------------------------------------ loss + gradients
+def run_loss_and_grads(eng, case):
+    import torch
+    eng.load_input(case["x"])
+    eng.set_labels(case["labels"], case["label_lengths"], case["prediction_lengths"])
+    eng.forward()
+    loss = eng.ctc()
+    eng.backward()
+    torch.cuda.synchronize()
+    return loss.cpu().numpy(), eng.get_gradients()
+
+
+@pytest.mark.parametrize("t", [64, 77])
+def test_loss_and_gradients_f32(t):
+    case = make_case(b=3, t=t, seed=5)
+    eng = make_engine(case, "f32")
+    losses, grads = run_loss_and_grads(eng, case)
+    ref = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), case["labels"],
+                               case["prediction_lengths"], case["label_lengths"])
+    np.testing.assert_allclose(losses, ref["losses"], rtol=1e-5)
+    worst = 0.0
+    for i, ((dw, db), (rw, rb)) in enumerate(zip(grads, ref["grads"])):
+        ew, eb = rel_l2(dw, rw), rel_l2(db, rb)
+        worst = max(worst, ew, eb)
+        assert ew < 1e-4 and eb < 1e-4, "layer {}: dW rel-L2 {}, db rel-L2 {}".format(i, ew, eb)
+    _report("grads_f32_worst_rel_l2_t{}".format(t), worst)
+
+
+def test_loss_and_gradients_bf16():
+    case = make_case(b=3, t=64, seed=5)
+    eng = make_engine(case, "bf16")
+    losses, grads = run_loss_and_grads(eng, case)
+    args = (case["labels"], case["prediction_lengths"], case["label_lengths"])
+    mirror = o.loss_and_gradients(case["ospecs"], case["weights"], case["x"], *args, bf16_mirror=True)
+    exact = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), *args)
+    np.testing.assert_allclose(losses, mirror["losses"], rtol=1e-3)
+    np.testing.assert_allclose(losses, exact["losses"], rtol=1e-3)  # north_star config 3: loss within 1e-3 of CPU
+    rep = {}
+    for i, ((dw, db), (mw, mb), (xw, xb)) in enumerate(zip(grads, mirror["grads"], exact["grads"])):
+        rep[case["specs"][i].name] = dict(dw_vs_mirror=rel_l2(dw, mw), db_vs_mirror=rel_l2(db, mb),
+                                          dw_vs_fp32=rel_l2(dw, xw), db_vs_fp32=rel_l2(db, xb))
+    _report("grads_bf16", rep)
+    # bf16 storage of the back-propagated signal is inherently noisy in a random-init net: the CPU oracle's own
+    # bf16 mirror deviates from exact fp32 by 0.1 % (output_conv) ... 16 % (striding_conv), and a 1e-6 perturbation of
+    # the weights moves the mirrored layer-0 gradient by 12 % (rounding decisions flip; measured in DESIGN.md).  The
+    # kernels themselves are exact (test_single_layer_kernels_with_exact_operands).  Criterion: the HIP path must be
+    # no noisier than the storage scheme itself.
+    for i, name in enumerate(s.name for s in case["specs"]):
+        r = rep[name]
+        scheme_w = rel_l2(mirror["grads"][i][0], exact["grads"][i][0])
+        scheme_b = rel_l2(mirror["grads"][i][1], exact["grads"][i][1])
+        assert r["dw_vs_fp32"] < 1.5 * scheme_w + 2e-3, (name, r, scheme_w)
+        assert r["db_vs_fp32"] < 1.5 * scheme_b + 2e-3, (name, r, scheme_b)
+    for name, tol in (("output_conv", 2e-3), ("big_conv_2", 1e-2), ("big_conv_1", 1.5e-2)):  # 81 % of the parameters
+        assert rep[name]["dw_vs_mirror"] < tol, (name, rep[name])
+    _report("loss_bf16_rel_err_vs_fp32", float(np.abs(losses / exact["losses"] - 1).max()))
+
+
+def test_frozen_layers_are_skipped():
+    case = make_case(b=2, t=64, seed=6)
+    eng = make_engine(case, "f32", frozen_layer_count=8)
+    _, grads = run_loss_and_grads(eng, case)
+    ref = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), case["labels"],
+                               case["prediction_lengths"], case["label_lengths"], frozen_layer_count=8)
+    for i, ((dw, db), (rw, rb)) in enumerate(zip(grads, ref["grads"])):
+        if i < 8:
+            assert not dw.any() and not db.any()
+        else:
+            assert rel_l2(dw, rw) < 1e-4
+
+
+def test_backward_is_deterministic():
+    import torch
+    case = make_case(b=4, t=128, seed=7)
+    eng = make_engine(case, "bf16")
+    run_loss_and_grads(eng, case)
+    first = eng.grads.clone()
+    run_loss_and_grads(eng, case)
+    assert torch.equal(first, eng.grads)
+
+
+# ------------------------------------------------------------------------------------------ CTC kernel alone
+def run_ctc_kernel(hip_lib, logits, labels, label_len, input_len, eps=1e-8):
+    import torch
+    from speechless_amd import _lib
+    b, t, k = logits.shape
+    dev = "cuda:0"
+    lg = torch.tensor(logits, dtype=torch.float32, device=dev)
+    probs = torch.zeros((b, t, k), dtype=torch.float32, device=dev)
+    logq = torch.zeros_like(probs)
+    lab = torch.tensor(labels, dtype=torch.int32, device=dev)
+    ll = torch.tensor(label_len, dtype=torch.int32, device=dev)
+    il = torch.tensor(input_len, dtype=torch.int32, device=dev)
+    loss = torch.zeros((b,), dtype=torch.float32, device=dev)
+    dl = torch.zeros((b, t, k), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    hip_lib.call("sl_softmax_logq", lg.data_ptr(), probs.data_ptr(), logq.data_ptr(), b, t, k, k, t * k, eps, st)
+    need = hip_lib.raw("sl_ctc_workspace_bytes")(b, t, lab.shape[1])
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    hip_lib.call("sl_ctc_loss_grad", probs.data_ptr(), logq.data_ptr(), lab.data_ptr(), ll.data_ptr(), il.data_ptr(),
+                 loss.data_ptr(), dl.data_ptr(), b, t, k, lab.shape[1], 0, k, t * k, _lib.SL_F32, eps, 1.0,
+                 ws.data_ptr(), need, st)
+    torch.cuda.synchronize()
+    return probs.cpu().numpy(), loss.cpu().numpy(), dl.cpu().numpy()
+
+
+def test_ctc_kernel_edge_cases(hip_lib):
+    rng = np.random.RandomState(9)
+    k, t = 7, 40
+    labels_list = [[0, 1, 2, 3], [4, 4, 4, 4, 4], [], [0, 5, 0, 5, 0, 5, 0], list(rng.randint(0, 6, size=19)),
+                   list(rng.randint(0, 6, size=30))]
+    input_len = [40, 40, 12, 13, 40, 25]  # last: 30 labels in 25 frames -> no valid alignment
+    logits = (rng.randn(len(labels_list), t, k) * 2).astype(np.float32)
+    labels = o.pack_label_batch([l if l else [-1] for l in labels_list])
+    lab_len = [len(l) for l in labels_list]
+    probs, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
+    ref_p = o.softmax(logits.astype(np.float64))
+    np.testing.assert_allclose(probs, ref_p, atol=2e-7)
+    ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
+    ref_dl = o.softmax_backward(ref_p, ref_dp)
+    assert np.isinf(ref_loss[5]) and np.isinf(loss[5])
+    np.testing.assert_allclose(loss[:5], ref_loss[:5], rtol=1e-5)
+    for i in range(len(labels_list)):
+        assert np.abs(dl[i] - ref_dl[i]).max() < 2e-5, i
+        assert not dl[i, input_len[i]:].any()
+
+
+def test_ctc_kernel_long_labels(hip_lib):
+    rng = np.random.RandomState(10)
+    k, t, b = 29, 500, 4
+    lab_len = [200, 137, 1, 60]
+    labels_list = [list(rng.randint(0, 28, size=n)) for n in lab_len]
+    logits = rng.randn(b, t, k).astype(np.float32)
+    labels = o.pack_label_batch(labels_list)
+    input_len = [500, 480, 500, 333]
+    _, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
+    ref_p = o.softmax(logits.astype(np.float64))
+    ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-5)
+    assert rel_l2(dl, o.softmax_backward(ref_p, ref_dp)) < 1e-3  # fp32 log-space lattice (|alpha| ~ 1e3, ulp 1e-4) vs float64 oracle
+
+
+# ------------------------------------------------------------------------------------------ decode, Adam
+def test_greedy_decode_known_answers(hip_lib):
+    import torch
+    kat = json.loads((ROOT / "tests" / "golden" / "codec_golden.json").read_text(encoding="utf8"))["tf_greedy_kat"]
+    probs = torch.tensor(o.softmax(np.array(kat["logits_t_k"])[None]), dtype=torch.float32, device="cuda:0")
+    il = torch.tensor([5], dtype=torch.int32, device="cuda:0")
+    out = torch.zeros((1, 5), dtype=torch.int32, device="cuda:0")
+    out_len = torch.zeros((1,), dtype=torch.int32, device="cuda:0")
+    hip_lib.call("sl_greedy_decode", probs.data_ptr(), il.data_ptr(), out.data_ptr(), out_len.data_ptr(), None, 1, 5,
+                 2, 1, torch.cuda.current_stream().cuda_stream)
+    assert int(out_len[0]) == 2 and out[0].tolist() == [0, 0, -1, -1, -1]  # test_ctc_decoders.py:40
+
+
+def test_greedy_decode_random_and_ties(hip_lib):
+    import torch
+    rng = np.random.RandomState(11)
+    b, t, k = 5, 333, 29
+    probs = rng.dirichlet(np.ones(k) * 0.3, size=(b, t)).astype(np.float32)
+    probs[0, :50] = 1.0 / k           # exact ties -> first index wins (numpy argmax semantics)
+    probs[1, 10:200, :] = 0
+    probs[1, 10:200, 28] = 1          # long blank run
+    probs[2, :, :] = 0
+    probs[2, :, 3] = 1                # one long repeat -> single symbol
+    lens = [333, 300, 333, 0, 1]
+    dev = "cuda:0"
+    p = torch.tensor(probs, device=dev)
+    il = torch.tensor(lens, dtype=torch.int32, device=dev)
+    out = torch.zeros((b, t), dtype=torch.int32, device=dev)
+    out_len = torch.zeros((b,), dtype=torch.int32, device=dev)
+    fa = torch.zeros((b, t), dtype=torch.int32, device=dev)
+    hip_lib.call("sl_greedy_decode", p.data_ptr(), il.data_ptr(), out.data_ptr(), out_len.data_ptr(), fa.data_ptr(), b,
+                 t, k, k - 1, torch.cuda.current_stream().cuda_stream)
+    ref = o.greedy_decode_indices(probs, lens)
+    got = [out[i, :int(out_len[i])].tolist() for i in range(b)]
+    assert got == ref
+    assert (out[3] == -1).all()
+
+
+def test_adam_matches_keras_formula(hip_lib):
+    import torch
+    rng = np.random.RandomState(12)
+    n = 4096
+    p = rng.randn(n).astype(np.float32)
+    m = np.zeros(n, dtype=np.float32)
+    v = np.zeros(n, dtype=np.float32)
+    tp, tm, tv = (torch.tensor(a, device="cuda:0") for a in (p, m, v))
+    rp, rm, rv = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for step in range(1, 4):
+        g = rng.randn(n).astype(np.float32)
+        tg = torch.tensor(g, device="cuda:0")
+        hip_lib.call("sl_adam_step", tp.data_ptr(), tg.data_ptr(), tm.data_ptr(), tv.data_ptr(), n, step, 1e-4, 0.9,
+                     0.999, 1e-8, torch.cuda.current_stream().cuda_stream)
+        rp, rm, rv = o.keras_adam_step(rp, g.astype(np.float64), rm, rv, step)
+    np.testing.assert_allclose(tp.cpu().numpy(), rp, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(tm.cpu().numpy(), rm, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(tv.cpu().numpy(), rv, rtol=2e-5, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_bf16_vs_f32_paths_agree():
+    """BASELINE config 3 shape (B=32, 128 mel x 1000 frames, labels <= 200): the bf16 MFMA path and the independently
+    written fp32 path (itself pinned to the oracle above) agree: loss within 1e-3, gradients within 2e-2 rel-L2,
+    batch-order equivariance, zero-gradient rows for never-scored frames."""
+    import torch
+    case = make_case(b=32, t=1000, seed=21)
+    results = {}
+    for dtype in ("f32", "bf16"):
+        eng = make_engine(case, dtype)
+        losses, _ = run_loss_and_grads(eng, case)
+        results[dtype] = (losses, eng.grads.clone(), eng.cur.probs.clone())
+        del eng
+        torch.cuda.empty_cache()
+    lf, gf, pf = results["f32"]
+    lb, gb, pb = results["bf16"]
+    assert np.isfinite(lf).all()
+    np.testing.assert_allclose(lb, lf, rtol=1e-3)
+    err = float(torch.linalg.norm(gb - gf) / torch.linalg.norm(gf))
+    _report("full_size_grad_rel_l2_bf16_vs_f32", err)
+    _report("full_size_loss_rel_err_bf16_vs_f32", float(np.abs(lb / lf - 1).max()))
+    agree = float((pb.argmax(-1) == pf.argmax(-1)).float().mean())
+    _report("full_size_argmax_agreement_bf16_vs_f32", agree)
+    assert err < 2e-2
+    assert agree > 0.97
+
+
+def test_full_size_batch_permutation_equivariance():
+    import torch
+    case = make_case(b=8, t=1000, seed=22)
+    eng = make_engine(case, "bf16")
+    l1, _ = run_loss_and_grads(eng, case)
+    g1 = eng.grads.clone()
+    perm = np.random.RandomState(0).permutation(8)
+    case2 = dict(case)
+    case2["x"] = case["x"][perm]
+    case2["labels"] = case["labels"][perm]
+    case2["label_lengths"] = [case["label_lengths"][i] for i in perm]
+    case2["prediction_lengths"] = [case["prediction_lengths"][i] for i in perm]
+    l2, _ = run_loss_and_grads(eng, case2)
+    np.testing.assert_array_equal(l1[perm], l2)  # per-utterance work is independent -> bitwise
+    assert float(torch.linalg.norm(eng.grads - g1) / torch.linalg.norm(g1)) < 1e-5  # sum order over b changes
+
+
+# ------------------------------------------------------------------------------------------ API surface
+def synthetic_examples(n, rng, f=128):
+    from speechless_amd.net import LabeledSpectrogram
+    words = ["she", "wasn't", "three", "abc", "xyz", "a", "it's", "zoo"]
+    out = []
+    for i in range(n):
+        t = int(rng.randint(120, 200))
+        label = " ".join(rng.choice(words, size=rng.randint(1, 4)))
+        out.append(LabeledSpectrogram(id="utt{}".format(i), label=label, spectrogram=rng.randn(t, f)))
+    return out
+
+
+def test_wav2letter_api_train_predict_save_load(tmp_path):
+    from speechless_amd import Wav2Letter, english_frequent_characters
+    from speechless_amd.net import Adam
+    rng = np.random.RandomState(13)
+    net = Wav2Letter(128, english_frequent_characters, optimizer=Adam(1e-3), seed=1)
+    assert net.input_to_prediction_length_ratio == 2
+    batch = synthetic_examples(4, rng)
+    before = net.test_and_predict_batch(batch)
+    assert len(before.results) == 4 and all(isinstance(r.predicted, str) for r in before.results)
+    assert isinstance(net.predict(batch[0]), str)
+    assert np.isfinite(net.test_and_predict(batch[0]).loss)
+    net.train([batch] * 12, preview_labeled_spectrogram_batch=batch[:2], tensor_board_log_directory=tmp_path / "tb",
+              net_directory=tmp_path / "nets", batches_per_epoch=4)
+    after = net.test_and_predict_batch(batch)
+    assert after.average_loss < before.average_loss
+    saved = sorted(p.name for p in (tmp_path / "nets").iterdir())
+    assert saved and all(name.startswith("weights-epoch") for name in saved)
+    net2 = Wav2Letter(128, english_frequent_characters, load_model_from_directory=tmp_path / "nets", load_epoch=2)
+    again = net2.test_and_predict_batch(batch)
+    assert [r.predicted for r in again.results] == [r.predicted for r in after.results]
+    probs = net2.prediction_batch(np.stack([e.z_normalized_transposed_spectrogram()[:120] for e in batch]))
+    assert probs.shape == (4, 60, 29)
+    assert net2.predict_batch_greedily([e.z_normalized_transposed_spectrogram() for e in batch]) == \
+        [r.predicted for r in again.results]
+
+
+def test_constructor_errors_match_reference():
+    from speechless_amd import Wav2Letter, english_frequent_characters
+    with pytest.raises(ValueError):
+        Wav2Letter(128, english_frequent_characters, frozen_layer_count=2)  # net.py:144-145
+    with pytest.raises(NotImplementedError):
+        Wav2Letter(128, english_frequent_characters, use_asg=True)  # net.py:396-399
+
+
+# ------------------------------------------------------------------------------------------ single kernels, exact inputs
+def _bf16_exact(rng, shape, scale=1.0):
+    """Random values that are exactly representable in bf16 (so bf16 and fp32 kernels see identical operands)."""
+    return o.round_to_bf16((rng.randn(*shape) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("layer", [0, 1, 8, 9, 10])
+def test_single_layer_kernels_with_exact_operands(dtype, layer):
+    """wgrad / bias-grad / dgrad / forward of ONE layer on operands that are exact in bf16: the only error left is the
+    fp32 accumulation order (and, for bf16 outputs, one final rounding)."""
+    import ctypes
+    import torch
+    from speechless_amd import _lib
+    from speechless_amd.engine import HALO
+    rng = np.random.RandomState(40 + layer)
+    case = make_case(b=3, t=150, seed=30)
+    eng = make_engine(case, dtype)
+    buf = eng.load_input(case["x"])
+    buf.ensure_backward(eng)
+    p = eng.plans[layer]
+    s = p.spec
+    t_out = buf.t_out
+    td = eng.torch_dtype
+    # ---- operands
+    if layer == 0:
+        x = _bf16_exact(rng, (3, 150, s.cin))
+        eng.load_input(x)
+        x_in = x
+    else:
+        x_in = np.maximum(_bf16_exact(rng, (3, t_out, s.cin)), 0)
+        xt = torch.zeros_like(buf.y[layer - 1])
+        xt[:, HALO:HALO + t_out, :s.cin] = torch.tensor(x_in).to(td)
+        buf.y[layer - 1].copy_(xt)
+    g = _bf16_exact(rng, (3, t_out, s.cout), 0.01)
+    gt = torch.zeros_like(buf.g[layer])
+    gt[:, HALO:HALO + t_out, :s.cout] = torch.tensor(g).to(td)
+    buf.g[layer].copy_(gt)
+    w = _bf16_exact(rng, (s.kernel_size, s.cin, s.cout), 0.05)
+    bias = _bf16_exact(rng, (s.cout,), 0.1)
+    weights = list(case["weights"])
+    weights[layer] = (w, bias)
+    eng.set_weights(weights)
+    eng.repack_weights()
+    st = torch.cuda.current_stream().cuda_stream
+    # ---- reference (float64)
+    dx_ref, dw_ref, db_ref = o.conv1d_backward(x_in.astype(np.float64), w.astype(np.float64), s.stride,
+                                               g.astype(np.float64))
+    # ---- wgrad + bias grad
+    dw_v, db_v = eng.layer_param_views(eng.grads, p)
+    eng.lib.call("sl_conv1d_wgrad", (buf.x0 if layer == 0 else buf.y[layer - 1]).data_ptr(), buf.g[layer].data_ptr(),
+                 dw_v.data_ptr(), ctypes.byref(buf.wgrad_geom[layer]), eng.dtype_code, buf.wgrad_ws.data_ptr(),
+                 buf.wgrad_ws.numel(), st)
+    eng.lib.call("sl_bias_grad", buf.g[layer].data_ptr(), db_v.data_ptr(), ctypes.byref(buf.wgrad_geom[layer]),
+                 eng.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
+    torch.cuda.synchronize()
+    dw = dw_v[:, :s.cin, :s.cout].cpu().numpy()
+    db = db_v[:s.cout].cpu().numpy()
+    assert rel_l2(dw, dw_ref) < 2e-6, ("wgrad", dtype, layer, rel_l2(dw, dw_ref))
+    assert rel_l2(db, db_ref) < 2e-6, ("bias grad", dtype, layer, rel_l2(db, db_ref))
+    full = dw_v.cpu().numpy()
+    assert not full[:, s.cin:, :].any() and not full[:, :, s.cout:].any()  # padded lanes stay zero
+    # ---- dgrad (with the ReLU mask of the layer input)
+    if layer > 0:
+        eng.lib.call("sl_conv1d_nt", buf.g[layer].data_ptr(), eng.w_dgrad[layer].data_ptr(), None,
+                     buf.y[layer - 1].data_ptr(), buf.g[layer - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[layer]),
+                     _lib.EPI_RELU_MASK, eng.dtype_code, 0, st)
+        torch.cuda.synchronize()
+        raw = buf.g[layer - 1].float().cpu().numpy()
+        got = raw[:, HALO:HALO + t_out, :s.cin]
+        want = dx_ref * (x_in > 0)
+        tol = 1e-5 if dtype == "f32" else 3e-3  # f32: sequential fp32 sum over up to 65536 terms; bf16: output rounding
+        assert rel_l2(got, want) < tol, ("dgrad", dtype, layer, rel_l2(got, want))
+        assert not raw[:, :HALO].any() and not raw[:, HALO + t_out:].any() and not raw[:, :, s.cin:].any()
+    # ---- forward
+    if layer < len(eng.plans) - 1:
+        eng.lib.call("sl_conv1d_nt", (buf.x0 if layer == 0 else buf.y[layer - 1]).data_ptr(),
+                     eng.w_fwd[layer].data_ptr(), eng.layer_param_views(eng.params, p)[1].data_ptr(), None,
+                     buf.y[layer].data_ptr(), ctypes.byref(buf.fwd_geom[layer]), _lib.EPI_BIAS_RELU, eng.dtype_code, 0,
+                     st)
+        torch.cuda.synchronize()
+        got = buf.y[layer].float().cpu().numpy()[:, HALO:HALO + t_out, :s.cout]
+        want = np.maximum(o.conv1d_preactivation(x_in.astype(np.float64), w.astype(np.float64),
+                                                 bias.astype(np.float64), s.stride), 0)
+        tol = 1e-5 if dtype == "f32" else 3e-3
+        assert rel_l2(got, want) < tol, ("forward", dtype, layer, rel_l2(got, want))
