@@ -146,6 +146,7 @@ def main():
     groups["bias_grad"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("bgrad:"))}
     groups["pack_weights"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("pack:"))}
     groups["big_conv_1"] = {k: avg_ms.get(k + ":big_conv_1") for k in ("fwd", "dgrad", "wgrad")}
+    groups["per_launch_ms"] = {t: round(v, 4) for t, v in sorted(avg_ms.items())}
 
     if rank != 0:
         if world > 1:

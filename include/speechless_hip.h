@@ -79,9 +79,15 @@ const char* sl_last_error(void);
  *   bias   : float[cout] or NULL (SL_EPI_BIAS*)
  *   mask   : same geometry as y, dtype (SL_EPI_RELU_MASK) or NULL
  *   y      : [B][rows][y_row_stride]; dtype, or float when out_f32 != 0
+ *   cfg    : 0 = library picks the tile shape / pipeline depth / split-K for this geometry (measured table);
+ *            otherwise wm | wn<<4 | stages<<8 | ksplit<<12 (work-group tile = 64*wm time rows x 64*wn channels),
+ *            used by the tuner and the tests.  bf16 only; ignored for SL_F32.
+ *   workspace: sl_conv1d_nt_workspace_bytes(geom, dtype, cfg) bytes (split-K partial tiles; 0 when not split).
  */
+size_t sl_conv1d_nt_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg);
 int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* mask, void* y,
-                 const sl_conv_geom* geom, int epilogue, int dtype, int out_f32, void* stream);
+                 const sl_conv_geom* geom, int epilogue, int dtype, int out_f32, int cfg, void* workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* ---- conv weight gradient -------------------------------------------------------------------------------------
  * Replaces: TF Conv2DBackpropFilter reached by autodiff from net.py:389,550.
@@ -89,9 +95,11 @@ int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* ma
  * geom: batch,taps,cin,cout,x_* as above; y_* describe g (y_row0 = g_row0, ...); t_out = valid rows of g
  * (rows >= t_out of g are zero by the layout invariant, so the kernel sums whole 64-row chunks).
  * Deterministic: split-K partials go to `workspace` and are reduced in a fixed order.
+ * cfg: 0 = library picks tile shape / ring depth / batch split (measured table); otherwise
+ *      wm | wn<<4 | stages<<8 | splits<<12 (tile = 64*wm input channels x 64*wn output channels; splits 0 = auto).
  */
-size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype);
-int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype,
+size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg);
+int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype, int cfg,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* bias gradient db[co] = sum_{b,t} g[b][g_row0+t][co] (fp32 out, deterministic two-stage).  Same autodiff site. */

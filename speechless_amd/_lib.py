@@ -41,10 +41,12 @@ class ConvGeom(ctypes.Structure):
 SIGNATURES = {
     "sl_version": (c_int, []),
     "sl_last_error": (c_char_p, []),
+    "sl_conv1d_nt_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int]),
     "sl_conv1d_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int, c_int,
-                             c_void_p]),
-    "sl_conv1d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int]),
-    "sl_conv1d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_void_p, c_size_t, c_void_p]),
+                             c_int, c_void_p, c_size_t, c_void_p]),
+    "sl_conv1d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int]),
+    "sl_conv1d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t,
+                                c_void_p]),
     "sl_bias_grad_workspace_bytes": (c_size_t, [POINTER(ConvGeom)]),
     "sl_bias_grad": (c_int, [c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_void_p, c_size_t, c_void_p]),
     "sl_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

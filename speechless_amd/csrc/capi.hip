@@ -29,42 +29,56 @@ static int check_geom(const sl_conv_geom* g, const char* who, int cin_mult, int 
     return SL_OK;
 }
 
+extern "C" size_t sl_conv1d_nt_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg) {
+    if (!geom || dtype != SL_BF16 || geom->taps <= 0 || geom->cin <= 0 || geom->cin % 64 || geom->cout <= 0 ||
+        geom->cout % 128 || geom->batch <= 0 || geom->t_out <= 0)
+        return 0;
+    return conv_nt_bf16_workspace_bytes(geom, cfg);
+}
+
 extern "C" int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* mask, void* y,
-                            const sl_conv_geom* geom, int epilogue, int dtype, int out_f32, void* stream) {
+                            const sl_conv_geom* geom, int epilogue, int dtype, int out_f32, int cfg, void* workspace,
+                            size_t workspace_bytes, void* stream) {
     int rc = check_geom(geom, "sl_conv1d_nt", 64, 128);
     if (rc != SL_OK) return rc;
     SL_CHECK_ARG(x && w && y, "sl_conv1d_nt: null tensor pointer");
     SL_CHECK_ARG(epilogue >= SL_EPI_NONE && epilogue <= SL_EPI_RELU_MASK, "sl_conv1d_nt: unknown epilogue %d", epilogue);
     if (epilogue == SL_EPI_BIAS || epilogue == SL_EPI_BIAS_RELU) SL_CHECK_ARG(bias, "sl_conv1d_nt: bias is null");
     if (epilogue == SL_EPI_RELU_MASK) SL_CHECK_ARG(mask, "sl_conv1d_nt: mask is null");
-    if (dtype == SL_BF16) return conv_nt_bf16(x, w, bias, mask, y, geom, epilogue, out_f32, (hipStream_t)stream);
+    if (dtype == SL_BF16)
+        return conv_nt_bf16(x, w, bias, mask, y, geom, epilogue, out_f32, cfg, workspace, workspace_bytes,
+                            (hipStream_t)stream);
     if (dtype == SL_F32) return conv_nt_f32(x, w, bias, mask, y, geom, epilogue, (hipStream_t)stream);
     sl_set_error("sl_conv1d_nt: unknown dtype %d", dtype);
     return SL_ERR_INVALID_ARGUMENT;
 }
 
-extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype) {
+extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg) {
     if (!geom || geom->taps <= 0 || geom->cin <= 0 || geom->cout <= 0 || geom->batch <= 0) return 0;
-    const int tile = dtype == SL_BF16 ? 128 : 64;
-    if (geom->cin % tile || geom->cout % tile) return 0;
-    const int splits = wgrad_split_count(geom, tile);
+    if (dtype == SL_BF16) {
+        if (geom->cin % 128 || geom->cout % 128) return 0;
+        return wgrad_tn_bf16_workspace_bytes(geom, cfg);
+    }
+    if (geom->cin % 64 || geom->cout % 64) return 0;
+    const int splits = wgrad_split_count(geom, 64);
     if (splits <= 1) return 0;
     return (size_t)splits * geom->taps * geom->cin * geom->cout * sizeof(float);
 }
 
-extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype,
+extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype, int cfg,
                                void* workspace, size_t workspace_bytes, void* stream) {
     SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32, "sl_conv1d_wgrad: unknown dtype %d", dtype);
     const int tile = dtype == SL_BF16 ? 128 : 64;
     int rc = check_geom(geom, "sl_conv1d_wgrad", tile, tile);
     if (rc != SL_OK) return rc;
     SL_CHECK_ARG(x && g && dw, "sl_conv1d_wgrad: null tensor pointer");
+    if (dtype == SL_BF16)
+        return wgrad_tn_bf16(x, g, dw, geom, cfg, (float*)workspace, workspace_bytes, (hipStream_t)stream);
     const int splits = wgrad_split_count(geom, tile);
-    const size_t need = sl_conv1d_wgrad_workspace_bytes(geom, dtype);
+    const size_t need = sl_conv1d_wgrad_workspace_bytes(geom, dtype, 0);
     if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
         sl_set_error("sl_conv1d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
         return SL_ERR_WORKSPACE_TOO_SMALL;
     }
-    if (dtype == SL_BF16) return wgrad_tn_bf16(x, g, dw, geom, (float*)workspace, splits, (hipStream_t)stream);
     return wgrad_tn_f32(x, g, dw, geom, (float*)workspace, splits, (hipStream_t)stream);
 }

@@ -57,10 +57,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
 
 // kernels' C++ entry points (called from capi.hip)
 int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
-                 int epilogue, int out_f32, hipStream_t s);
+                 int epilogue, int out_f32, int cfg, void* workspace, size_t workspace_bytes, hipStream_t s);
+size_t conv_nt_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
 int conv_nt_f32(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
                 int epilogue, hipStream_t s);
 int wgrad_split_count(const sl_conv_geom* g, int tile);
-int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits,
+int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, float* ws, size_t ws_bytes,
                   hipStream_t s);
+size_t wgrad_tn_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
 int wgrad_tn_f32(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits, hipStream_t s);

@@ -6,26 +6,30 @@
 // weights, its input gradient (autodiff from net.py:389,550).
 //
 // Mapping to CDNA4:
-//   * work-group = 128 time rows x 128 output channels, 4 waves (2x2), each wave a 64x64 patch = 4x4 MFMA
-//     v_mfma_f32_16x16x32_bf16 tiles; fp32 accumulators (64 VGPR/lane).
-//   * the contraction runs over (tap, 64-channel chunk): one step = one 128x64 activation tile (a plain row-shifted
-//     2-D tile of the halo'd channels-last tensor -> no im2col, no bounds checks) and one 128x64 weight tile.
-//   * both tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered, one barrier
-//     per step.  LDS rows are 128 B; the 16-B slot index is XOR-swizzled (on the SOURCE address, LDS image stays
-//     lane-linear as the DMA requires) so that every ds_read_b128 lane group hits 16 distinct bank slots.
-//   * D^T orientation: MFMA "A" = weights (rows = co), "B" = activations (cols = t), so each lane ends up holding
-//     16 CONSECUTIVE output channels of one time row -> the epilogue (bias + ReLU / ReLU-mask, bf16 convert) stores
-//     32 contiguous bytes per lane straight into the channels-last tensor.
+//   * work-group tile = (64*WM) time rows x (64*WN) output channels, WM*WN waves, each wave a 64x64 patch = 4x4
+//     v_mfma_f32_16x16x32_bf16 tiles with fp32 accumulators (64 VGPR/lane).  Tile shapes 128x128 (4 waves, 2 WG/CU),
+//     256x128 / 128x256 (8 waves) and 256x256 (16 waves, 1 WG/CU): bigger tiles halve the L2->LDS operand traffic
+//     per flop, which is what bounds the 128x128 tile (~16 TB/s at 1 PFLOP/s against a ~34 TB/s L2).
+//   * the contraction runs over (tap, 64-channel chunk): one step = one BMx64 activation tile (a plain row-shifted
+//     2-D tile of the halo'd channels-last tensor -> no im2col, no bounds checks) and one BNx64 weight tile.
+//   * tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip) through a STAGES-deep ring; the wait
+//     is a COUNTED s_waitcnt vmcnt(N) (never 0 in steady state) and the barrier a raw s_barrier, so STAGES-1 tiles
+//     stay in flight across barriers -- this is what makes the short-K layers (28 steps, one work-group per CU)
+//     stop being load-latency bound.
+//   * LDS rows are 128 B; the 16-B slot index is XOR-swizzled on the DMA *source* address (the LDS image must stay
+//     lane-linear) with a key chosen per operand so that every ds_read_b128 lane group hits 16 distinct bank slots.
+//   * D^T orientation: MFMA "A" = weights (rows = co), "B" = activations (cols = t), with the co rows of the four
+//     MFMA tiles interleaved so that each lane ends up with 16 CONSECUTIVE output channels of one time row: the
+//     epilogue (bias + ReLU / ReLU-mask, bf16 convert) stores 32 contiguous bytes per lane.
+//   * split-K (over taps x chunks) when the tile count cannot fill the chip (dgrad of big_conv_1: K = 65536, 64..256
+//     tiles): fp32 partial tiles go to a workspace and nt_splitk_epilogue_kernel reduces them in a fixed order and
+//     applies the epilogue (deterministic).
 //   * blockIdx -> tile mapping is XCD-aware: an XCD's work-groups share weight tiles in its private L2.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128;
-constexpr int BN = 128;
 constexpr int BK = 64;
-constexpr int TILE_BYTES = 128 * BK * 2;   // 16 KiB per operand tile
-constexpr int LDS_BYTES = 4 * TILE_BYTES;  // {X,W} x 2 buffers = 64 KiB -> 2 work-groups per CU
 
 struct NtArgs {
     const __bf16* x;
@@ -33,107 +37,154 @@ struct NtArgs {
     const float* bias;
     const __bf16* mask;
     void* y;
+    float* partial;  // split-K workspace [ksplit][batch][t_tiles*BM][cout]
     int batch, t_out, t_tiles, n_tiles;
     int x_row0, x_rs;
     long x_bs;
     int y_row0, y_rs;
     long y_bs;
+    int cout;
     int w_rs;    // taps * cin
     int chunks;  // cin / 64
     int nsteps;  // taps * chunks
+    int ksplit, steps_per_split;
 };
 
 __device__ __forceinline__ void glds16(const __bf16* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const SL_GLOBAL void*)gsrc, (SL_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void conv_nt_bf16_kernel(NtArgs a) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+enum { MODE_PARTIAL = 4 };  // besides the SL_EPI_* values: raw fp32 accumulators to the split-K workspace
+
+// IT = 16-row time tiles per wave (4: 64x64 wave patch, 2: 32x64 wave patch -> twice the waves per tile, half the DMA
+// instructions per wave: for the short layers that only have one work-group per CU)
+template <int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_bf16_kernel(NtArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = 16 * IT * WM;
+    constexpr int BN = 64 * WN;
+    constexpr int X_BYTES = BM * 128;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int XPW = (BM / 8) / NW;  // DMA instructions per wave per stage for the activation tile
+    constexpr int WPW = (BN / 8) / NW;  // ... and for the weight tile
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
+    constexpr int NI = XPW + WPW;
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1;  // which 64-row half (time)
-    const int wn = wave & 1;   // which 64-channel half (co)
+    const int wm = wave / WN;  // which 64-row block (time)
+    const int wn = wave % WN;  // which 64-channel block (co)
     const int g = lane >> 4;
 
     const int m_tiles = a.batch * a.t_tiles;
-    const int wg = xcd_remap(blockIdx.x, m_tiles * a.n_tiles);
-    const int n_tile = wg / m_tiles;
-    const int m_tile = wg - n_tile * m_tiles;
+    const int tiles = m_tiles * a.n_tiles;
+    const int id = xcd_remap(blockIdx.x, tiles * a.ksplit);
+    const int split = id / tiles;
+    const int tile = id - split * tiles;
+    const int n_tile = tile / m_tiles;
+    const int m_tile = tile - n_tile * m_tiles;
     const int b = m_tile / a.t_tiles;
     const int t0 = (m_tile - b * a.t_tiles) * BM;
     const int co0 = n_tile * BN;
+    const int s_begin = split * a.steps_per_split;
+    int n = a.nsteps - s_begin;
+    if (n > a.steps_per_split) n = a.steps_per_split;
 
-    // ---- staging addresses: wave `wave` DMA-copies rows [wave*32, wave*32+32) of both tiles, 8 rows per instruction
-    const int srow = wave * 32 + (lane >> 3);                // + q*8
-    const int xchunk = (lane & 7) ^ (lane >> 3);             // slot ^ (row & 7)
-    const __bf16* xsrc = a.x + (long)b * a.x_bs + (long)(a.x_row0 + t0 + srow) * a.x_rs + xchunk * 8;
-    const __bf16* wsrc = a.w + (long)(co0 + srow) * a.w_rs;
-    int wchunk[4];
+    // ---- staging: DMA instruction j copies rows [8j, 8j+8) of a tile (lane -> row 8j + lane/8, 16-B slot lane%8)
+    const __bf16* xbase = a.x + (long)b * a.x_bs + (long)(a.x_row0 + t0) * a.x_rs;
+    const __bf16* wbase = a.w + (long)co0 * a.w_rs;
+    int xoff[XPW], woff[WPW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = wave * 32 + q * 8 + (lane >> 3);
-        const int key = ((row >> 1) & 1) | (((row >> 4) & 3) << 1);
-        wchunk[q] = ((lane & 7) ^ key) * 8;
+    for (int q = 0; q < XPW; ++q) {
+        const int row = (wave * XPW + q) * 8 + (lane >> 3);
+        xoff[q] = row * a.x_rs + (((lane & 7) ^ (lane >> 3)) << 3);  // slot ^ (row & 7)
     }
-    const long x_q_stride = 8L * a.x_rs;
-    const long w_q_stride = 8L * a.w_rs;
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+        const int j = wave * WPW + q;
+        const int row = j * 8 + (lane >> 3);
+        const int key = ((lane >> 4) & 1) | (((j >> 1) & 3) << 1);  // ((row>>1)&1) | (((row>>4)&3)<<1)
+        woff[q] = row * a.w_rs + (((lane & 7) ^ key) << 3);
+    }
 
     auto stage = [&](int step, int buf) {
         const int tap = step / a.chunks;
         const int cc = step - tap * a.chunks;
-        const __bf16* xs = xsrc + (long)tap * a.x_rs + cc * BK;
-        const __bf16* ws = wsrc + (long)step * BK;
-        char* xl = smem + buf * (2 * TILE_BYTES) + wave * (32 * 128);
-        char* wl = xl + TILE_BYTES;
+        const __bf16* xs = xbase + (long)tap * a.x_rs + cc * BK;
+        const __bf16* ws = wbase + (long)step * BK;
+        char* xl = smem + buf * STAGE_BYTES + (wave * XPW) * 1024;
+        char* wl = smem + buf * STAGE_BYTES + X_BYTES + (wave * WPW) * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            glds16(xs + q * x_q_stride, xl + q * 1024);
-            glds16(ws + q * w_q_stride + wchunk[q], wl + q * 1024);
-        }
+        for (int q = 0; q < XPW; ++q) glds16(xs + xoff[q], xl + q * 1024);
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) glds16(ws + woff[q], wl + q * 1024);
     };
 
     // ---- fragment read addresses
-    const int brow = wm * 64 + (lane & 15);                                    // + it*16
-    const int arow = wn * 64 + ((lane & 15) >> 2) * 16 + (lane & 3);           // + jn*4
+    const int brow = wm * (16 * IT) + (lane & 15);                    // + it*16
+    const int arow = wn * 64 + ((lane & 15) >> 2) * 16 + (lane & 3);  // + jn*4
     const int bkey = lane & 7;
     const int akey = ((lane >> 1) & 1) | (((lane >> 2) & 3) << 1);
     const int boff = brow * 128 + ((g ^ bkey) << 4);
-    const int aoff = arow * 128 + ((g ^ akey) << 4);
+    const int aoff = X_BYTES + arow * 128 + ((g ^ akey) << 4);
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][IT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < IT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    for (int s = 0; s < a.nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < a.nsteps) stage(s + 1, (s + 1) & 1);
-        const char* xl = smem + (s & 1) * (2 * TILE_BYTES);
-        const char* wl = xl + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < STAGES - 1; ++i)
+        if (i < n) stage(s_begin + i, i);
+    int cur = 0;            // ring slot of tile i
+    int nxt = STAGES - 1;   // ring slot tile i+STAGES-1 goes to
+    for (int i = 0; i < n; ++i) {
+        if (i + STAGES - 1 <= n)
+            wait_vmcnt<NI*(STAGES - 2)>();  // tile i has landed; the STAGES-2 younger tiles stay in flight
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();       // everyone's share of tile i landed; everyone finished reading slot nxt
+        asm volatile("" ::: "memory");
+        if (i + STAGES - 1 < n) stage(s_begin + i + STAGES - 1, nxt);
+        const char* sl = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[4], bfr[IT];
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) af[jn] = *(const bf16x8*)(wl + ((aoff + jn * 512) ^ (kk << 6)));
+            for (int jn = 0; jn < 4; ++jn) af[jn] = *(const bf16x8*)(sl + ((aoff + jn * 512) ^ (kk << 6)));
 #pragma unroll
-            for (int it = 0; it < 4; ++it) bfr[it] = *(const bf16x8*)(xl + ((boff + it * 2048) ^ (kk << 6)));
+            for (int it = 0; it < IT; ++it) bfr[it] = *(const bf16x8*)(sl + ((boff + it * 2048) ^ (kk << 6)));
 #pragma unroll
             for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-                for (int it = 0; it < 4; ++it)
+                for (int it = 0; it < IT; ++it)
                     acc[jn][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn][it], 0, 0, 0);
         }
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
 
     // ---- epilogue: lane holds, for each it, 16 consecutive channels co_base..co_base+15 of time row t
     const int co_base = co0 + wn * 64 + g * 16;
+    if (MODE == MODE_PARTIAL) {
+        float* out = a.partial +
+                     ((long)(split * a.batch + b) * (a.t_tiles * BM) + t0 + wm * (16 * IT) + (lane & 15)) * a.cout + co_base;
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) *(f32x4*)(out + (long)(it * 16) * a.cout + jn * 4) = acc[jn][it];
+        return;
+    }
     float bias_v[16];
-    if (EPI == SL_EPI_BIAS || EPI == SL_EPI_BIAS_RELU) {
+    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4 bv = *(const f32x4*)(a.bias + co_base + i * 4);
@@ -144,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void conv_nt_bf16_kernel(NtArgs a) {
         }
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int t = t0 + wm * 64 + it * 16 + (lane & 15);
+    for (int it = 0; it < IT; ++it) {
+        const int t = t0 + wm * (16 * IT) + it * 16 + (lane & 15);
         if (t >= a.t_out) continue;
         const long yidx = (long)b * a.y_bs + (long)(a.y_row0 + t) * a.y_rs + co_base;
         float v[16];
@@ -153,15 +204,15 @@ __global__ __launch_bounds__(256, 2) void conv_nt_bf16_kernel(NtArgs a) {
         for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[jn * 4 + r] = acc[jn][it][r];
-        if (EPI == SL_EPI_BIAS || EPI == SL_EPI_BIAS_RELU) {
+        if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] += bias_v[i];
         }
-        if (EPI == SL_EPI_BIAS_RELU) {
+        if (MODE == SL_EPI_BIAS_RELU) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        if (EPI == SL_EPI_RELU_MASK) {
+        if (MODE == SL_EPI_RELU_MASK) {
             const u32x4 m0 = *(const u32x4*)(a.mask + yidx);
             const u32x4 m1 = *(const u32x4*)(a.mask + yidx + 8);
 #pragma unroll
@@ -194,53 +245,230 @@ __global__ __launch_bounds__(256, 2) void conv_nt_bf16_kernel(NtArgs a) {
     }
 }
 
-template <int EPI, bool OUT_F32>
-int launch_one(const NtArgs& a, hipStream_t s) {
+// split-K tail: out = epi(sum_split partial), 8 channels per thread, fixed summation order
+template <int MODE, bool OUT_F32>
+__global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int rows_per_batch) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = a.cout / 8;
+    const long total = (long)a.batch * a.t_out * c8;
+    if (i >= total) return;
+    const int co = (int)(i % c8) * 8;
+    const long r = i / c8;
+    const int t = (int)(r % a.t_out);
+    const int b = (int)(r / a.t_out);
+    const long split_stride = (long)a.batch * rows_per_batch * a.cout;
+    const float* p = a.partial + ((long)b * rows_per_batch + t) * a.cout + co;
+    float v[8];
+    {
+        const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = v0[j];
+            v[4 + j] = v1[j];
+        }
+    }
+    for (int s = 1; s < a.ksplit; ++s) {
+        const f32x4 v0 = *(const f32x4*)(p + s * split_stride), v1 = *(const f32x4*)(p + s * split_stride + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] += v0[j];
+            v[4 + j] += v1[j];
+        }
+    }
+    const long yidx = (long)b * a.y_bs + (long)(a.y_row0 + t) * a.y_rs + co;
+    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += a.bias[co + j];
+    }
+    if (MODE == SL_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    if (MODE == SL_EPI_RELU_MASK) {
+        const u32x4 m = *(const u32x4*)(a.mask + yidx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned int lo = m[j] & 0xFFFFu, hi = m[j] >> 16;
+            if (!(lo != 0 && lo < 0x8000u)) v[2 * j] = 0.f;
+            if (!(hi != 0 && hi < 0x8000u)) v[2 * j + 1] = 0.f;
+        }
+    }
+    if (OUT_F32) {
+        float* yo = (float*)a.y + yidx;
+        *(f32x4*)yo = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)(yo + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+        u32x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+        *(u32x4*)((__bf16*)a.y + yidx) = pk;
+    }
+}
+
+template <int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
+int launch_main(const NtArgs& a, hipStream_t s) {
+    constexpr int LDS_BYTES = STAGES * (16 * IT * WM + 64 * WN) * 128;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_nt_bf16_kernel<EPI, OUT_F32>,
+        (void)hipFuncSetAttribute((const void*)conv_nt_bf16_kernel<IT, WM, WN, STAGES, MODE, OUT_F32>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    const int grid = a.batch * a.t_tiles * a.n_tiles;
-    hipLaunchKernelGGL((conv_nt_bf16_kernel<EPI, OUT_F32>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+    const int grid = a.batch * a.t_tiles * a.n_tiles * a.ksplit;
+    hipLaunchKernelGGL((conv_nt_bf16_kernel<IT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid), dim3(64 * WM * WN), LDS_BYTES, s,
+                       a);
     return sl_check_launch("sl_conv1d_nt(bf16)");
 }
 
-template <int EPI>
-int launch(const NtArgs& a, int out_f32, hipStream_t s) {
-    return out_f32 ? launch_one<EPI, true>(a, s) : launch_one<EPI, false>(a, s);
+template <int MODE, bool OUT_F32>
+int launch_tail(const NtArgs& a, int rows_per_batch, hipStream_t s) {
+    const long total = (long)a.batch * a.t_out * (a.cout / 8);
+    hipLaunchKernelGGL((nt_splitk_epilogue_kernel<MODE, OUT_F32>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       a, rows_per_batch);
+    return sl_check_launch("sl_conv1d_nt(bf16 split-K epilogue)");
+}
+
+template <int IT, int WM, int WN, int STAGES>
+int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
+    a.t_tiles = (a.t_out + 16 * IT * WM - 1) / (16 * IT * WM);
+    a.n_tiles = a.cout / (64 * WN);
+    if (a.ksplit > 1) {
+        int rc = launch_main<IT, WM, WN, STAGES, MODE_PARTIAL, true>(a, s);
+        if (rc != SL_OK) return rc;
+        const int rows = a.t_tiles * 16 * IT * WM;
+        if (out_f32) {
+            if (epilogue == SL_EPI_BIAS) return launch_tail<SL_EPI_BIAS, true>(a, rows, s);
+            if (epilogue == SL_EPI_NONE) return launch_tail<SL_EPI_NONE, true>(a, rows, s);
+        } else {
+            switch (epilogue) {
+                case SL_EPI_NONE: return launch_tail<SL_EPI_NONE, false>(a, rows, s);
+                case SL_EPI_BIAS: return launch_tail<SL_EPI_BIAS, false>(a, rows, s);
+                case SL_EPI_BIAS_RELU: return launch_tail<SL_EPI_BIAS_RELU, false>(a, rows, s);
+                case SL_EPI_RELU_MASK: return launch_tail<SL_EPI_RELU_MASK, false>(a, rows, s);
+            }
+        }
+    } else if (out_f32) {
+        if (epilogue == SL_EPI_BIAS) return launch_main<IT, WM, WN, STAGES, SL_EPI_BIAS, true>(a, s);
+        if (epilogue == SL_EPI_NONE) return launch_main<IT, WM, WN, STAGES, SL_EPI_NONE, true>(a, s);
+    } else {
+        switch (epilogue) {
+            case SL_EPI_NONE: return launch_main<IT, WM, WN, STAGES, SL_EPI_NONE, false>(a, s);
+            case SL_EPI_BIAS: return launch_main<IT, WM, WN, STAGES, SL_EPI_BIAS, false>(a, s);
+            case SL_EPI_BIAS_RELU: return launch_main<IT, WM, WN, STAGES, SL_EPI_BIAS_RELU, false>(a, s);
+            case SL_EPI_RELU_MASK: return launch_main<IT, WM, WN, STAGES, SL_EPI_RELU_MASK, false>(a, s);
+        }
+    }
+    sl_set_error("sl_conv1d_nt(bf16): unsupported epilogue %d with out_f32=%d", epilogue, out_f32);
+    return SL_ERR_UNSUPPORTED;
+}
+
+struct Cfg {
+    int wm, wn, stages, ksplit, it;
+    int bm() const { return 16 * it * wm; }
+};
+
+// cfg word: wm | wn << 4 | stages << 8 | ksplit << 12 | it << 20 (it = 0 means 4); 0 = choose automatically
+Cfg decode_cfg(int cfg) {
+    Cfg c{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 15, (cfg >> 12) & 255, (cfg >> 20) & 15};
+    if (c.it == 0) c.it = 4;
+    return c;
+}
+
+Cfg auto_cfg(const sl_conv_geom* g) {
+    // Table measured on MI355X with tools/tune_kernels.py (profiles/r01_tune_nt.json): see DESIGN.md "NT kernel tuning".
+    const long nsteps = (long)g->taps * (g->cin / BK);
+    if (g->cout % 256 == 0) {
+        const long tiles256 = (long)g->batch * ((g->t_out + 255) / 256) * (g->cout / 256);
+        // 256x256 tile, 16 waves, one work-group per CU: 1.35 PFLOP/s on big_conv_1 (vs 1.03 for 128x128)
+        if (tiles256 >= 192) return Cfg{4, 4, 2, 1, 4};
+        if (nsteps >= 256) {  // long contraction but few tiles (dgrad of big_conv_1: 64 tiles, K = 65536): split K
+            long ks = (256 + tiles256 - 1) / tiles256;
+            if (ks > 8) ks = 8;
+            return Cfg{4, 4, 2, (int)ks, 4};
+        }
+    }
+    // short layers (one 128x128 tile per CU at most): 8 waves of 32x64 per tile so that each SIMD holds two waves and
+    // one wave's DMA issue overlaps the other's MFMAs; 3-deep ring
+    return Cfg{4, 2, 3, 1, 2};
+}
+
+bool valid_cfg(const Cfg& c, const sl_conv_geom* g) {
+    const bool shape = (c.it == 2 && c.wm == 4 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) ||
+                       (c.it == 2 && c.wm == 8 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
+                       (c.it == 4 && c.wm == 2 && c.wn == 2 && (c.stages >= 2 && c.stages <= 4)) ||
+                       (c.it == 4 && c.wm == 4 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
+                       (c.it == 4 && c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
+                       (c.it == 4 && c.wm == 4 && c.wn == 4 && c.stages == 2);
+    if (!shape || c.ksplit < 1) return false;
+    if (g->cout % (64 * c.wn)) return false;
+    const long nsteps = (long)g->taps * (g->cin / BK);
+    return c.ksplit <= nsteps;
 }
 
 }  // namespace
 
+size_t conv_nt_bf16_workspace_bytes(const sl_conv_geom* g, int cfg) {
+    Cfg c = cfg ? decode_cfg(cfg) : auto_cfg(g);
+    if (!valid_cfg(c, g) || c.ksplit <= 1) return 0;
+    const long rows = (long)((g->t_out + c.bm() - 1) / c.bm()) * c.bm();
+    return (size_t)c.ksplit * g->batch * rows * g->cout * sizeof(float);
+}
+
 int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
-                 int epilogue, int out_f32, hipStream_t s) {
+                 int epilogue, int out_f32, int cfg, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    Cfg c = cfg ? decode_cfg(cfg) : auto_cfg(g);
+    if (!valid_cfg(c, g)) {
+        sl_set_error("sl_conv1d_nt(bf16): invalid tile configuration it=%d wm=%d wn=%d stages=%d ksplit=%d for cout=%d",
+                     c.it, c.wm, c.wn, c.stages, c.ksplit, g->cout);
+        return SL_ERR_INVALID_ARGUMENT;
+    }
     NtArgs a;
     a.x = (const __bf16*)x;
     a.w = (const __bf16*)w;
     a.bias = bias;
     a.mask = (const __bf16*)mask;
     a.y = y;
+    a.partial = (float*)workspace;
     a.batch = g->batch;
     a.t_out = g->t_out;
-    a.t_tiles = (g->t_out + BM - 1) / BM;
-    a.n_tiles = g->cout / BN;
     a.x_row0 = g->x_row0;
     a.x_rs = g->x_row_stride;
     a.x_bs = g->x_batch_stride;
     a.y_row0 = g->y_row0;
     a.y_rs = g->y_row_stride;
     a.y_bs = g->y_batch_stride;
+    a.cout = g->cout;
     a.w_rs = g->taps * g->cin;
     a.chunks = g->cin / BK;
     a.nsteps = g->taps * a.chunks;
-    switch (epilogue) {
-        case SL_EPI_NONE: return launch<SL_EPI_NONE>(a, out_f32, s);
-        case SL_EPI_BIAS: return launch<SL_EPI_BIAS>(a, out_f32, s);
-        case SL_EPI_BIAS_RELU: return launch<SL_EPI_BIAS_RELU>(a, out_f32, s);
-        case SL_EPI_RELU_MASK: return launch<SL_EPI_RELU_MASK>(a, out_f32, s);
+    a.ksplit = c.ksplit;
+    a.steps_per_split = (a.nsteps + c.ksplit - 1) / c.ksplit;
+    a.ksplit = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;  // no empty splits
+    if (a.ksplit > 1) {
+        const size_t need = conv_nt_bf16_workspace_bytes(g, cfg);
+        if (workspace == nullptr || workspace_bytes < need) {
+            sl_set_error("sl_conv1d_nt(bf16): split-K workspace too small (%zu < %zu)", workspace_bytes, need);
+            return SL_ERR_WORKSPACE_TOO_SMALL;
+        }
     }
-    sl_set_error("sl_conv1d_nt: unknown epilogue %d", epilogue);
-    return SL_ERR_INVALID_ARGUMENT;
+#define SL_NT_CASE(IT_, WM_, WN_, ST_)                                  \
+    if (c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
+        return launch_cfg<IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);
+    SL_NT_CASE(4, 2, 2, 2)
+    SL_NT_CASE(4, 2, 2, 3)
+    SL_NT_CASE(4, 2, 2, 4)
+    SL_NT_CASE(4, 4, 2, 2)
+    SL_NT_CASE(4, 4, 2, 3)
+    SL_NT_CASE(4, 2, 4, 2)
+    SL_NT_CASE(4, 2, 4, 3)
+    SL_NT_CASE(4, 4, 4, 2)
+    SL_NT_CASE(2, 4, 2, 2)
+    SL_NT_CASE(2, 4, 2, 3)
+    SL_NT_CASE(2, 4, 2, 4)
+    SL_NT_CASE(2, 8, 2, 2)
+    SL_NT_CASE(2, 8, 2, 3)
+#undef SL_NT_CASE
+    sl_set_error("sl_conv1d_nt(bf16): configuration not instantiated");
+    return SL_ERR_UNSUPPORTED;
 }

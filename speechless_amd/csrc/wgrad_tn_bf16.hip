@@ -5,24 +5,21 @@
 //
 // Both operands are time-major in HBM (channels-last), i.e. the contraction index t is the STRIDED one: a "TN" GEMM.
 // Mapping to CDNA4:
-//   * work-group = one (tap, 128 input channels, 128 output channels) tile of dw, 4 waves (2x2) of 64x64 patches,
-//     v_mfma_f32_16x16x32_bf16; the contraction walks (utterance, 64-row time chunk); the tap is only a row shift
-//     of the activation tile's source address.
-//   * tiles are DMA-copied to LDS in their natural [t][channel] shape (global_load_lds_dwordx4, double buffered) and
-//     the K-major MFMA fragments are produced by the gfx950 transpose read ds_read_b64_tr_b16 (one 4(t)x16(channel)
-//     block per 16-lane group).  LDS rows are 256 B; the 32-B slot index is XOR-swizzled (on the DMA source address)
-//     so that the 8 rows a 32-lane group touches cover all 64 banks.
+//   * work-group = one (tap, 64*WM input channels, 64*WN output channels) tile of dw, WM*WN waves of 64x64 patches
+//     (v_mfma_f32_16x16x32_bf16, fp32 accumulators); 128x128 (4 waves) ... 256x256 (16 waves, one work-group per CU).
+//     The contraction walks (utterance, 64-row time chunk); the tap is only a row shift of the activation tile's
+//     source address (im2col-free).
+//   * tiles are DMA-copied to LDS in their natural [t][channel] shape (global_load_lds_dwordx4) through a STAGES-deep
+//     ring with counted s_waitcnt vmcnt(N) + raw s_barrier, and the K-major MFMA fragments are produced by the gfx950
+//     transpose read ds_read_b64_tr_b16 (one 4(t) x 16(channel) block per 16-lane group).  The 32-B slot index of each
+//     LDS row is XOR-swizzled (on the DMA source address) so that the 8 rows a 32-lane group touches cover all 64 banks.
 //   * reduction over the batch is split across work-groups when the tile count cannot fill 256 CUs; partials go to a
 //     workspace and are summed in a fixed order by wgrad_reduce_kernel (deterministic, no float atomics).
 #include "common.h"
 
 namespace {
 
-constexpr int TCI = 128;
-constexpr int TCO = 128;
-constexpr int TK = 64;                      // time rows per step
-constexpr int TILE_BYTES = TK * 128 * 2;    // 16 KiB
-constexpr int LDS_BYTES = 4 * TILE_BYTES;   // {X,G} x 2 buffers
+constexpr int TK = 64;  // time rows per step
 
 struct TnArgs {
     const __bf16* x;
@@ -42,23 +39,55 @@ __device__ __forceinline__ void glds16(const __bf16* gsrc, char* lds_wave_base) 
     __builtin_amdgcn_global_load_lds((const SL_GLOBAL void*)gsrc, (SL_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int RB>
 __device__ __forceinline__ bf16x8 tr_read8(const char* p0) {
-    // two 4x16 transpose reads: rows t..t+3 and t+4..t+7 (the +4 rows sit 4*256 B further)
+    // two 4x16 transpose reads: rows t..t+3 and t+4..t+7 (the +4 rows sit 4 LDS rows further, same swizzle key)
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SL_LDS s16x4*)(p0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SL_LDS s16x4*)(p0 + 4 * 256));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SL_LDS s16x4*)(p0 + 4 * RB));
     s16x8 v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
     v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_tn_bf16_kernel(TnArgs a) {
+// per-lane source offset (elements) of DMA instruction j for a [64][W*64] bf16 tile whose LDS rows are RB = 128*W bytes:
+// lane -> row j*RPI + lane/LPR, 16-B slot lane%LPR; the 32-B slot index is XORed with key(row) = (row&3)|((row>>3)&1)<<2
+template <int W>
+__device__ __forceinline__ int dma_src_offset(int j, int lane, int row_stride) {
+    constexpr int LPR = 8 * W;      // lanes (16-B slots) per row
+    constexpr int RPI = 64 / LPR;   // rows per 1-KiB DMA instruction
+    const int row = j * RPI + lane / LPR;
+    const int slot16 = lane % LPR;
+    const int key = (row & 3) | (((row >> 3) & 1) << 2);
+    const int chunk16 = (((slot16 >> 1) ^ key) << 1) | (slot16 & 1);
+    return row * row_stride + chunk16 * 8;
+}
+
+template <int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_tn_bf16_kernel(TnArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int TCI = 64 * WM;
+    constexpr int TCO = 64 * WN;
+    constexpr int XRB = 128 * WM;  // LDS row bytes of the activation tile
+    constexpr int GRB = 128 * WN;
+    constexpr int X_BYTES = TK * XRB;
+    constexpr int STAGE_BYTES = TK * (XRB + GRB);
+    constexpr int XPW = (8 * WM) / NW;  // DMA instructions per wave per stage (activation tile = 8*WM KiB)
+    constexpr int GPW = (8 * WN) / NW;
+    static_assert((8 * WM) % NW == 0 && (8 * WN) % NW == 0, "tiles must split evenly over the waves");
+    constexpr int NI = XPW + GPW;
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1;  // ci half
-    const int wn = wave & 1;   // co half
+    const int wm = wave / WN;  // ci block
+    const int wn = wave % WN;  // co block
     const int g = lane >> 4;
 
     // logical id = ((split * co_tiles + co_tile) * ci_tiles + ci_tile) * taps + tap
@@ -72,19 +101,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_bf16_kernel(TnArgs a) {
     const int b_begin = split * a.b_per_split;
     int b_end = b_begin + a.b_per_split;
     if (b_end > a.batch) b_end = a.batch;
-    const int nsteps = (b_end - b_begin) * a.t_chunks;
+    const int n = (b_end - b_begin) * a.t_chunks;
 
-    // ---- staging: wave copies rows [wave*16, wave*16+16) of both tiles, 4 rows (1 KiB) per instruction
-    const int srow = wave * 16 + (lane >> 4);  // + q*4
-    int schunk[4];
+    int xoff[XPW], goff_src[GPW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int key = (lane >> 4) | ((q >> 1) << 2);
-        const int slot16 = lane & 15;
-        schunk[q] = ((((slot16 >> 1) ^ key) << 1) | (slot16 & 1)) * 8;
-    }
-    const __bf16* xbase = a.x + (long)(a.x_row0 + tap + srow) * a.x_rs + ci_tile * TCI;
-    const __bf16* gbase = a.g + (long)(a.g_row0 + srow) * a.g_rs + co_tile * TCO;
+    for (int q = 0; q < XPW; ++q) xoff[q] = dma_src_offset<WM>(wave * XPW + q, lane, a.x_rs);
+#pragma unroll
+    for (int q = 0; q < GPW; ++q) goff_src[q] = dma_src_offset<WN>(wave * GPW + q, lane, a.g_rs);
+    const __bf16* xbase = a.x + (long)(a.x_row0 + tap) * a.x_rs + ci_tile * TCI;
+    const __bf16* gbase = a.g + (long)a.g_row0 * a.g_rs + co_tile * TCO;
 
     auto stage = [&](int step, int buf) {
         const int bb = step / a.t_chunks;
@@ -92,25 +117,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_bf16_kernel(TnArgs a) {
         const int b = b_begin + bb;
         const __bf16* xs = xbase + (long)b * a.x_bs + (long)(tc * TK) * a.x_rs;
         const __bf16* gs = gbase + (long)b * a.g_bs + (long)(tc * TK) * a.g_rs;
-        char* xl = smem + buf * (2 * TILE_BYTES) + wave * (16 * 256);
-        char* gl = xl + TILE_BYTES;
+        char* xl = smem + buf * STAGE_BYTES + (wave * XPW) * 1024;
+        char* gl = smem + buf * STAGE_BYTES + X_BYTES + (wave * GPW) * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            glds16(xs + (long)(q * 4) * a.x_rs + schunk[q], xl + q * 1024);
-            glds16(gs + (long)(q * 4) * a.g_rs + schunk[q], gl + q * 1024);
-        }
+        for (int q = 0; q < XPW; ++q) glds16(xs + xoff[q], xl + q * 1024);
+#pragma unroll
+        for (int q = 0; q < GPW; ++q) glds16(gs + goff_src[q], gl + q * 1024);
     };
 
     // ---- transpose-read addresses.  lane (g, i): row = kk*32 + g*8 + h*4 + (i>>2); 8-B piece (i&3) of 16-col block c16
     const int i16 = lane & 15;
     const int rkey = (i16 >> 2) | ((g & 1) << 2);
     const int rrow = g * 8 + (i16 >> 2);
-    // byte offset inside a tile for column block c16: rrow*256 + ((c16 ^ rkey) * 32) + (i16 & 3) * 8
-    int xoff[4], goff[4];
+    int xoffr[4], goffr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        xoff[j] = rrow * 256 + (((wm * 4 + j) ^ rkey) * 32) + (i16 & 3) * 8;
-        goff[j] = rrow * 256 + (((wn * 4 + j) ^ rkey) * 32) + (i16 & 3) * 8;
+        xoffr[j] = rrow * XRB + (((wm * 4 + j) ^ rkey) * 32) + (i16 & 3) * 8;
+        goffr[j] = X_BYTES + rrow * GRB + (((wn * 4 + j) ^ rkey) * 32) + (i16 & 3) * 8;
     }
 
     f32x4 acc[4][4];
@@ -119,26 +142,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_bf16_kernel(TnArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nsteps > 0) stage(0, 0);
-    for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < nsteps) stage(s + 1, (s + 1) & 1);
-        const char* xl = smem + (s & 1) * (2 * TILE_BYTES);
-        const char* gl = xl + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < STAGES - 1; ++i)
+        if (i < n) stage(i, i);
+    int cur = 0, nxt = STAGES - 1;
+    for (int i = 0; i < n; ++i) {
+        if (i + STAGES - 1 <= n)
+            wait_vmcnt<NI*(STAGES - 2)>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (i + STAGES - 1 < n) stage(i + STAGES - 1, nxt);
+        const char* sl = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) af[jn] = tr_read8(gl + goff[jn] + kk * (32 * 256));
+            for (int jn = 0; jn < 4; ++jn) af[jn] = tr_read8<GRB>(sl + goffr[jn] + kk * (32 * GRB));
 #pragma unroll
-            for (int it = 0; it < 4; ++it) bfr[it] = tr_read8(xl + xoff[it] + kk * (32 * 256));
+            for (int it = 0; it < 4; ++it) bfr[it] = tr_read8<XRB>(sl + xoffr[it] + kk * (32 * XRB));
 #pragma unroll
             for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
                     acc[jn][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn][it], 0, 0, 0);
         }
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
 
     // ---- store: lane holds co = co_base + jn*16 + g*4 + {0..3} for ci = ci_base + it*16 + (lane & 15)
@@ -151,6 +182,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_bf16_kernel(TnArgs a) {
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn) *(f32x4*)(out + row + co_base + jn * 16) = acc[jn][it];
     }
+}
+
+template <int WM, int WN, int STAGES>
+int launch(const TnArgs& a, hipStream_t s) {
+    constexpr int LDS_BYTES = STAGES * TK * 128 * (WM + WN);
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_bf16_kernel<WM, WN, STAGES>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<WM, WN, STAGES>), dim3(a.tiles * a.splits), dim3(64 * WM * WN), LDS_BYTES, s,
+                       a);
+    return sl_check_launch("sl_conv1d_wgrad(bf16)");
+}
+
+struct WCfg {
+    int wm, wn, stages, splits;  // splits = 0: choose
+};
+
+WCfg decode_wcfg(int cfg) { return WCfg{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 15, (cfg >> 12) & 255}; }
+
+int choose_splits(const sl_conv_geom* g, int tci, int tco, int target_wgs) {
+    const long tiles = (long)g->taps * (g->cin / tci) * (g->cout / tco);
+    long want = (target_wgs + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    if (want > g->batch) want = g->batch;
+    const int bps = (int)((g->batch + want - 1) / want);
+    return (g->batch + bps - 1) / bps;
+}
+
+WCfg auto_wcfg(const sl_conv_geom* g) {
+    // measured on MI355X with tools/tune_kernels.py (profiles/r01_tune.json), see DESIGN.md "kernel tuning"
+    if (g->cin % 256 == 0 && g->cout % 256 == 0) {
+        const long tiles256 = (long)g->taps * (g->cin / 256) * (g->cout / 256);
+        // 256x256 tile, 16 waves: big_conv_1 1085 TFLOP/s (128x128: 890), big_conv_2 918, striding_conv 643
+        if (tiles256 >= 24) return WCfg{4, 4, 2, choose_splits(g, 256, 256, 256)};
+    }
+    // short layers: 128x128 tiles, batch split so that ~2 work-groups land on every CU (deeper rings measured no gain)
+    return WCfg{2, 2, 2, choose_splits(g, 128, 128, 512)};
+}
+
+bool valid_wcfg(const WCfg& c, const sl_conv_geom* g) {
+    const bool shape = (c.wm == 2 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) ||
+                       (c.wm == 4 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
+                       (c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
+                       (c.wm == 4 && c.wn == 4 && c.stages == 2);
+    return shape && g->cin % (64 * c.wm) == 0 && g->cout % (64 * c.wn) == 0 && c.splits >= 1 && c.splits <= g->batch;
+}
+
+WCfg resolve_wcfg(const sl_conv_geom* g, int cfg) {
+    if (cfg == 0) return auto_wcfg(g);
+    WCfg c = decode_wcfg(cfg);
+    if (c.splits == 0 && c.wm > 0 && c.wn > 0 && g->cin % (64 * c.wm) == 0 && g->cout % (64 * c.wn) == 0)
+        c.splits = choose_splits(g, 64 * c.wm, 64 * c.wn, c.wm * c.wn >= 16 ? 256 : 512);
+    return c;
 }
 
 }  // namespace
@@ -166,12 +254,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 }
 
 int wgrad_split_count(const sl_conv_geom* g, int tile) {
-    const long tiles = (long)g->taps * (g->cin / tile) * (g->cout / tile);
-    long want = (512 + tiles - 1) / tiles;
-    if (want < 1) want = 1;
-    if (want > g->batch) want = g->batch;
-    const int bps = (int)((g->batch + want - 1) / want);
-    return (g->batch + bps - 1) / bps;
+    sl_conv_geom gg = *g;
+    return choose_splits(&gg, tile, tile, 512);
 }
 
 int wgrad_reduce(const float* ws, float* dw, long n, int splits, hipStream_t s) {
@@ -181,8 +265,22 @@ int wgrad_reduce(const float* ws, float* dw, long n, int splits, hipStream_t s) 
     return sl_check_launch("wgrad_reduce");
 }
 
-int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits,
+size_t wgrad_tn_bf16_workspace_bytes(const sl_conv_geom* g, int cfg) {
+    const WCfg c = resolve_wcfg(g, cfg);
+    if (!valid_wcfg(c, g)) return 0;
+    const int bps = (g->batch + c.splits - 1) / c.splits;
+    const int splits = (g->batch + bps - 1) / bps;
+    return splits > 1 ? (size_t)splits * g->taps * g->cin * g->cout * sizeof(float) : 0;
+}
+
+int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, float* ws, size_t ws_bytes,
                   hipStream_t s) {
+    const WCfg c = resolve_wcfg(g, cfg);
+    if (!valid_wcfg(c, g)) {
+        sl_set_error("sl_conv1d_wgrad(bf16): invalid tile configuration wm=%d wn=%d stages=%d splits=%d for cin=%d cout=%d",
+                     c.wm, c.wn, c.stages, c.splits, g->cin, g->cout);
+        return SL_ERR_INVALID_ARGUMENT;
+    }
     TnArgs a;
     a.x = (const __bf16*)x;
     a.g = (const __bf16*)gr;
@@ -197,21 +295,30 @@ int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* 
     a.g_row0 = g->y_row0;
     a.g_rs = g->y_row_stride;
     a.g_bs = g->y_batch_stride;
-    a.ci_tiles = g->cin / TCI;
-    a.co_tiles = g->cout / TCO;
+    a.ci_tiles = g->cin / (64 * c.wm);
+    a.co_tiles = g->cout / (64 * c.wn);
     a.tiles = a.taps * a.ci_tiles * a.co_tiles;
-    a.splits = splits;
-    a.b_per_split = (g->batch + splits - 1) / splits;
+    a.b_per_split = (g->batch + c.splits - 1) / c.splits;
+    a.splits = (g->batch + a.b_per_split - 1) / a.b_per_split;
     a.split_stride = (long)g->taps * g->cin * g->cout;
-    a.out = splits > 1 ? ws : dw;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
+    if (a.splits > 1 && (ws == nullptr || ws_bytes < (size_t)a.splits * a.split_stride * sizeof(float))) {
+        sl_set_error("sl_conv1d_wgrad(bf16): workspace too small");
+        return SL_ERR_WORKSPACE_TOO_SMALL;
     }
-    hipLaunchKernelGGL(wgrad_tn_bf16_kernel, dim3(a.tiles * splits), dim3(256), LDS_BYTES, s, a);
-    int rc = sl_check_launch("sl_conv1d_wgrad(bf16)");
+    a.out = a.splits > 1 ? ws : dw;
+    int rc = SL_ERR_UNSUPPORTED;
+#define SL_TN_CASE(WM_, WN_, ST_) \
+    if (c.wm == WM_ && c.wn == WN_ && c.stages == ST_) rc = launch<WM_, WN_, ST_>(a, s);
+    SL_TN_CASE(2, 2, 2)
+    SL_TN_CASE(2, 2, 3)
+    SL_TN_CASE(2, 2, 4)
+    SL_TN_CASE(4, 2, 2)
+    SL_TN_CASE(4, 2, 3)
+    SL_TN_CASE(2, 4, 2)
+    SL_TN_CASE(2, 4, 3)
+    SL_TN_CASE(4, 4, 2)
+#undef SL_TN_CASE
     if (rc != SL_OK) return rc;
-    if (splits > 1) return wgrad_reduce(ws, dw, a.split_stride, splits, s);
+    if (a.splits > 1) return wgrad_reduce(ws, dw, a.split_stride, a.splits, s);
     return SL_OK;
 }

@@ -137,6 +137,17 @@ class _Buffers:
                 g.y_batch_stride = self.rows * p.cout_pad
             self.fwd_geom.append(g)
         self.bwd_ready = False
+        self.nt_ws = None
+        self.size_nt_workspace(eng, self.fwd_geom, "fwd")
+
+    def size_nt_workspace(self, eng, geoms, kind):
+        need = 16
+        for p, g in zip(eng.plans, geoms):
+            if g is not None:
+                need = max(need, lib().raw("sl_conv1d_nt_workspace_bytes")(
+                    ctypes.byref(g), eng.dtype_code, eng.nt_cfg.get((kind, p.spec.name), 0)))
+        if self.nt_ws is None or self.nt_ws.numel() < need:
+            self.nt_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
 
     def ensure_backward(self, eng):
         if self.bwd_ready:
@@ -159,7 +170,8 @@ class _Buffers:
             wg.y_row_stride = p.cout_pad
             wg.y_batch_stride = self.rows * p.cout_pad
             self.wgrad_geom[p.index] = wg
-            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(ctypes.byref(wg), eng.dtype_code))
+            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
+                ctypes.byref(wg), eng.dtype_code, eng.nt_cfg.get(("wgrad", p.spec.name), 0)))
             bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
             if p.index > first:
                 dg = ConvGeom()
@@ -175,6 +187,7 @@ class _Buffers:
                 dg.y_row_stride = p.cin_pad
                 dg.y_batch_stride = self.rows * p.cin_pad
                 self.dgrad_geom[p.index] = dg
+        self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
         self.wgrad_ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
         self.bias_ws = torch.empty((max(bias_ws, 16),), dtype=torch.uint8, device=dev)
         self.ctc_ws = None
@@ -251,6 +264,7 @@ class Engine:
         self._buffers = {}
         self.cur = None
         self.timeline = None
+        self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -367,7 +381,8 @@ class Engine:
             _, bias = self.layer_param_views(self.params, p)
             self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(), None,
                           y.data_ptr(), ctypes.byref(buf.fwd_geom[p.index]),
-                          _lib.EPI_BIAS if last else _lib.EPI_BIAS_RELU, self.dtype_code, 1 if last else 0, st)
+                          _lib.EPI_BIAS if last else _lib.EPI_BIAS_RELU, self.dtype_code, 1 if last else 0,
+                          self.nt_cfg.get(("fwd", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
             x = y
         self._launch("softmax", "sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
                       buf.t_out, self.grapheme_set_size, self.plans[-1].cout_pad, buf.tt_pad * self.plans[-1].cout_pad,
@@ -444,8 +459,8 @@ class Engine:
             x = buf.x0 if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
             self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), dw.data_ptr(),
-                          ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, buf.wgrad_ws.data_ptr(),
-                          buf.wgrad_ws.numel(), st)
+                          ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, self.nt_cfg.get(("wgrad", p.spec.name), 0),
+                          buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
             self._launch("bgrad:" + p.spec.name, "sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), ctypes.byref(buf.wgrad_geom[i]),
                           self.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
             if on_bucket_ready is not None and i == split:
@@ -453,7 +468,8 @@ class Engine:
             if i > first:
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
                               buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
-                              _lib.EPI_RELU_MASK, self.dtype_code, 0, st)
+                              _lib.EPI_RELU_MASK, self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
+                              buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
         if on_bucket_ready is not None and split > first:
             on_bucket_ready(1)
 

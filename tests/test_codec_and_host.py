@@ -85,7 +85,7 @@ def test_header_symbols_are_exported_and_bound():
     assert library.raw("sl_version")() == 1
     # argument validation works without a GPU: a bad geometry is rejected before any launch
     geom = _lib.ConvGeom()
-    rc = library.raw("sl_conv1d_nt")(1, 1, None, None, 1, geom, 0, 0, 0, None)
+    rc = library.raw("sl_conv1d_nt")(1, 1, None, None, 1, geom, 0, 0, 0, 0, None, 0, None)
     assert rc == -1 and "must be positive" in library.last_error()
 
 

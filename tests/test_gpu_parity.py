@@ -476,7 +476,7 @@ def test_single_layer_kernels_with_exact_operands(dtype, layer):
     # ---- wgrad + bias grad
     dw_v, db_v = eng.layer_param_views(eng.grads, p)
     eng.lib.call("sl_conv1d_wgrad", (buf.x0 if layer == 0 else buf.y[layer - 1]).data_ptr(), buf.g[layer].data_ptr(),
-                 dw_v.data_ptr(), ctypes.byref(buf.wgrad_geom[layer]), eng.dtype_code, buf.wgrad_ws.data_ptr(),
+                 dw_v.data_ptr(), ctypes.byref(buf.wgrad_geom[layer]), eng.dtype_code, 0, buf.wgrad_ws.data_ptr(),
                  buf.wgrad_ws.numel(), st)
     eng.lib.call("sl_bias_grad", buf.g[layer].data_ptr(), db_v.data_ptr(), ctypes.byref(buf.wgrad_geom[layer]),
                  eng.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
@@ -491,7 +491,7 @@ def test_single_layer_kernels_with_exact_operands(dtype, layer):
     if layer > 0:
         eng.lib.call("sl_conv1d_nt", buf.g[layer].data_ptr(), eng.w_dgrad[layer].data_ptr(), None,
                      buf.y[layer - 1].data_ptr(), buf.g[layer - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[layer]),
-                     _lib.EPI_RELU_MASK, eng.dtype_code, 0, st)
+                     _lib.EPI_RELU_MASK, eng.dtype_code, 0, 0, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
         torch.cuda.synchronize()
         raw = buf.g[layer - 1].float().cpu().numpy()
         got = raw[:, HALO:HALO + t_out, :s.cin]
@@ -504,7 +504,7 @@ def test_single_layer_kernels_with_exact_operands(dtype, layer):
         eng.lib.call("sl_conv1d_nt", (buf.x0 if layer == 0 else buf.y[layer - 1]).data_ptr(),
                      eng.w_fwd[layer].data_ptr(), eng.layer_param_views(eng.params, p)[1].data_ptr(), None,
                      buf.y[layer].data_ptr(), ctypes.byref(buf.fwd_geom[layer]), _lib.EPI_BIAS_RELU, eng.dtype_code, 0,
-                     st)
+                     0, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
         torch.cuda.synchronize()
         got = buf.y[layer].float().cpu().numpy()[:, HALO:HALO + t_out, :s.cout]
         want = np.maximum(o.conv1d_preactivation(x_in.astype(np.float64), w.astype(np.float64),
