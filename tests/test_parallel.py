@@ -1,0 +1,93 @@
+"""CPU tests (gloo, world_size 2) of the data-parallel gradient exchange in speechless_amd/parallel.py.
+
+Each rank computes, with the CPU oracle (allowed in tests), the gradient of its utterance shard scaled by
+1/(B_local * world) -- exactly what Engine.train_step_resident asks the CTC kernel for -- packs it into a flat fp32
+buffer, and the bucketed all-reduce must reproduce the single-process gradient of the global batch."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def _toy_problem():
+    from oracle import w2l_oracle as o
+    specs = o.layer_specs(4, 5, main_filter_count=6, out_filter_count=8, striding_kernel=6, inner_kernel=3,
+                          big_kernel=4, inner_count=2)
+    weights = o.glorot_uniform_weights(specs, 2, np.float64)
+    x = np.random.RandomState(0).randn(4, 20, 4)
+    labels = np.array([[0, 1, 2], [3, 3, -1], [1, -1, -1], [2, 0, 2]])
+    return specs, weights, x, labels, [10, 9, 8, 10], [3, 2, 1, 3]
+
+
+def _flat(grads):
+    return np.concatenate([np.concatenate([dw.ravel(), db.ravel()]) for dw, db in grads]).astype(np.float32)
+
+
+def _worker(rank, world, port, out_dir):
+    from oracle import w2l_oracle as o
+    from speechless_amd.parallel import GradBucketReducer, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs, weights, x, labels, pred_len, lab_len = _toy_problem()
+    lo, hi = shard_range(x.shape[0], rank, world)
+    r = o.loss_and_gradients(specs, weights, x[lo:hi], labels[lo:hi], pred_len[lo:hi], lab_len[lo:hi])
+    # the oracle scales by 1/B_local (mean over the shard); the engine uses 1/(B_local*world)
+    flat = torch.from_numpy(_flat(r["grads"]) / world)
+    n = flat.numel()
+    ranges = [(n // 3, n), (0, n // 3)]  # "late layers first" bucket order, like Engine.bucket_ranges()
+    reducer = GradBucketReducer(flat, ranges)
+    assert reducer.world_size == world
+    reducer.reduce_bucket(0)
+    reducer.reduce_bucket(1)
+    reducer.wait_all()
+    np.save(os.path.join(out_dir, "rank{}.npy".format(rank)), flat.numpy())
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_allreduce_equals_single_process_gradient(tmp_path):
+    from oracle import w2l_oracle as o
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    specs, weights, x, labels, pred_len, lab_len = _toy_problem()
+    ref = _flat(o.loss_and_gradients(specs, weights, x, labels, pred_len, lab_len)["grads"])
+    for rank in range(world):
+        got = np.load(str(tmp_path / "rank{}.npy".format(rank)))
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-7)
+
+
+def test_shard_range_partitions_everything():
+    from speechless_amd.parallel import shard_range
+    for total, world in [(256, 8), (64, 8), (10, 4), (3, 2), (1, 1)]:
+        covered = []
+        for r in range(world):
+            lo, hi = shard_range(total, r, world)
+            covered += list(range(lo, hi))
+        assert covered == list(range(total))
+    assert shard_range(256, 3, 8) == (96, 128)  # rank r takes utterances [32r, 32r+32) (config 4)
+
+
+def test_single_process_reducer_is_a_no_op():
+    from speechless_amd.parallel import GradBucketReducer
+    flat = torch.arange(10, dtype=torch.float32)
+    reducer = GradBucketReducer(flat, [(5, 10), (0, 5)])
+    reducer.reduce_bucket(0)
+    reducer.reduce_bucket(1)
+    reducer.wait_all()
+    assert torch.equal(flat, torch.arange(10, dtype=torch.float32))
