@@ -21,10 +21,17 @@
 
 namespace {
 
-__device__ __forceinline__ float lse3(float a, float b, float c) {
+// The lattice lives in LOG2 units: v_exp_f32 / v_log_f32 are base-2 natively, so a 3-way log-sum-exp is 3 + 1 raw
+// transcendentals instead of 4 range-reduced libm calls on the 500-step sequential critical path.  The arguments are
+// <= 0 (exp2) and in [1,3] (log2), so the raw instructions need no denormal / range fix-ups.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ float lse3_2(float a, float b, float c) {
     const float m = fmaxf(a, fmaxf(b, c));
     if (m == -INFINITY) return -INFINITY;
-    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
+                                     __builtin_amdgcn_exp2f(c - m));
 }
 
 __global__ void softmax_logq_kernel(const float* __restrict__ logits, float* __restrict__ probs,
@@ -105,47 +112,56 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
     const int tstart = dir == 0 ? 0 : T - 1;
     const int tstep = dir == 0 ? 1 : -1;
 
-    float e[8];
+    // Emissions: RAW log q values are fetched one 8-frame chunk AHEAD, unconditionally (every lane has a valid address:
+    // dead lanes point at the blank column, steps past the end are clamped), and only scaled to log2 units when consumed.
+    // Lessons from the ISA (hipcc 7.2): (1) any arithmetic or exec-masked branch at load time puts s_waitcnt vmcnt(0)
+    // right behind the load; (2) a value loaded in one loop iteration and consumed in the next makes the waitcnt pass
+    // fall back to vmcnt(1) (it loses the count across the back-edge); (3) an exec-masked store between load and use
+    // forces vmcnt(0).  So: loads at the top of the iteration, all 8 frames' stores unconditional (blockDim == sp, dead
+    // lanes own a padding column), and the chunk is pinned (empty asm) at the BOTTOM of the same iteration, where the
+    // pass can count the 8 younger stores exactly -> the HBM/L2 latency hides under 8 frames of recursion.
+    auto load_e = [&](int step) {
+        const int st = step < T ? step : T - 1;
+        return lq[(long)(tstart + tstep * st) * k];
+    };
+    float ec[8], en[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int t = tstart + tstep * j;
-        e[j] = (live && j < T) ? lq[(long)t * k] : 0.f;
-    }
-    // t = tstart
-    float a = -INFINITY;
-    if (live) {
-        const bool init = dir == 0 ? (s <= 1) : (s >= S - 2);
-        if (init) a = e[0];
-    }
-    buf0[s + 2] = a;
-    if (live) out[(long)tstart * sp + s] = a;
-    if (8 < T) e[0] = live ? lq[(long)(tstart + tstep * 8) * k] : 0.f;  // slot 0 next serves frame-step 8
+    for (int j = 0; j < 8; ++j) ec[j] = load_e(j);
     float* prev = buf0;
     float* cur = buf1;
     const int nb = dir == 0 ? -1 : 1;  // neighbour direction
-    for (int base = 1; base < T; base += 8) {
-        // frames base .. base+7 use e[(base+j) & 7]; ring slot j below is refilled for frame base+j+7 ... keep simple:
+    for (int base = 0; base < T; base += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) en[j] = load_e(base + 8 + j);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int step = base + j;           // 1-based distance from tstart
+            const int step = base + j;  // distance from tstart
             if (step < T) {
-                const int slot = (j + 1) & 7;     // e[] slot holding frame `step` (step = 8q + 1 + j)
                 const int t = tstart + tstep * step;
-                __syncthreads();
-                const float a0 = prev[s + 2];
-                const float a1 = prev[s + 2 + nb];
-                const float a2 = skip ? prev[s + 2 + 2 * nb] : -INFINITY;
-                float v = lse3(a0, a1, a2) + e[slot];
-                if (!live) v = -INFINITY;
+                float v;
+                if (step == 0) {
+                    const bool init = dir == 0 ? (s <= 1) : (s >= S - 2);
+                    v = (live && init) ? ec[0] * LOG2E : -INFINITY;
+                } else {
+                    // LDS-only barrier: __syncthreads() would also drain vmcnt(0) every frame
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    const float a0 = prev[s + 2];
+                    const float a1 = prev[s + 2 + nb];
+                    const float a2 = skip ? prev[s + 2 + 2 * nb] : -INFINITY;
+                    v = fmaf(ec[j], LOG2E, lse3_2(a0, a1, a2));
+                    if (!live) v = -INFINITY;
+                }
                 cur[s + 2] = v;
-                if (live) out[(long)t * sp + s] = v;
-                // refill this slot with the emission 8 frames ahead
-                const int ahead = step + 8;
-                if (ahead < T) e[slot] = live ? lq[(long)(tstart + tstep * ahead) * k] : 0.f;
+                out[(long)t * sp + s] = v;
                 float* tmp = prev;
                 prev = cur;
                 cur = tmp;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("" : "+v"(en[j]));  // materialise the prefetched chunk here, inside the iteration
+            ec[j] = en[j];
         }
     }
     if (dir == 0) {
@@ -154,8 +170,8 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
             const float last = prev[S - 1 + 2];
             const float last2 = S >= 2 ? prev[S - 2 + 2] : -INFINITY;
             const float m = fmaxf(last, last2);
-            const float lp = (m == -INFINITY) ? -INFINITY : m + logf(expf(last - m) + expf(last2 - m));
-            loss[b] = -lp;
+            const float lp2 = (m == -INFINITY) ? -INFINITY : m + log2f(exp2f(last - m) + exp2f(last2 - m));
+            loss[b] = -lp2 * LN2;  // back to natural-log units: -log p(label | x)
         }
     }
 }
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 
     const float nll = loss[b];
     const bool feasible = nll < INFINITY;
-    const float log_p = -nll;
+    const float log_p = -nll * LOG2E;  // lattice units are log2
     float* gam = s_gam + wave * l_max;
     const int t_begin = blockIdx.x * frames_per_wg;
     for (int tt = wave; tt < frames_per_wg; tt += 4) {
@@ -223,18 +239,18 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
             if (feasible) {
                 const float* al = alpha + fidx * sp;
                 const float* be = beta + fidx * sp;
-                const float lq_blank = lq[blank];
+                const float lq_blank = lq[blank] * LOG2E;
                 // blank states (even s) -> butterfly sum; grapheme states (odd s) -> gamma[] in LDS
                 float blank_part = 0.f;
                 for (int s = lane; s < S; s += 64) {
                     const float ab = al[s] + be[s];
                     if (s & 1) {
                         const int pos = s >> 1;
-                        const float lg = ab - lq[s_lab[pos]] - log_p;
-                        gam[pos] = (ab == -INFINITY) ? 0.f : expf(lg);
+                        const float lg = ab - lq[s_lab[pos]] * LOG2E - log_p;
+                        gam[pos] = (ab == -INFINITY) ? 0.f : exp2f(lg);
                     } else {
                         const float lg = ab - lq_blank - log_p;
-                        blank_part += (ab == -INFINITY) ? 0.f : expf(lg);
+                        blank_part += (ab == -INFINITY) ? 0.f : exp2f(lg);
                     }
                 }
 #pragma unroll

@@ -61,12 +61,19 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const T* __restr
     for (int t = rl; t < t_out; t += 16) {
         const T* p = base + (long)t * g_rs;
         if (sizeof(T) == 2) {
-            const u32x4 v = *(const u32x4*)p;
+            // four independent 16-B loads in flight per lane (rows t, t+16, t+32, t+48) -> HBM latency is overlapped
+            u32x4 v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[2 * i] += __uint_as_float(v[i] << 16);
-                acc[2 * i + 1] += __uint_as_float(v[i] & 0xFFFF0000u);
-            }
+            for (int u = 0; u < 4; ++u)
+                v[u] = (t + 16 * u < t_out) ? *(const u32x4*)(p + (long)(16 * u) * g_rs) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[2 * i] += __uint_as_float(v[u][i] << 16);
+                    acc[2 * i + 1] += __uint_as_float(v[u][i] & 0xFFFF0000u);
+                }
+            t += 48;
         } else {
             const f32x4 v0 = *(const f32x4*)p;
             const f32x4 v1 = *(const f32x4*)((const float*)p + 4);

@@ -264,6 +264,7 @@ class Engine:
         self._buffers = {}
         self.cur = None
         self.timeline = None
+        self._side_stream = None
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
 
     # ------------------------------------------------------------------ plumbing
@@ -452,24 +453,43 @@ class Engine:
         after the launches that complete gradient bucket i (see bucket_ranges) have been enqueued."""
         buf = self.cur
         st = self._stream()
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
         first = self.frozen_layer_count
         _, split = self.bucket_ranges()
+
+        def join_side():
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
+
         for p in reversed(self.plans[first:]):
             i = p.index
             x = buf.x0 if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
+            # the bias gradient only streams g[i] once (HBM-bound): it runs on a side stream underneath the MFMA-bound
+            # wgrad/dgrad kernels of the same layer instead of in front of them
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                self._launch("bgrad:" + p.spec.name, "sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(),
+                             ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, buf.bias_ws.data_ptr(),
+                             buf.bias_ws.numel(), side.cuda_stream)
             self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), dw.data_ptr(),
                           ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, self.nt_cfg.get(("wgrad", p.spec.name), 0),
                           buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
-            self._launch("bgrad:" + p.spec.name, "sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), ctypes.byref(buf.wgrad_geom[i]),
-                          self.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
             if on_bucket_ready is not None and i == split:
+                join_side()
                 on_bucket_ready(0)
             if i > first:
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
                               buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
                               _lib.EPI_RELU_MASK, self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
                               buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+        join_side()
         if on_bucket_ready is not None and split > first:
             on_bucket_ready(1)
 
