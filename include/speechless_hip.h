@@ -157,6 +157,13 @@ int sl_greedy_decode(const float* probs, const int32_t* input_len, int32_t* out,
 int sl_adam_step(float* param, const float* grad, float* m, float* v, size_t n, int step, float lr, float beta1,
                  float beta2, float eps, void* stream);
 
+/* Same Adam update for ONE layer block laid out [k][cin_pad][cout_pad] weights followed by cout_pad biases (param,
+ * grad, m, v point at the block's first weight), fused with sl_pack_weights: the pass that updates the fp32 masters
+ * also rewrites w_fwd [cout_pad][k][cin_pad] and (if non-NULL) w_dgrad [cin_pad][k][cout_pad] (taps flipped). */
+int sl_adam_pack_layer(float* param, const float* grad, float* m, float* v, void* w_fwd, void* w_dgrad, int k,
+                       int cin_pad, int cout_pad, int dtype, int step, float lr, float beta1, float beta2, float eps,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

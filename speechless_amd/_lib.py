@@ -61,6 +61,8 @@ SIGNATURES = {
                                  c_void_p]),
     "sl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_float,
                              c_float, c_void_p]),
+    "sl_adam_pack_layer": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_int, c_float, c_float, c_float, c_float, c_void_p]),
 }
 
 

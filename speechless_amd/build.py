@@ -10,7 +10,8 @@ CSRC = PACKAGE_DIR / "csrc"
 LIB_PATH = PACKAGE_DIR / "libspeechless_hip.so"
 SOURCES = ["capi.hip", "conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_f32.hip", "ctc.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+    os.environ.get("SL_EXTRA_FLAGS", "").split()  # experiments only (e.g. -DSL_NT_SETPRIO); the default build has none
 
 
 def _newest_source_mtime():

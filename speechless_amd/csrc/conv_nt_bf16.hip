@@ -6,26 +6,30 @@
 // weights, its input gradient (autodiff from net.py:389,550).
 //
 // Mapping to CDNA4:
-//   * work-group tile = (64*WM) time rows x (64*WN) output channels, WM*WN waves, each wave a 64x64 patch = 4x4
-//     v_mfma_f32_16x16x32_bf16 tiles with fp32 accumulators (64 VGPR/lane).  Tile shapes 128x128 (4 waves, 2 WG/CU),
-//     256x128 / 128x256 (8 waves) and 256x256 (16 waves, 1 WG/CU): bigger tiles halve the L2->LDS operand traffic
-//     per flop, which is what bounds the 128x128 tile (~16 TB/s at 1 PFLOP/s against a ~34 TB/s L2).
+//   * work-group tile = BM time rows x (64*WN) output channels, WM*WN waves.  Two wave-level MFMA shapes:
+//       M32 = false: v_mfma_f32_16x16x32_bf16, wave patch (16*IT) x 64 (IT = 4: 64x64; IT = 2: 32x64, twice the waves)
+//       M32 = true : v_mfma_f32_32x32x16_bf16, wave patch 64 x 64 = 2x2 tiles (higher MFMA ceiling: 2.38 vs 2.07 PF/s
+//                    micro-benchmark, half the MFMA instructions)
+//     Tile shapes 128x128 (4 or 8 waves) ... 256x256 (16 waves, 1 work-group/CU): bigger tiles halve the L2->LDS
+//     operand traffic per flop, which is what bounds the 128x128 tile (~16 TB/s at 1 PFLOP/s against a ~34 TB/s L2).
 //   * the contraction runs over (tap, 64-channel chunk): one step = one BMx64 activation tile (a plain row-shifted
 //     2-D tile of the halo'd channels-last tensor -> no im2col, no bounds checks) and one BNx64 weight tile.
 //   * tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip) through a STAGES-deep ring; the wait
 //     is a COUNTED s_waitcnt vmcnt(N) (never 0 in steady state) and the barrier a raw s_barrier, so STAGES-1 tiles
-//     stay in flight across barriers -- this is what makes the short-K layers (28 steps, one work-group per CU)
-//     stop being load-latency bound.
+//     stay in flight across barriers.
 //   * LDS rows are 128 B; the 16-B slot index is XOR-swizzled on the DMA *source* address (the LDS image must stay
-//     lane-linear) with a key chosen per operand so that every ds_read_b128 lane group hits 16 distinct bank slots.
-//   * D^T orientation: MFMA "A" = weights (rows = co), "B" = activations (cols = t), with the co rows of the four
-//     MFMA tiles interleaved so that each lane ends up with 16 CONSECUTIVE output channels of one time row: the
+//     lane-linear) with a key chosen per operand / MFMA shape so that every ds_read_b128 lane group (the hardware
+//     serves {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... together) hits 16 distinct bank slots.
+//   * D^T orientation: MFMA "A" = weights (rows = co), "B" = activations (cols = t), with the weight rows fed to the
+//     MFMA in a permuted order so that each lane ends up with 16 CONSECUTIVE output channels of one time row: the
 //     epilogue (bias + ReLU / ReLU-mask, bf16 convert) stores 32 contiguous bytes per lane.
-//   * split-K (over taps x chunks) when the tile count cannot fill the chip (dgrad of big_conv_1: K = 65536, 64..256
-//     tiles): fp32 partial tiles go to a workspace and nt_splitk_epilogue_kernel reduces them in a fixed order and
-//     applies the epilogue (deterministic).
+//   * split-K (over taps x chunks) when the tile count cannot fill the chip (dgrad of big_conv_1: K = 65536, 64 tiles):
+//     fp32 partial tiles go to a workspace and nt_splitk_epilogue_kernel reduces them in a fixed order and applies the
+//     epilogue (deterministic).
 //   * blockIdx -> tile mapping is XCD-aware: an XCD's work-groups share weight tiles in its private L2.
 #include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 
@@ -45,8 +49,8 @@ struct NtArgs {
     long y_bs;
     int cout;
     int w_rs;    // taps * cin
-    int chunks;  // cin / 64
-    int nsteps;  // taps * chunks
+    int taps, cin;
+    int nsteps;  // taps * cin / 64
     int ksplit, steps_per_split;
 };
 
@@ -61,12 +65,64 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 enum { MODE_PARTIAL = 4 };  // besides the SL_EPI_* values: raw fp32 accumulators to the split-K workspace
 
-// IT = 16-row time tiles per wave (4: 64x64 wave patch, 2: 32x64 wave patch -> twice the waves per tile, half the DMA
-// instructions per wave: for the short layers that only have one work-group per CU)
-template <int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
+// epilogue of one run of 16 consecutive output channels of one time row
+template <int MODE, bool OUT_F32>
+__device__ __forceinline__ void store_run16(const NtArgs& a, float (&v)[16], const float (&bias_v)[16], long yidx) {
+    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += bias_v[i];
+    }
+    if (MODE == SL_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (MODE == SL_EPI_RELU_MASK) {
+        const u32x4 m0 = *(const u32x4*)(a.mask + yidx);
+        const u32x4 m1 = *(const u32x4*)(a.mask + yidx + 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+            const unsigned int lo0 = m0[i] & 0xFFFFu, hi0 = m0[i] >> 16;
+            const unsigned int lo1 = m1[i] & 0xFFFFu, hi1 = m1[i] >> 16;
+            if (!(lo0 != 0 && lo0 < 0x8000u)) v[i * 2] = 0.f;
+            if (!(hi0 != 0 && hi0 < 0x8000u)) v[i * 2 + 1] = 0.f;
+            if (!(lo1 != 0 && lo1 < 0x8000u)) v[8 + i * 2] = 0.f;
+            if (!(hi1 != 0 && hi1 < 0x8000u)) v[8 + i * 2 + 1] = 0.f;
+        }
+    }
+    if (OUT_F32) {
+        float* yo = (float*)a.y + yidx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(yo + i * 4) = (f32x4){v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+    } else {
+        __bf16* yo = (__bf16*)a.y + yidx;
+        u32x4 p0, p1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p0[i] = pack_bf16x2(v[i * 2], v[i * 2 + 1]);
+            p1[i] = pack_bf16x2(v[8 + i * 2], v[8 + i * 2 + 1]);
+        }
+        *(u32x4*)(yo) = p0;
+        *(u32x4*)(yo + 8) = p1;
+    }
+}
+
+__device__ __forceinline__ void load_bias16(const float* bias, int co, float (&bias_v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 bv = *(const f32x4*)(bias + co + i * 4);
+        bias_v[i * 4 + 0] = bv[0];
+        bias_v[i * 4 + 1] = bv[1];
+        bias_v[i * 4 + 2] = bv[2];
+        bias_v[i * 4 + 3] = bv[3];
+    }
+}
+
+template <bool M32, int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_bf16_kernel(NtArgs a) {
     constexpr int NW = WM * WN;
-    constexpr int BM = 16 * IT * WM;
+    constexpr int WROWS = M32 ? 64 : 16 * IT;  // time rows per wave
+    constexpr int BM = WROWS * WM;
     constexpr int BN = 64 * WN;
     constexpr int X_BYTES = BM * 128;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
@@ -79,9 +135,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN;  // which 64-row block (time)
+    const int wm = wave / WN;  // which block of time rows
     const int wn = wave % WN;  // which 64-channel block (co)
-    const int g = lane >> 4;
 
     const int m_tiles = a.batch * a.t_tiles;
     const int tiles = m_tiles * a.n_tiles;
@@ -97,26 +152,37 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     int n = a.nsteps - s_begin;
     if (n > a.steps_per_split) n = a.steps_per_split;
 
-    // ---- staging: DMA instruction j copies rows [8j, 8j+8) of a tile (lane -> row 8j + lane/8, 16-B slot lane%8)
+    // ---- staging: DMA instruction j copies rows [8j, 8j+8) of a tile (lane -> row 8j + lane/8, 16-B slot lane%8).
+    // swizzle keys (function of the tile row r):
+    //   16x16 shape, activations: r & 7            weights: ((r>>1)&1) | (((r>>4)&3)<<1)   (rows reach the MFMA permuted)
+    //   32x32 shape, both:        ((r>>1)&3) | (((r>>4)&1)<<2)
     const __bf16* xbase = a.x + (long)b * a.x_bs + (long)(a.x_row0 + t0) * a.x_rs;
     const __bf16* wbase = a.w + (long)co0 * a.w_rs;
     int xoff[XPW], woff[WPW];
 #pragma unroll
     for (int q = 0; q < XPW; ++q) {
-        const int row = (wave * XPW + q) * 8 + (lane >> 3);
-        xoff[q] = row * a.x_rs + (((lane & 7) ^ (lane >> 3)) << 3);  // slot ^ (row & 7)
+        const int j = wave * XPW + q;
+        const int row = j * 8 + (lane >> 3);
+        const int key = M32 ? (((lane >> 4) & 3) | (((j >> 1) & 1) << 2)) : (lane >> 3);
+        xoff[q] = row * a.x_rs + (((lane & 7) ^ key) << 3);
     }
 #pragma unroll
     for (int q = 0; q < WPW; ++q) {
         const int j = wave * WPW + q;
         const int row = j * 8 + (lane >> 3);
-        const int key = ((lane >> 4) & 1) | (((j >> 1) & 3) << 1);  // ((row>>1)&1) | (((row>>4)&3)<<1)
+        const int key = M32 ? (((lane >> 4) & 3) | (((j >> 1) & 1) << 2)) : (((lane >> 4) & 1) | (((j >> 1) & 3) << 1));
         woff[q] = row * a.w_rs + (((lane & 7) ^ key) << 3);
     }
 
+    // contraction order: tap OUTER, 64-channel chunk INNER (the weight rows are then walked contiguously).  The
+    // alternative (chunk outer, tap inner: consecutive steps re-read the same activation rows shifted by one, L2 reuse
+    // distance of one step) was measured SLOWER on MI355X (big_conv_1 fwd 0.424 vs 0.378 ms, dgrad 0.434 vs 0.404 ms):
+    // the activation re-reads that miss the 4 MiB L2 (FETCH_SIZE 0.6-1.2 GB per launch) are served by the 256 MiB
+    // Infinity Cache and are not the bottleneck, while the strided weight walk costs more.
     auto stage = [&](int step, int buf) {
-        const int tap = step / a.chunks;
-        const int cc = step - tap * a.chunks;
+        const int chunks = a.cin / BK;
+        const int tap = step / chunks;
+        const int cc = step - tap * chunks;
         const __bf16* xs = xbase + (long)tap * a.x_rs + cc * BK;
         const __bf16* ws = wbase + (long)step * BK;
         char* xl = smem + buf * STAGE_BYTES + (wave * XPW) * 1024;
@@ -127,19 +193,39 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         for (int q = 0; q < WPW; ++q) glds16(ws + woff[q], wl + q * 1024);
     };
 
-    // ---- fragment read addresses
-    const int brow = wm * (16 * IT) + (lane & 15);                    // + it*16
-    const int arow = wn * 64 + ((lane & 15) >> 2) * 16 + (lane & 3);  // + jn*4
-    const int bkey = lane & 7;
-    const int akey = ((lane >> 1) & 1) | (((lane >> 2) & 3) << 1);
-    const int boff = brow * 128 + ((g ^ bkey) << 4);
-    const int aoff = X_BYTES + arow * 128 + ((g ^ akey) << 4);
+    // ---- fragment read addresses (byte offsets inside a ring slot, for k-chunk 0)
+    int boff, aoff;
+    if (M32) {
+        // B operand: lane -> time row lane&31 (+32*it), 16-B chunk (lane>>5) + 2*kstep
+        // A operand: lane -> MFMA row i = lane&31 fed from weight row perm(i) = ((i>>2)&1)*16 + (i&3) + 4*(i>>3), so that
+        //            D rows (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15, are the 16 consecutive channels (lane>>5)*16 + r
+        const int i = lane & 31, h = lane >> 5;
+        const int brow = wm * 64 + i;
+        const int arow = wn * 64 + ((i >> 2) & 1) * 16 + (i & 3) + 4 * (i >> 3);
+        const int bkey = ((i >> 1) & 3) | (((i >> 4) & 1) << 2);
+        const int akey = ((i >> 1) & 1) | (((i >> 3) & 1) << 1) | (((i >> 2) & 1) << 2);
+        boff = brow * 128 + ((h ^ bkey) << 4);
+        aoff = X_BYTES + arow * 128 + ((h ^ akey) << 4);
+    } else {
+        const int g = lane >> 4;
+        const int brow = wm * WROWS + (lane & 15);                        // + it*16
+        const int arow = wn * 64 + ((lane & 15) >> 2) * 16 + (lane & 3);  // + jn*4
+        const int bkey = lane & 7;
+        const int akey = ((lane >> 1) & 1) | (((lane >> 2) & 3) << 1);
+        boff = brow * 128 + ((g ^ bkey) << 4);
+        aoff = X_BYTES + arow * 128 + ((g ^ akey) << 4);
+    }
 
-    f32x4 acc[4][IT];
+    constexpr int NACC16 = M32 ? 1 : 4 * IT;
+    constexpr int NACC32 = M32 ? 4 : 1;
+    f32x4 acc[NACC16];    // [jn][it] 16x16 tiles
+    f32x16 acc32[NACC32]; // [jn][it] 32x32 tiles
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NACC16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < IT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NACC32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][r] = 0.f;
 
 #pragma unroll
     for (int i = 0; i < STAGES - 1; ++i)
@@ -153,94 +239,90 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();       // everyone's share of tile i landed; everyone finished reading slot nxt
         asm volatile("" ::: "memory");
+#ifndef SL_NT_LATE_DMA
         if (i + STAGES - 1 < n) stage(s_begin + i + STAGES - 1, nxt);
+#endif
         const char* sl = smem + cur * STAGE_BYTES;
+        if (M32) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bfr[IT];
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 af[2], bfr[2];
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) af[jn] = *(const bf16x8*)(sl + ((aoff + jn * 512) ^ (kk << 6)));
+                for (int jn = 0; jn < 2; ++jn) af[jn] = *(const bf16x8*)(sl + ((aoff + jn * 4096) ^ (ks << 5)));
 #pragma unroll
-            for (int it = 0; it < IT; ++it) bfr[it] = *(const bf16x8*)(sl + ((boff + it * 2048) ^ (kk << 6)));
+                for (int it = 0; it < 2; ++it) bfr[it] = *(const bf16x8*)(sl + ((boff + it * 4096) ^ (ks << 5)));
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn)
+                for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
-                for (int it = 0; it < IT; ++it)
-                    acc[jn][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn][it], 0, 0, 0);
+                    for (int it = 0; it < 2; ++it)
+                        acc32[jn * 2 + it] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[jn], bfr[it], acc32[jn * 2 + it], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[4], bfr[IT];
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) af[jn] = *(const bf16x8*)(sl + ((aoff + jn * 512) ^ (kk << 6)));
+#pragma unroll
+                for (int it = 0; it < IT; ++it) bfr[it] = *(const bf16x8*)(sl + ((boff + it * 2048) ^ (kk << 6)));
+#ifdef SL_NT_LATE_DMA
+                if (kk == 0 && i + STAGES - 1 < n) stage(s_begin + i + STAGES - 1, nxt);
+#endif
+#ifdef SL_NT_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                    for (int it = 0; it < IT; ++it)
+                        acc[jn * IT + it] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn * IT + it], 0, 0, 0);
+#ifdef SL_NT_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
         }
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
         nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
 
-    // ---- epilogue: lane holds, for each it, 16 consecutive channels co_base..co_base+15 of time row t
-    const int co_base = co0 + wn * 64 + g * 16;
-    if (MODE == MODE_PARTIAL) {
-        float* out = a.partial +
-                     ((long)(split * a.batch + b) * (a.t_tiles * BM) + t0 + wm * (16 * IT) + (lane & 15)) * a.cout + co_base;
+    // ---- epilogue: the lane holds runs of 16 consecutive channels of a time row
+    //   16x16 shape: per it one run   at co0 + wn*64 + (lane>>4)*16, row t0 + wm*WROWS + it*16 + (lane&15)
+    //   32x32 shape: per (it, jn) one at co0 + wn*64 + jn*32 + (lane>>5)*16, row t0 + wm*64 + it*32 + (lane&31)
+    constexpr int NRUN_T = M32 ? 2 : IT;
+    constexpr int NRUN_C = M32 ? 2 : 1;
+    const int lane_t = M32 ? (lane & 31) : (lane & 15);
+    const int lane_c = M32 ? (lane >> 5) * 16 : (lane >> 4) * 16;
 #pragma unroll
-        for (int it = 0; it < IT; ++it)
+    for (int jc = 0; jc < NRUN_C; ++jc) {
+        const int co_base = co0 + wn * 64 + jc * 32 + lane_c;
+        float bias_v[16];
+        if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) load_bias16(a.bias, co_base, bias_v);
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) *(f32x4*)(out + (long)(it * 16) * a.cout + jn * 4) = acc[jn][it];
-        return;
-    }
-    float bias_v[16];
-    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) {
+        for (int it = 0; it < NRUN_T; ++it) {
+            const int trow = wm * WROWS + it * (M32 ? 32 : 16) + lane_t;
+            float v[16];
+            if (M32) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 bv = *(const f32x4*)(a.bias + co_base + i * 4);
-            bias_v[i * 4 + 0] = bv[0];
-            bias_v[i * 4 + 1] = bv[1];
-            bias_v[i * 4 + 2] = bv[2];
-            bias_v[i * 4 + 3] = bv[3];
-        }
-    }
+                for (int r = 0; r < 16; ++r) v[r] = acc32[jc * 2 + it][r];
+            } else {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int t = t0 + wm * (16 * IT) + it * 16 + (lane & 15);
-        if (t >= a.t_out) continue;
-        const long yidx = (long)b * a.y_bs + (long)(a.y_row0 + t) * a.y_rs + co_base;
-        float v[16];
+                for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[jn * 4 + r] = acc[jn][it][r];
-        if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] += bias_v[i];
-        }
-        if (MODE == SL_EPI_BIAS_RELU) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
-        }
-        if (MODE == SL_EPI_RELU_MASK) {
-            const u32x4 m0 = *(const u32x4*)(a.mask + yidx);
-            const u32x4 m1 = *(const u32x4*)(a.mask + yidx + 8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // bf16 > 0  <=>  sign bit clear and magnitude non-zero
-                const unsigned int lo0 = m0[i] & 0xFFFFu, hi0 = m0[i] >> 16;
-                const unsigned int lo1 = m1[i] & 0xFFFFu, hi1 = m1[i] >> 16;
-                if (!(lo0 != 0 && lo0 < 0x8000u)) v[i * 2] = 0.f;
-                if (!(hi0 != 0 && hi0 < 0x8000u)) v[i * 2 + 1] = 0.f;
-                if (!(lo1 != 0 && lo1 < 0x8000u)) v[8 + i * 2] = 0.f;
-                if (!(hi1 != 0 && hi1 < 0x8000u)) v[8 + i * 2 + 1] = 0.f;
+                    for (int r = 0; r < 4; ++r) v[jn * 4 + r] = acc[jn * IT + it][r];
             }
-        }
-        if (OUT_F32) {
-            float* yo = (float*)a.y + yidx;
+            if (MODE == MODE_PARTIAL) {
+                float* out = a.partial + ((long)(split * a.batch + b) * (a.t_tiles * BM) + t0 + trow) * a.cout + co_base;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *(f32x4*)(yo + i * 4) = (f32x4){v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
-        } else {
-            __bf16* yo = (__bf16*)a.y + yidx;
-            u32x4 p0, p1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                p0[i] = pack_bf16x2(v[i * 2], v[i * 2 + 1]);
-                p1[i] = pack_bf16x2(v[8 + i * 2], v[8 + i * 2 + 1]);
+                for (int i = 0; i < 4; ++i) *(f32x4*)(out + i * 4) = (f32x4){v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+            } else {
+                const int t = t0 + trow;
+                if (t < a.t_out) {
+                    const long yidx = (long)b * a.y_bs + (long)(a.y_row0 + t) * a.y_rs + co_base;
+                    store_run16<MODE, OUT_F32>(a, v, bias_v, yidx);
+                }
             }
-            *(u32x4*)(yo) = p0;
-            *(u32x4*)(yo + 8) = p1;
         }
     }
 }
@@ -305,19 +387,19 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
     }
 }
 
-template <int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
+template <bool M32, int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
 int launch_main(const NtArgs& a, hipStream_t s) {
-    constexpr int LDS_BYTES = STAGES * (16 * IT * WM + 64 * WN) * 128;
+    constexpr int LDS_BYTES = STAGES * ((M32 ? 64 : 16 * IT) * WM + 64 * WN) * 128;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_nt_bf16_kernel<IT, WM, WN, STAGES, MODE, OUT_F32>,
+        (void)hipFuncSetAttribute((const void*)conv_nt_bf16_kernel<M32, IT, WM, WN, STAGES, MODE, OUT_F32>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     const int grid = a.batch * a.t_tiles * a.n_tiles * a.ksplit;
-    hipLaunchKernelGGL((conv_nt_bf16_kernel<IT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid), dim3(64 * WM * WN), LDS_BYTES, s,
-                       a);
+    hipLaunchKernelGGL((conv_nt_bf16_kernel<M32, IT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid), dim3(64 * WM * WN),
+                       LDS_BYTES, s, a);
     return sl_check_launch("sl_conv1d_nt(bf16)");
 }
 
@@ -329,14 +411,15 @@ int launch_tail(const NtArgs& a, int rows_per_batch, hipStream_t s) {
     return sl_check_launch("sl_conv1d_nt(bf16 split-K epilogue)");
 }
 
-template <int IT, int WM, int WN, int STAGES>
+template <bool M32, int IT, int WM, int WN, int STAGES>
 int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
-    a.t_tiles = (a.t_out + 16 * IT * WM - 1) / (16 * IT * WM);
+    constexpr int BM = (M32 ? 64 : 16 * IT) * WM;
+    a.t_tiles = (a.t_out + BM - 1) / BM;
     a.n_tiles = a.cout / (64 * WN);
     if (a.ksplit > 1) {
-        int rc = launch_main<IT, WM, WN, STAGES, MODE_PARTIAL, true>(a, s);
+        int rc = launch_main<M32, IT, WM, WN, STAGES, MODE_PARTIAL, true>(a, s);
         if (rc != SL_OK) return rc;
-        const int rows = a.t_tiles * 16 * IT * WM;
+        const int rows = a.t_tiles * BM;
         if (out_f32) {
             if (epilogue == SL_EPI_BIAS) return launch_tail<SL_EPI_BIAS, true>(a, rows, s);
             if (epilogue == SL_EPI_NONE) return launch_tail<SL_EPI_NONE, true>(a, rows, s);
@@ -349,14 +432,14 @@ int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
             }
         }
     } else if (out_f32) {
-        if (epilogue == SL_EPI_BIAS) return launch_main<IT, WM, WN, STAGES, SL_EPI_BIAS, true>(a, s);
-        if (epilogue == SL_EPI_NONE) return launch_main<IT, WM, WN, STAGES, SL_EPI_NONE, true>(a, s);
+        if (epilogue == SL_EPI_BIAS) return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS, true>(a, s);
+        if (epilogue == SL_EPI_NONE) return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_NONE, true>(a, s);
     } else {
         switch (epilogue) {
-            case SL_EPI_NONE: return launch_main<IT, WM, WN, STAGES, SL_EPI_NONE, false>(a, s);
-            case SL_EPI_BIAS: return launch_main<IT, WM, WN, STAGES, SL_EPI_BIAS, false>(a, s);
-            case SL_EPI_BIAS_RELU: return launch_main<IT, WM, WN, STAGES, SL_EPI_BIAS_RELU, false>(a, s);
-            case SL_EPI_RELU_MASK: return launch_main<IT, WM, WN, STAGES, SL_EPI_RELU_MASK, false>(a, s);
+            case SL_EPI_NONE: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_NONE, false>(a, s);
+            case SL_EPI_BIAS: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS, false>(a, s);
+            case SL_EPI_BIAS_RELU: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS_RELU, false>(a, s);
+            case SL_EPI_RELU_MASK: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_RELU_MASK, false>(a, s);
         }
     }
     sl_set_error("sl_conv1d_nt(bf16): unsupported epilogue %d with out_f32=%d", epilogue, out_f32);
@@ -364,42 +447,51 @@ int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
 }
 
 struct Cfg {
-    int wm, wn, stages, ksplit, it;
-    int bm() const { return 16 * it * wm; }
+    int wm, wn, stages, ksplit, it, m32;
+    int bm() const { return (m32 ? 64 : 16 * it) * wm; }
 };
 
-// cfg word: wm | wn << 4 | stages << 8 | ksplit << 12 | it << 20 (it = 0 means 4); 0 = choose automatically
+// cfg word: wm | wn << 4 | stages << 8 | ksplit << 12 | it << 20 (it = 0 means 4) | m32 << 24; 0 = choose automatically
 Cfg decode_cfg(int cfg) {
-    Cfg c{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 15, (cfg >> 12) & 255, (cfg >> 20) & 15};
+    Cfg c{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 15, (cfg >> 12) & 255, (cfg >> 20) & 15, (cfg >> 24) & 1};
     if (c.it == 0) c.it = 4;
+    if (c.m32) c.it = 4;
     return c;
 }
 
 Cfg auto_cfg(const sl_conv_geom* g) {
-    // Table measured on MI355X with tools/tune_kernels.py (profiles/r01_tune_nt.json): see DESIGN.md "NT kernel tuning".
+    // Table measured on MI355X with tools/tune_kernels.py (profiles/r01_tune_kernels.json), see DESIGN.md section 3.1.
     const long nsteps = (long)g->taps * (g->cin / BK);
     if (g->cout % 256 == 0) {
         const long tiles256 = (long)g->batch * ((g->t_out + 255) / 256) * (g->cout / 256);
         // 256x256 tile, 16 waves, one work-group per CU: 1.35 PFLOP/s on big_conv_1 (vs 1.03 for 128x128)
-        if (tiles256 >= 192) return Cfg{4, 4, 2, 1, 4};
+        if (tiles256 >= 192) return Cfg{4, 4, 2, 1, 4, 0};
         if (nsteps >= 256) {  // long contraction but few tiles (dgrad of big_conv_1: 64 tiles, K = 65536): split K
             long ks = (256 + tiles256 - 1) / tiles256;
             if (ks > 8) ks = 8;
-            return Cfg{4, 4, 2, (int)ks, 4};
+            return Cfg{4, 4, 2, (int)ks, 4, 0};
         }
     }
     // short layers (one 128x128 tile per CU at most): 8 waves of 32x64 per tile so that each SIMD holds two waves and
     // one wave's DMA issue overlaps the other's MFMAs; 3-deep ring
-    return Cfg{4, 2, 3, 1, 2};
+    return Cfg{4, 2, 3, 1, 2, 0};
 }
 
 bool valid_cfg(const Cfg& c, const sl_conv_geom* g) {
-    const bool shape = (c.it == 2 && c.wm == 4 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) ||
-                       (c.it == 2 && c.wm == 8 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
-                       (c.it == 4 && c.wm == 2 && c.wn == 2 && (c.stages >= 2 && c.stages <= 4)) ||
-                       (c.it == 4 && c.wm == 4 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
-                       (c.it == 4 && c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
-                       (c.it == 4 && c.wm == 4 && c.wn == 4 && c.stages == 2);
+    bool shape;
+    if (c.m32)
+        shape = (c.wm == 2 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) || (c.wm == 4 && c.wn == 4 && c.stages == 2) ||
+                (c.wm == 4 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
+                (c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3));
+    else
+        shape = (c.it == 2 && c.wm == 2 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) ||
+                (c.it == 2 && c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
+                (c.it == 2 && c.wm == 4 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) ||
+                (c.it == 2 && c.wm == 8 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
+                (c.it == 4 && c.wm == 2 && c.wn == 2 && (c.stages >= 2 && c.stages <= 4)) ||
+                (c.it == 4 && c.wm == 4 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
+                (c.it == 4 && c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
+                (c.it == 4 && c.wm == 4 && c.wn == 4 && c.stages == 2);
     if (!shape || c.ksplit < 1) return false;
     if (g->cout % (64 * c.wn)) return false;
     const long nsteps = (long)g->taps * (g->cin / BK);
@@ -419,8 +511,9 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
                  int epilogue, int out_f32, int cfg, void* workspace, size_t workspace_bytes, hipStream_t s) {
     Cfg c = cfg ? decode_cfg(cfg) : auto_cfg(g);
     if (!valid_cfg(c, g)) {
-        sl_set_error("sl_conv1d_nt(bf16): invalid tile configuration it=%d wm=%d wn=%d stages=%d ksplit=%d for cout=%d",
-                     c.it, c.wm, c.wn, c.stages, c.ksplit, g->cout);
+        sl_set_error(
+            "sl_conv1d_nt(bf16): invalid tile configuration m32=%d it=%d wm=%d wn=%d stages=%d ksplit=%d for cout=%d",
+            c.m32, c.it, c.wm, c.wn, c.stages, c.ksplit, g->cout);
         return SL_ERR_INVALID_ARGUMENT;
     }
     NtArgs a;
@@ -440,8 +533,9 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
     a.y_bs = g->y_batch_stride;
     a.cout = g->cout;
     a.w_rs = g->taps * g->cin;
-    a.chunks = g->cin / BK;
-    a.nsteps = g->taps * a.chunks;
+    a.taps = g->taps;
+    a.cin = g->cin;
+    a.nsteps = g->taps * (g->cin / BK);
     a.ksplit = c.ksplit;
     a.steps_per_split = (a.nsteps + c.ksplit - 1) / c.ksplit;
     a.ksplit = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;  // no empty splits
@@ -452,22 +546,35 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
             return SL_ERR_WORKSPACE_TOO_SMALL;
         }
     }
-#define SL_NT_CASE(IT_, WM_, WN_, ST_)                                  \
-    if (c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
-        return launch_cfg<IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);
-    SL_NT_CASE(4, 2, 2, 2)
-    SL_NT_CASE(4, 2, 2, 3)
-    SL_NT_CASE(4, 2, 2, 4)
-    SL_NT_CASE(4, 4, 2, 2)
-    SL_NT_CASE(4, 4, 2, 3)
-    SL_NT_CASE(4, 2, 4, 2)
-    SL_NT_CASE(4, 2, 4, 3)
-    SL_NT_CASE(4, 4, 4, 2)
-    SL_NT_CASE(2, 4, 2, 2)
-    SL_NT_CASE(2, 4, 2, 3)
-    SL_NT_CASE(2, 4, 2, 4)
-    SL_NT_CASE(2, 8, 2, 2)
-    SL_NT_CASE(2, 8, 2, 3)
+#define SL_NT_CASE(M32_, IT_, WM_, WN_, ST_)                                                \
+    if (c.m32 == M32_ && c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
+        return launch_cfg<(M32_ != 0), IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);
+    SL_NT_CASE(0, 4, 2, 2, 2)
+    SL_NT_CASE(0, 4, 2, 2, 3)
+    SL_NT_CASE(0, 4, 2, 2, 4)
+    SL_NT_CASE(0, 4, 4, 2, 2)
+    SL_NT_CASE(0, 4, 4, 2, 3)
+    SL_NT_CASE(0, 4, 2, 4, 2)
+    SL_NT_CASE(0, 4, 2, 4, 3)
+    SL_NT_CASE(0, 4, 4, 4, 2)
+    SL_NT_CASE(0, 2, 2, 2, 2)
+    SL_NT_CASE(0, 2, 2, 2, 3)
+    SL_NT_CASE(0, 2, 2, 2, 4)
+    SL_NT_CASE(0, 2, 2, 4, 2)
+    SL_NT_CASE(0, 2, 2, 4, 3)
+    SL_NT_CASE(0, 2, 4, 2, 2)
+    SL_NT_CASE(0, 2, 4, 2, 3)
+    SL_NT_CASE(0, 2, 4, 2, 4)
+    SL_NT_CASE(0, 2, 8, 2, 2)
+    SL_NT_CASE(0, 2, 8, 2, 3)
+    SL_NT_CASE(1, 4, 2, 2, 2)
+    SL_NT_CASE(1, 4, 2, 2, 3)
+    SL_NT_CASE(1, 4, 2, 2, 4)
+    SL_NT_CASE(1, 4, 4, 2, 2)
+    SL_NT_CASE(1, 4, 4, 2, 3)
+    SL_NT_CASE(1, 4, 2, 4, 2)
+    SL_NT_CASE(1, 4, 2, 4, 3)
+    SL_NT_CASE(1, 4, 4, 4, 2)
 #undef SL_NT_CASE
     sl_set_error("sl_conv1d_nt(bf16): configuration not instantiated");
     return SL_ERR_UNSUPPORTED;

@@ -122,7 +122,90 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     ((f32x4*)p)[i] = pv;
 }
 
+// Fused Adam + operand repack for ONE layer: a single pass over the layer's fp32 master weights / gradient / moments
+// [k][cin][cout] (+ the bias block that follows them) that also emits both device operand layouts
+//   w_fwd [cout][k][cin]   (32x64 tile transposed through LDS)   and   w_dgrad[cin][k-1-tap][cout]
+// 4 fp32 reads + 3 fp32 writes + 2 narrow writes per parameter instead of Adam (4r+3w) followed by pack (1r+2w).
+// grid (cout/64, cin/32, k + 1): z == k is the bias block (only y == 0 works there).
+template <typename T>
+__global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, T* __restrict__ wf,
+                                                        T* __restrict__ wd, int k, int cin, int cout, float lr_t, float b1,
+                                                        float b2, float eps) {
+    __shared__ float tile[32][65];
+    const int tap = blockIdx.z;
+    const int co0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    auto adam4 = [&](long idx) {
+        const f32x4 gv = *(const f32x4*)(g + idx);
+        f32x4 mv = *(f32x4*)(m + idx), vv = *(f32x4*)(v + idx), pv = *(f32x4*)(p + idx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mv[j] = b1 * mv[j] + (1.f - b1) * gv[j];
+            vv[j] = b2 * vv[j] + (1.f - b2) * gv[j] * gv[j];
+            pv[j] = pv[j] - lr_t * mv[j] / (sqrtf(vv[j]) + eps);
+        }
+        *(f32x4*)(m + idx) = mv;
+        *(f32x4*)(v + idx) = vv;
+        *(f32x4*)(p + idx) = pv;
+        return pv;
+    };
+    if (tap == k) {  // bias block: cout floats right behind the weights
+        if (blockIdx.y == 0 && ty == 0) adam4((long)k * cin * cout + co0 + tx * 4);
+        return;
+    }
+    const int ci0 = blockIdx.y * 32;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int cil = ty + r * 16;
+        const long idx = ((long)tap * cin + ci0 + cil) * cout + co0 + tx * 4;
+        const f32x4 pv = adam4(idx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[cil][tx * 4 + j] = pv[j];
+        if (wd) {
+            T* o = wd + ((long)(ci0 + cil) * k + (k - 1 - tap)) * cout + co0 + tx * 4;
+            if (sizeof(T) == 2) {
+                *(u32x2*)o = (u32x2){pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+            } else {
+                *(f32x4*)o = pv;
+            }
+        }
+    }
+    __syncthreads();
+    // transposed store: 64 co rows x 32 ci; thread -> (co = threadIdx/8 + 32*r, ci4 = (threadIdx%8)*4)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int col = (threadIdx.x >> 3) + r * 32;
+        const int ci4 = (threadIdx.x & 7) * 4;
+        T* o = wf + ((long)(co0 + col) * k + tap) * cin + ci0 + ci4;
+        const float a0 = tile[ci4][col], a1 = tile[ci4 + 1][col], a2 = tile[ci4 + 2][col], a3 = tile[ci4 + 3][col];
+        if (sizeof(T) == 2) {
+            *(u32x2*)o = (u32x2){pack_bf16x2(a0, a1), pack_bf16x2(a2, a3)};
+        } else {
+            *(f32x4*)o = (f32x4){a0, a1, a2, a3};
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int sl_adam_pack_layer(float* param, const float* grad, float* m, float* v, void* w_fwd, void* w_dgrad, int k,
+                                  int cin_pad, int cout_pad, int dtype, int step, float lr, float beta1, float beta2,
+                                  float eps, void* stream) {
+    SL_CHECK_ARG(param && grad && m && v && w_fwd, "sl_adam_pack_layer: null pointer");
+    SL_CHECK_ARG(k > 0 && cin_pad > 0 && cout_pad > 0 && cin_pad % 32 == 0 && cout_pad % 64 == 0 && step >= 1,
+                 "sl_adam_pack_layer: need cin_pad %% 32 == 0, cout_pad %% 64 == 0, step >= 1");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    dim3 grid(cout_pad / 64, cin_pad / 32, k + 1);
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL((adam_pack_kernel<unsigned short>), grid, dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                           (unsigned short*)w_fwd, (unsigned short*)w_dgrad, k, cin_pad, cout_pad, (float)lr_t, beta1,
+                           beta2, eps);
+    else
+        hipLaunchKernelGGL((adam_pack_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                           (float*)w_fwd, (float*)w_dgrad, k, cin_pad, cout_pad, (float)lr_t, beta1, beta2, eps);
+    return sl_check_launch("sl_adam_pack_layer");
+}
 
 extern "C" int sl_pack_weights(const float* w_master, void* w_fwd, void* w_dgrad, int k, int cin_pad, int cout_pad,
                                int dtype, void* stream) {

@@ -449,56 +449,72 @@ class Engine:
         return buf.loss
 
     def backward(self, on_bucket_ready=None):
-        """wgrad / bias-grad / dgrad for every trainable layer, output layer first.  on_bucket_ready(i) is called
-        after the launches that complete gradient bucket i (see bucket_ranges) have been enqueued."""
+        """wgrad / bias-grad / dgrad for every trainable layer, output layer first.
+
+        Two HIP streams: the MAIN stream carries the critical chain dgrad_n -> dgrad_{n-1} -> ... (each needs the
+        previous one's output), the SIDE stream carries every layer's wgrad + bias-grad, which only need g[i] and the
+        saved activation.  The short layers put one work-group on each CU at most, so a wgrad and a dgrad kernel of
+        different layers co-reside on the CUs instead of running back to back; the HBM-bound bias gradients stream
+        underneath the MFMA-bound kernels.  on_bucket_ready(i) is called (on the side stream) once the launches that
+        complete gradient bucket i (see bucket_ranges) have been enqueued."""
         buf = self.cur
-        st = self._stream()
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
         side = self._side_stream
         first = self.frozen_layer_count
         _, split = self.bucket_ranges()
-
-        def join_side():
-            done = torch.cuda.Event()
-            done.record(side)
-            main.wait_event(done)
-
         for p in reversed(self.plans[first:]):
             i = p.index
             x = buf.x0 if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
-            # the bias gradient only streams g[i] once (HBM-bound): it runs on a side stream underneath the MFMA-bound
-            # wgrad/dgrad kernels of the same layer instead of in front of them
             ready = torch.cuda.Event()
-            ready.record(main)
+            ready.record(main)  # g[i] (CTC gradient or the previous dgrad) is complete at this point of MAIN
             with torch.cuda.stream(side):
                 side.wait_event(ready)
+                self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
+                             dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
+                             self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
+                             buf.wgrad_ws.numel(), side.cuda_stream)
                 self._launch("bgrad:" + p.spec.name, "sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(),
                              ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, buf.bias_ws.data_ptr(),
                              buf.bias_ws.numel(), side.cuda_stream)
-            self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), dw.data_ptr(),
-                          ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, self.nt_cfg.get(("wgrad", p.spec.name), 0),
-                          buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
-            if on_bucket_ready is not None and i == split:
-                join_side()
-                on_bucket_ready(0)
+                if on_bucket_ready is not None and i == split:
+                    on_bucket_ready(0)
             if i > first:
-                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
-                              buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
-                              _lib.EPI_RELU_MASK, self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
-                              buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-        join_side()
+                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(),
+                             None, buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
+                             _lib.EPI_RELU_MASK, self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
+                             buf.nt_ws.data_ptr(), buf.nt_ws.numel(), main.cuda_stream)
         if on_bucket_ready is not None and split > first:
-            on_bucket_ready(1)
+            with torch.cuda.stream(side):
+                on_bucket_ready(1)
+        done = torch.cuda.Event()
+        done.record(side)
+        main.wait_event(done)
 
-    def adam_step(self):
+    def adam_step(self, fused=True):
+        """Keras-2.0 Adam on the flat fp32 masters.  fused=True: one kernel per trainable layer that applies Adam AND
+        rewrites the layer's two bf16 operand copies in the same pass (no separate repack); fused=False: one flat
+        elementwise launch, operands repacked lazily by the next forward()."""
         self.adam_iterations += 1
-        self._launch("adam", "sl_adam_step", self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
-                      self.adam_v.data_ptr(), self.param_numel, self.adam_iterations, self.lr, self.beta_1,
-                      self.beta_2, self.adam_epsilon, self._stream())
-        self._packed_dirty = True
+        st = self._stream()
+        if not fused:
+            self._launch("adam", "sl_adam_step", self.params.data_ptr(), self.grads.data_ptr(),
+                         self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.param_numel, self.adam_iterations,
+                         self.lr, self.beta_1, self.beta_2, self.adam_epsilon, st)
+            self._packed_dirty = True
+            return
+        if self._packed_dirty:
+            self.repack_weights()  # frozen layers keep these copies; trainable ones are rewritten below
+        for p in self.plans[self.frozen_layer_count:]:
+            off = p.w_off * 4
+            wd = self.w_dgrad[p.index]
+            self._launch("adam:" + p.spec.name, "sl_adam_pack_layer", self.params.data_ptr() + off,
+                         self.grads.data_ptr() + off, self.adam_m.data_ptr() + off, self.adam_v.data_ptr() + off,
+                         self.w_fwd[p.index].data_ptr(), wd.data_ptr() if wd is not None else None,
+                         p.spec.kernel_size, p.cin_pad, p.cout_pad, self.dtype_code, self.adam_iterations, self.lr,
+                         self.beta_1, self.beta_2, self.adam_epsilon, st)
 
     def train_step(self, input_batch, label_batch, label_lengths, prediction_lengths, reducer=None):
         """One full optimisation step (forward, CTC, backward, [gradient all-reduce], Adam, weight repack).
@@ -518,5 +534,4 @@ class Engine:
             self.backward(on_bucket_ready=reducer.reduce_bucket)
             reducer.wait_all()
         self.adam_step()
-        self.repack_weights()
         return loss

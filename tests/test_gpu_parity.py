@@ -512,3 +512,45 @@ def test_single_layer_kernels_with_exact_operands(dtype, layer):
                                                  bias.astype(np.float64), s.stride), 0)
         tol = 1e-5 if dtype == "f32" else 3e-3
         assert rel_l2(got, want) < tol, ("forward", dtype, layer, rel_l2(got, want))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_fused_adam_pack_equals_adam_then_pack(dtype):
+    """sl_adam_pack_layer (one pass: Adam + both operand layouts) against sl_adam_step followed by sl_pack_weights, and
+    the masters against the Keras-2.0 formula of the oracle."""
+    import torch
+    case = make_case(b=2, t=64, seed=8)
+    engines = []
+    for fused in (False, True):
+        eng = make_engine(case, dtype, lr=1e-3)
+        run_loss_and_grads(eng, case)
+        for _ in range(2):  # two steps on the same gradient: exercises non-zero moments
+            eng.adam_step(fused=fused)
+            if not fused:
+                eng.repack_weights()
+        torch.cuda.synchronize()
+        engines.append(eng)
+    a, b = engines
+    # not bitwise: hipcc contracts b1*m + (1-b1)*g into FMAs differently in the two kernels (last-ulp differences)
+    for x, y in ((a.params, b.params), (a.adam_m, b.adam_m), (a.adam_v, b.adam_v)):
+        assert torch.allclose(x, y, rtol=2e-6, atol=1e-9)
+    ulp = 2.0 ** -7 if dtype == "bf16" else 1e-6  # a last-ulp master difference may flip one bf16 rounding
+    for i in range(len(a.plans)):
+        assert torch.allclose(a.w_fwd[i].float(), b.w_fwd[i].float(), rtol=ulp, atol=1e-9), i
+        if a.w_dgrad[i] is not None:
+            assert torch.allclose(a.w_dgrad[i].float(), b.w_dgrad[i].float(), rtol=ulp, atol=1e-9), i
+        # and the two operand copies of the fused path hold exactly the rounded masters, in the right layout
+        p = b.plans[i]
+        wv, _ = b.layer_param_views(b.params, p)
+        assert torch.equal(b.w_fwd[i], wv.permute(2, 0, 1).contiguous().to(b.torch_dtype)), i
+        if b.w_dgrad[i] is not None:
+            assert torch.equal(b.w_dgrad[i], wv.flip(0).permute(1, 0, 2).contiguous().to(b.torch_dtype)), i
+    grads = a.get_gradients()
+    for (w0, b0), (w2, b2), (gw, gb) in zip(case["weights"], a.get_weights(), grads):
+        p, m, v = w0.astype(np.float64), np.zeros_like(w0, dtype=np.float64), np.zeros_like(w0, dtype=np.float64)
+        pb, mb, vb = b0.astype(np.float64), np.zeros_like(b0, dtype=np.float64), np.zeros_like(b0, dtype=np.float64)
+        for step in (1, 2):
+            p, m, v = o.keras_adam_step(p, gw.astype(np.float64), m, v, step, lr=1e-3)
+            pb, mb, vb = o.keras_adam_step(pb, gb.astype(np.float64), mb, vb, step, lr=1e-3)
+        np.testing.assert_allclose(w2, p, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(b2, pb, rtol=1e-5, atol=1e-7)

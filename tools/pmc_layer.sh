@@ -1,0 +1,25 @@
+# usage: bash tools/pmc_layer.sh <kind> <layer> <kernel-name-substring>
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+KIND=$1; LAYER=$2; SUB=$3
+run() { name=$1; shift
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_${LAYER}_$name -o p -- python tools/run_one.py --kind $KIND --layer $LAYER --reps 5 > gpurun_out/pmc_${LAYER}_$name.log 2>&1; }
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES
+run ta TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run grbm GRBM_GUI_ACTIVE
+python - <<PY
+import csv,glob
+for name in ["sq1","sq2","ta","fetch","write","grbm"]:
+    fs=glob.glob("gpurun_out/pmc_${LAYER}_%s/*counter_collection.csv"%name)
+    if not fs: print(name,"no file"); continue
+    rows=[r for r in csv.DictReader(open(fs[0])) if "$SUB" in r["Kernel_Name"]]
+    if not rows: print(name,"no rows"); continue
+    ids=sorted(set(int(r["Dispatch_Id"]) for r in rows))[-5:]
+    agg={}
+    for r in rows:
+        if int(r["Dispatch_Id"]) in ids: agg.setdefault(r["Counter_Name"],[]).append(float(r["Counter_Value"]))
+    dur=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"])) for r in rows if int(r["Dispatch_Id"]) in ids]
+    print(name,"dur_us",round(sum(dur)/len(dur)/1e3,1),{k:round(sum(v)/len(v)) for k,v in agg.items()},"grid",rows[0]["Grid_Size"],"wg",rows[0]["Workgroup_Size"])
+PY

@@ -17,8 +17,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def cfg_word(wm, wn, stages, ksplit, it=4):
-    return wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20)
+def cfg_word(wm, wn, stages, ksplit, it=4, m32=0):
+    return wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20) | (m32 << 24)
 
 
 def main():
@@ -57,7 +57,11 @@ def main():
     ws = torch.empty((512 << 20,), dtype=torch.uint8, device=eng.device)
     st = torch.cuda.current_stream().cuda_stream
     shapes = [(2, 2, 2, 4), (2, 2, 3, 4), (2, 2, 4, 4), (4, 2, 2, 4), (4, 2, 3, 4), (2, 4, 2, 4), (2, 4, 3, 4), (4, 4, 2, 4),
-              (4, 2, 2, 2), (4, 2, 3, 2), (4, 2, 4, 2), (8, 2, 2, 2), (8, 2, 3, 2)]
+              (4, 2, 2, 2), (4, 2, 3, 2), (4, 2, 4, 2), (8, 2, 2, 2), (8, 2, 3, 2),
+              (2, 2, 2, 2), (2, 2, 3, 2), (2, 2, 4, 2), (2, 4, 2, 2), (2, 4, 3, 2),  # 64-row tiles: 2+ work-groups per CU
+              # it = 32: the v_mfma_f32_32x32x16_bf16 variant (64x64 wave patch)
+              (2, 2, 2, 32), (2, 2, 3, 32), (2, 2, 4, 32), (4, 2, 2, 32), (4, 2, 3, 32), (2, 4, 2, 32), (2, 4, 3, 32),
+              (4, 4, 2, 32)]
     results = {}
     n = len(eng.plans)
 
@@ -92,7 +96,7 @@ def main():
             for ks in (1, 2, 4, 8):
                 if ks > 1 and nsteps < 12 * ks:
                     continue
-                cfg = cfg_word(wm, wn, stg, ks, it)
+                cfg = cfg_word(wm, wn, stg, ks, 4, 1) if it == 32 else cfg_word(wm, wn, stg, ks, it)
                 try:
                     out = run(kind, p, cfg)
                     torch.cuda.synchronize()
