@@ -131,18 +131,30 @@ def main():
     eng.timeline = None
     avg_ms = {tag: float(np.mean(v)) for tag, v in per_tag.items()}
     names = [s.name for s in specs]
-    # dominant kernel = conv_nt_bf16_kernel<BIAS_RELU, bf16 out>: the forward of the 10 hidden layers
-    fwd_tags = ["fwd:" + n for n in names[:-1]]
-    fwd_flops = sum(fl[:-1]) * BATCH_PER_GPU / len(fwd_tags)           # algorithmic FLOPs per launch (average)
-    fwd_ms = sum(avg_ms[t] for t in fwd_tags) / len(fwd_tags)            # average launch duration
-    achieved = fwd_flops / (fwd_ms * 1e-3) / 1e12
+    # Dominant kernel (largest share of GPU time in profiles/r01b_kernel_stats.csv, 22 %): wgrad_tn_bf16_kernel<4,4,2>,
+    # the 256x256-tile weight-gradient kernel.  Three launches per step use this instantiation (the library's measured
+    # table picks it for striding_conv, big_conv_1, big_conv_2); algorithmic FLOPs per launch = their average.
+    dom_layers = ["striding_conv", "big_conv_1", "big_conv_2"]
+    dom_tags = ["wgrad:" + n for n in dom_layers]
+    dom_flops = sum(fl[names.index(n)] for n in dom_layers) * BATCH_PER_GPU / len(dom_tags)
+    dom_ms = sum(avg_ms[t] for t in dom_tags) / len(dom_tags)
+    achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+    traffic = None
+    pmc = ROOT / "profiles" / "r01c_pmc_traffic_wgrad442.json"
+    if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 read correction)
+        traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
+    # second kernel by time: the 256x256 forward/dgrad NT kernel (fwd of big_conv_1 and big_conv_2)
+    nt_tags = ["fwd:big_conv_1", "fwd:big_conv_2"]
+    nt_flops = (fl[names.index("big_conv_1")] + fl[names.index("big_conv_2")]) * BATCH_PER_GPU / 2
+    nt_ms = sum(avg_ms[t] for t in nt_tags) / 2
     groups = {}
     for prefix, flops_of in (("fwd", lambda i: fl[i]), ("dgrad", lambda i: fl[i]), ("wgrad", lambda i: fl[i])):
         tags = [(i, prefix + ":" + n) for i, n in enumerate(names) if prefix + ":" + n in avg_ms]
         ms = sum(avg_ms[t] for _, t in tags)
         groups[prefix] = {"ms_per_step": ms, "tflops": sum(flops_of(i) for i, _ in tags) * BATCH_PER_GPU / (ms * 1e-3) / 1e12}
-    for other in ("ctc", "softmax", "adam"):
+    for other in ("ctc", "softmax"):
         groups[other] = {"ms_per_step": avg_ms.get(other, 0.0)}
+    groups["adam_and_repack"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("adam"))}
     groups["bias_grad"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("bgrad:"))}
     groups["pack_weights"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("pack:"))}
     groups["big_conv_1"] = {k: avg_ms.get(k + ":big_conv_1") for k in ("fwd", "dgrad", "wgrad")}
@@ -173,11 +185,18 @@ def main():
                    "parallelism": "dp{}".format(world)},
         "final_mean_loss": final_loss,
         "step_mfma_frac": utt_per_s * fwdbwd_flops_per_utt / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world),
-        "roofline": {"bound": "mfma", "kernel": "conv_nt_bf16_kernel<SL_EPI_BIAS_RELU,bf16-out> (forward of the 10 "
-                                                "hidden conv layers; average over its launches in a step)",
+        "roofline": {"bound": "mfma", "kernel": "wgrad_tn_bf16_kernel<4,4,2> (weight gradient of striding_conv, "
+                                                "big_conv_1, big_conv_2; average over its 3 launches per step)",
                      "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
-                     "flops_per_launch": fwd_flops, "avg_launch_ms": fwd_ms},
+                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits "
+                                     "included), from profiles/r01c_pmc_traffic_wgrad442.json",
+                     "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms},
+        "roofline_nt_256x256": {"bound": "mfma", "kernel": "conv_nt_bf16_kernel<M32=0,IT=4,WM=4,WN=4,STAGES=2,"
+                                                           "BIAS_RELU,bf16> (forward of big_conv_1, big_conv_2)",
+                                "achieved": nt_flops / (nt_ms * 1e-3) / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": nt_flops / (nt_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                                "flops_per_launch": nt_flops, "avg_launch_ms": nt_ms},
         "kernels": groups,
     }
     if world == 1 and not args.no_cpu_baseline:

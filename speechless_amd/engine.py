@@ -265,6 +265,7 @@ class Engine:
         self.cur = None
         self.timeline = None
         self._side_stream = None
+        self.overlap_wgrad = False
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
 
     # ------------------------------------------------------------------ plumbing
@@ -451,12 +452,12 @@ class Engine:
     def backward(self, on_bucket_ready=None):
         """wgrad / bias-grad / dgrad for every trainable layer, output layer first.
 
-        Two HIP streams: the MAIN stream carries the critical chain dgrad_n -> dgrad_{n-1} -> ... (each needs the
-        previous one's output), the SIDE stream carries every layer's wgrad + bias-grad, which only need g[i] and the
-        saved activation.  The short layers put one work-group on each CU at most, so a wgrad and a dgrad kernel of
-        different layers co-reside on the CUs instead of running back to back; the HBM-bound bias gradients stream
-        underneath the MFMA-bound kernels.  on_bucket_ready(i) is called (on the side stream) once the launches that
-        complete gradient bucket i (see bucket_ranges) have been enqueued."""
+        The HBM-bound bias gradients (they only stream g[i] once) run on a SIDE stream underneath the MFMA-bound
+        wgrad/dgrad kernels instead of in front of them.  With self.overlap_wgrad the weight gradients move to the side
+        stream as well, under the critical dgrad chain of the MAIN stream (they only need g[i] and the saved
+        activation; the short layers put at most one work-group on a CU, so kernels of different layers co-reside).
+        That is worth +1.3 % at B=32 but makes per-kernel event/rocprof durations overlap, so it is off by default.
+        on_bucket_ready(i) is called once the launches that complete gradient bucket i (bucket_ranges) are enqueued."""
         buf = self.cur
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
@@ -464,34 +465,53 @@ class Engine:
         side = self._side_stream
         first = self.frozen_layer_count
         _, split = self.bucket_ranges()
+
+        def join_side():
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
+
         for p in reversed(self.plans[first:]):
             i = p.index
             x = buf.x0 if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
             ready = torch.cuda.Event()
             ready.record(main)  # g[i] (CTC gradient or the previous dgrad) is complete at this point of MAIN
+            wgrad_stream = side if self.overlap_wgrad else main
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
-                             dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
-                             self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
-                             buf.wgrad_ws.numel(), side.cuda_stream)
+                if self.overlap_wgrad:
+                    self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
+                                 dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
+                                 self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
+                                 buf.wgrad_ws.numel(), wgrad_stream.cuda_stream)
                 self._launch("bgrad:" + p.spec.name, "sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(),
                              ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, buf.bias_ws.data_ptr(),
                              buf.bias_ws.numel(), side.cuda_stream)
+                if self.overlap_wgrad and on_bucket_ready is not None and i == split:
+                    on_bucket_ready(0)
+            if not self.overlap_wgrad:
+                self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
+                             dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
+                             self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
+                             buf.wgrad_ws.numel(), main.cuda_stream)
                 if on_bucket_ready is not None and i == split:
+                    join_side()
                     on_bucket_ready(0)
             if i > first:
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(),
                              None, buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
                              _lib.EPI_RELU_MASK, self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
                              buf.nt_ws.data_ptr(), buf.nt_ws.numel(), main.cuda_stream)
-        if on_bucket_ready is not None and split > first:
-            with torch.cuda.stream(side):
+        if self.overlap_wgrad:
+            if on_bucket_ready is not None and split > first:
+                with torch.cuda.stream(side):
+                    on_bucket_ready(1)
+            join_side()
+        else:
+            join_side()
+            if on_bucket_ready is not None and split > first:
                 on_bucket_ready(1)
-        done = torch.cuda.Event()
-        done.record(side)
-        main.wait_event(done)
 
     def adam_step(self, fused=True):
         """Keras-2.0 Adam on the flat fp32 masters.  fused=True: one kernel per trainable layer that applies Adam AND
