@@ -43,7 +43,9 @@ typedef enum sl_epilogue {
     SL_EPI_NONE = 0,      /* y = acc                                  (dgrad into a linear layer)              */
     SL_EPI_BIAS = 1,      /* y = acc + bias[co]                       (output_conv logits, net.py:328-330)     */
     SL_EPI_BIAS_RELU = 2, /* y = max(acc + bias[co], 0)               (Conv1D(activation="relu"), net.py:304)  */
-    SL_EPI_RELU_MASK = 3  /* y = acc * (mask[b,t,co] > 0)             (autodiff through relu, net.py:389,550)  */
+    SL_EPI_RELU_MASK = 3, /* y = acc * (mask[b,t,co] > 0)             (autodiff through relu, net.py:389,550)  */
+    SL_EPI_BIAS_ELU = 4,  /* y = elu(acc + bias[co])                  (activation="elu", main.py:71-78)         */
+    SL_EPI_ELU_MASK = 5   /* y = acc * (m > 0 ? 1 : m + 1), m = mask  (autodiff through elu via its output)      */
 } sl_epilogue;
 
 /*

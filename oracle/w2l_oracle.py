@@ -314,6 +314,7 @@ def loss_and_gradients(specs, weights, input_batch, labels, prediction_lengths, 
     dz = softmax_backward(probs, dprobs) / bsz
     dlogits = dz.copy()
     grads = [(np.zeros_like(w), np.zeros_like(b)) for (w, b) in weights]
+    dzs = [None] * len(specs)  # dL/d(pre-activation) per layer, as consumed by that layer's wgrad/dgrad
     # frozen layers (net.py:335-339) are the FIRST frozen_layer_count layers: no dW/db for them and no
     # dgrad below the first trainable layer.
     for li in range(len(specs) - 1, frozen_layer_count - 1, -1):
@@ -324,6 +325,7 @@ def loss_and_gradients(specs, weights, input_batch, labels, prediction_lengths, 
             dz = round_to_bf16(dz).astype(dz.dtype)
         dx, dw, db = conv1d_backward(xs[li], w, spec.stride, dz)
         grads[li] = (dw, db)
+        dzs[li] = dz
         if li == frozen_layer_count:
             break
         prev_spec = specs[li - 1]
@@ -335,7 +337,7 @@ def loss_and_gradients(specs, weights, input_batch, labels, prediction_lengths, 
             dz = dx * np.where(zs[li - 1] > 0, 1.0, np.exp(np.minimum(zs[li - 1], 0)))
         else:
             raise ValueError(prev_spec.activation)
-    return dict(probs=probs, losses=losses, mean_loss=losses.mean(), grads=grads, dlogits=dlogits)
+    return dict(probs=probs, losses=losses, mean_loss=losses.mean(), grads=grads, dlogits=dlogits, dzs=dzs)
 
 
 # ----------------------------------------------------------------------------------------------

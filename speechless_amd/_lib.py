@@ -18,6 +18,8 @@ EPI_NONE = 0
 EPI_BIAS = 1
 EPI_BIAS_RELU = 2
 EPI_RELU_MASK = 3
+EPI_BIAS_ELU = 4
+EPI_ELU_MASK = 5
 
 
 class ConvGeom(ctypes.Structure):

@@ -1,0 +1,78 @@
+"""Host-side batch formation for the long-form regime (BASELINE config 5: 257-bin x up-to-8000-frame utterances).
+
+The reference samples batches at random and zero-pads every batch to its longest member
+(speechless/corpus.py:224-226, speechless/net.py:578-587), so the padded frames are convolved like real ones; with
+lengths U{2000..8000} that wastes ~40 % of the FLOPs.  Length bucketing is a NEW host feature of this implementation
+("long-context"): utterances are sorted into buckets of similar length, batches are cut from one
+bucket at a time, and in data-parallel runs the batches of a step are balanced across ranks by total frame count.
+Semantics inside a batch are unchanged (still zero-padded to the batch maximum, exactly like the reference), so parity
+per batch is unaffected; only the composition of batches differs from the reference's random sampling.
+"""
+import random
+
+
+def bucket_batches(examples, batch_size, length_of=None, bucket_width=None, shuffle=True, seed=0, drop_last=False):
+    """Groups `examples` into batches of similar length.
+
+    length_of: example -> frame count (default: rows of example.z_normalized_transposed_spectrogram()).
+    bucket_width: frames per bucket (default: spread / 16).  Returns a list of lists (each <= batch_size long)."""
+    if length_of is None:
+        def length_of(e):
+            return e.z_normalized_transposed_spectrogram().shape[0]
+    items = [(length_of(e), i, e) for i, e in enumerate(examples)]
+    if not items:
+        return []
+    lo = min(n for n, _, _ in items)
+    hi = max(n for n, _, _ in items)
+    if bucket_width is None:
+        bucket_width = max(1, (hi - lo + 16) // 16)
+    rng = random.Random(seed)
+    buckets = {}
+    for n, i, e in items:
+        buckets.setdefault((n - lo) // bucket_width, []).append((n, i, e))
+    batches = []
+    leftovers = []
+    for key in sorted(buckets):
+        members = buckets[key]
+        if shuffle:
+            rng.shuffle(members)
+        while len(members) >= batch_size:
+            batches.append([e for _, _, e in members[:batch_size]])
+            members = members[batch_size:]
+        leftovers.extend(members)  # sorted by bucket: neighbours in length
+    while leftovers and not (drop_last and len(leftovers) < batch_size):
+        batches.append([e for _, _, e in leftovers[:batch_size]])
+        leftovers = leftovers[batch_size:]
+    if shuffle:
+        rng.shuffle(batches)
+    return batches
+
+
+def padding_waste(batches, length_of=None):
+    """Fraction of convolved frames that are padding (0 = none)."""
+    if length_of is None:
+        def length_of(e):
+            return e.z_normalized_transposed_spectrogram().shape[0]
+    real = padded = 0
+    for batch in batches:
+        lengths = [length_of(e) for e in batch]
+        real += sum(lengths)
+        padded += max(lengths) * len(lengths)
+    return 1.0 - real / padded if padded else 0.0
+
+
+def balance_across_ranks(batches, world_size, length_of=None):
+    """Assigns whole batches to ranks so that every rank sees about the same number of frames per step: batches are
+    sorted by cost and dealt out in groups of `world_size` (a step = one group; rank r takes the r-th batch of it)."""
+    if length_of is None:
+        def length_of(e):
+            return e.z_normalized_transposed_spectrogram().shape[0]
+
+    def cost(batch):
+        return max(length_of(e) for e in batch) * len(batch)
+    ordered = sorted(batches, key=cost)
+    steps = [ordered[i:i + world_size] for i in range(0, len(ordered) - world_size + 1, world_size)]
+    # serpentine dealing: the cheapest batch of a step goes to rank 0 on even steps and to the last rank on odd steps,
+    # so that the per-rank totals even out as well (within a step the costs are already neighbours in sorted order)
+    return [[step[r] if k % 2 == 0 else step[world_size - 1 - r] for k, step in enumerate(steps)]
+            for r in range(world_size)]

@@ -42,9 +42,10 @@ extern "C" int sl_conv1d_nt(const void* x, const void* w, const float* bias, con
     int rc = check_geom(geom, "sl_conv1d_nt", 64, 128);
     if (rc != SL_OK) return rc;
     SL_CHECK_ARG(x && w && y, "sl_conv1d_nt: null tensor pointer");
-    SL_CHECK_ARG(epilogue >= SL_EPI_NONE && epilogue <= SL_EPI_RELU_MASK, "sl_conv1d_nt: unknown epilogue %d", epilogue);
-    if (epilogue == SL_EPI_BIAS || epilogue == SL_EPI_BIAS_RELU) SL_CHECK_ARG(bias, "sl_conv1d_nt: bias is null");
-    if (epilogue == SL_EPI_RELU_MASK) SL_CHECK_ARG(mask, "sl_conv1d_nt: mask is null");
+    SL_CHECK_ARG(epilogue >= SL_EPI_NONE && epilogue <= SL_EPI_ELU_MASK, "sl_conv1d_nt: unknown epilogue %d", epilogue);
+    if (epilogue == SL_EPI_BIAS || epilogue == SL_EPI_BIAS_RELU || epilogue == SL_EPI_BIAS_ELU)
+        SL_CHECK_ARG(bias, "sl_conv1d_nt: bias is null");
+    if (epilogue == SL_EPI_RELU_MASK || epilogue == SL_EPI_ELU_MASK) SL_CHECK_ARG(mask, "sl_conv1d_nt: mask is null");
     if (dtype == SL_BF16)
         return conv_nt_bf16(x, w, bias, mask, y, geom, epilogue, out_f32, cfg, workspace, workspace_bytes,
                             (hipStream_t)stream);

@@ -75,17 +75,26 @@ __global__ __launch_bounds__(256) void conv_nt_f32_kernel(F32NtArgs a) {
 
     const int co = co0 + tx * 4;
     f32x4 bias_v = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == SL_EPI_BIAS || EPI == SL_EPI_BIAS_RELU) bias_v = *(const f32x4*)(a.bias + co);
+    if (EPI == SL_EPI_BIAS || EPI == SL_EPI_BIAS_RELU || EPI == SL_EPI_BIAS_ELU) bias_v = *(const f32x4*)(a.bias + co);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int t = t0 + ty * 4 + i;
         if (t >= a.t_out) continue;
         const long yidx = (long)b * a.y_bs + (long)(a.y_row0 + t) * a.y_rs + co;
         f32x4 v = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-        if (EPI == SL_EPI_BIAS || EPI == SL_EPI_BIAS_RELU) v += bias_v;
+        if (EPI == SL_EPI_BIAS || EPI == SL_EPI_BIAS_RELU || EPI == SL_EPI_BIAS_ELU) v += bias_v;
         if (EPI == SL_EPI_BIAS_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (EPI == SL_EPI_BIAS_ELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : expm1f(v[j]);
+        }
+        if (EPI == SL_EPI_ELU_MASK) {
+            const f32x4 mv = *(const f32x4*)(a.mask + yidx);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= mv[j] > 0.f ? 1.f : mv[j] + 1.f;
         }
         if (EPI == SL_EPI_RELU_MASK) {
             const f32x4 mv = *(const f32x4*)(a.mask + yidx);
@@ -198,6 +207,8 @@ int conv_nt_f32(const void* x, const void* w, const float* bias, const void* mas
         case SL_EPI_BIAS: return launch_nt<SL_EPI_BIAS>(a, s);
         case SL_EPI_BIAS_RELU: return launch_nt<SL_EPI_BIAS_RELU>(a, s);
         case SL_EPI_RELU_MASK: return launch_nt<SL_EPI_RELU_MASK>(a, s);
+        case SL_EPI_BIAS_ELU: return launch_nt<SL_EPI_BIAS_ELU>(a, s);
+        case SL_EPI_ELU_MASK: return launch_nt<SL_EPI_ELU_MASK>(a, s);
     }
     sl_set_error("sl_conv1d_nt: unknown epilogue %d", epilogue);
     return SL_ERR_INVALID_ARGUMENT;

@@ -63,18 +63,39 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-enum { MODE_PARTIAL = 4 };  // besides the SL_EPI_* values: raw fp32 accumulators to the split-K workspace
+enum { MODE_PARTIAL = 100 };  // besides the SL_EPI_* values: raw fp32 accumulators to the split-K workspace
+
+__device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_float(u & 0xFFFF0000u); }
+// ELU: y = z > 0 ? z : exp(z) - 1;   dy/dz expressed through the stored output: y > 0 ? 1 : y + 1
+__device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
+__device__ __forceinline__ float elu_grad_from_y(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
 // epilogue of one run of 16 consecutive output channels of one time row
 template <int MODE, bool OUT_F32>
 __device__ __forceinline__ void store_run16(const NtArgs& a, float (&v)[16], const float (&bias_v)[16], long yidx) {
-    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) {
+    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU || MODE == SL_EPI_BIAS_ELU) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] += bias_v[i];
     }
     if (MODE == SL_EPI_BIAS_RELU) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (MODE == SL_EPI_BIAS_ELU) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = elu_f(v[i]);
+    }
+    if (MODE == SL_EPI_ELU_MASK) {
+        const u32x4 m0 = *(const u32x4*)(a.mask + yidx);
+        const u32x4 m1 = *(const u32x4*)(a.mask + yidx + 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i * 2] *= elu_grad_from_y(bf16_lo(m0[i]));
+            v[i * 2 + 1] *= elu_grad_from_y(bf16_hi(m0[i]));
+            v[8 + i * 2] *= elu_grad_from_y(bf16_lo(m1[i]));
+            v[8 + i * 2 + 1] *= elu_grad_from_y(bf16_hi(m1[i]));
+        }
     }
     if (MODE == SL_EPI_RELU_MASK) {
         const u32x4 m0 = *(const u32x4*)(a.mask + yidx);
@@ -298,7 +319,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     for (int jc = 0; jc < NRUN_C; ++jc) {
         const int co_base = co0 + wn * 64 + jc * 32 + lane_c;
         float bias_v[16];
-        if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) load_bias16(a.bias, co_base, bias_v);
+        if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU || MODE == SL_EPI_BIAS_ELU)
+            load_bias16(a.bias, co_base, bias_v);
 #pragma unroll
         for (int it = 0; it < NRUN_T; ++it) {
             const int trow = wm * WROWS + it * (M32 ? 32 : 16) + lane_t;
@@ -358,13 +380,25 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
         }
     }
     const long yidx = (long)b * a.y_bs + (long)(a.y_row0 + t) * a.y_rs + co;
-    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU) {
+    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU || MODE == SL_EPI_BIAS_ELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += a.bias[co + j];
     }
     if (MODE == SL_EPI_BIAS_RELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    if (MODE == SL_EPI_BIAS_ELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = elu_f(v[j]);
+    }
+    if (MODE == SL_EPI_ELU_MASK) {
+        const u32x4 m = *(const u32x4*)(a.mask + yidx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] *= elu_grad_from_y(bf16_lo(m[j]));
+            v[2 * j + 1] *= elu_grad_from_y(bf16_hi(m[j]));
+        }
     }
     if (MODE == SL_EPI_RELU_MASK) {
         const u32x4 m = *(const u32x4*)(a.mask + yidx);
@@ -429,6 +463,8 @@ int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
                 case SL_EPI_BIAS: return launch_tail<SL_EPI_BIAS, false>(a, rows, s);
                 case SL_EPI_BIAS_RELU: return launch_tail<SL_EPI_BIAS_RELU, false>(a, rows, s);
                 case SL_EPI_RELU_MASK: return launch_tail<SL_EPI_RELU_MASK, false>(a, rows, s);
+                case SL_EPI_BIAS_ELU: return launch_tail<SL_EPI_BIAS_ELU, false>(a, rows, s);
+                case SL_EPI_ELU_MASK: return launch_tail<SL_EPI_ELU_MASK, false>(a, rows, s);
             }
         }
     } else if (out_f32) {
@@ -440,6 +476,8 @@ int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
             case SL_EPI_BIAS: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS, false>(a, s);
             case SL_EPI_BIAS_RELU: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS_RELU, false>(a, s);
             case SL_EPI_RELU_MASK: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_RELU_MASK, false>(a, s);
+            case SL_EPI_BIAS_ELU: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS_ELU, false>(a, s);
+            case SL_EPI_ELU_MASK: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_ELU_MASK, false>(a, s);
         }
     }
     sl_set_error("sl_conv1d_nt(bf16): unsupported epilogue %d with out_f32=%d", epilogue, out_f32);

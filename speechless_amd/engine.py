@@ -232,16 +232,17 @@ class Engine:
         for i, s in enumerate(specs):
             if s.stride not in (1, 2) or (s.stride == 2 and i != 0):
                 raise NotImplementedError("only the first layer may stride (spectrogram-input stack, net.py:317)")
-            hidden_ok = s.activation == "relu" if i < len(specs) - 1 else s.activation == "softmax"
+            hidden_ok = s.activation in ("relu", "elu") if i < len(specs) - 1 else s.activation == "softmax"
             if not hidden_ok:
                 raise NotImplementedError(
-                    "HIP path supports relu hidden layers and a softmax output layer (got {!r} on {})".format(
+                    "HIP path supports relu/elu hidden layers and a softmax output layer (got {!r} on {})".format(
                         s.activation, s.name))
         if specs[-1].cout != grapheme_set_size:
             raise ValueError("output layer width must equal the grapheme set size")
         self.plans = []
         off = 0
-        cin_pad = _round_up(specs[0].cin, 32)
+        # pair view of the striding layer = 2*cin_pad channels; the wgrad tile needs that to be a multiple of 128
+        cin_pad = _round_up(specs[0].cin, 64)
         for i, s in enumerate(specs):
             cout_pad = _round_up(s.cout, 128)
             w_off = off
@@ -383,7 +384,9 @@ class Engine:
             _, bias = self.layer_param_views(self.params, p)
             self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(), None,
                           y.data_ptr(), ctypes.byref(buf.fwd_geom[p.index]),
-                          _lib.EPI_BIAS if last else _lib.EPI_BIAS_RELU, self.dtype_code, 1 if last else 0,
+                          _lib.EPI_BIAS if last else
+                          (_lib.EPI_BIAS_ELU if p.spec.activation == "elu" else _lib.EPI_BIAS_RELU),
+                          self.dtype_code, 1 if last else 0,
                           self.nt_cfg.get(("fwd", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
             x = y
         self._launch("softmax", "sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
@@ -501,7 +504,8 @@ class Engine:
             if i > first:
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(),
                              None, buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
-                             _lib.EPI_RELU_MASK, self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
+                             _lib.EPI_ELU_MASK if self.specs[i - 1].activation == "elu" else _lib.EPI_RELU_MASK,
+                             self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
                              buf.nt_ws.data_ptr(), buf.nt_ws.numel(), main.cuda_stream)
         if self.overlap_wgrad:
             if on_bucket_ready is not None and split > first:
