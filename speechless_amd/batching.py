@@ -61,18 +61,18 @@ def padding_waste(batches, length_of=None):
     return 1.0 - real / padded if padded else 0.0
 
 
-def balance_across_ranks(batches, world_size, length_of=None):
-    """Assigns whole batches to ranks so that every rank sees about the same number of frames per step: batches are
-    sorted by cost and dealt out in groups of `world_size` (a step = one group; rank r takes the r-th batch of it)."""
+def steps_for_ranks(examples, batch_size, world_size, length_of=None, bucket_width=None, shuffle=True, seed=0):
+    """Data-parallel batch formation: a step is a GLOBAL batch of world_size*batch_size utterances cut from one length
+    bucket and dealt to the ranks round-robin in length order, so every rank of a step pads to (nearly) the same
+    length and does (nearly) the same work -- a synchronous step is as slow as its most expensive rank.
+    Returns a list of steps; each step is a list of world_size batches (rank r takes step[r])."""
     if length_of is None:
         def length_of(e):
             return e.z_normalized_transposed_spectrogram().shape[0]
-
-    def cost(batch):
-        return max(length_of(e) for e in batch) * len(batch)
-    ordered = sorted(batches, key=cost)
-    steps = [ordered[i:i + world_size] for i in range(0, len(ordered) - world_size + 1, world_size)]
-    # serpentine dealing: the cheapest batch of a step goes to rank 0 on even steps and to the last rank on odd steps,
-    # so that the per-rank totals even out as well (within a step the costs are already neighbours in sorted order)
-    return [[step[r] if k % 2 == 0 else step[world_size - 1 - r] for k, step in enumerate(steps)]
-            for r in range(world_size)]
+    global_batches = bucket_batches(examples, batch_size * world_size, length_of=length_of, bucket_width=bucket_width,
+                                    shuffle=shuffle, seed=seed, drop_last=True)
+    steps = []
+    for gb in global_batches:
+        ordered = sorted(gb, key=length_of)
+        steps.append([ordered[r::world_size] for r in range(world_size)])
+    return steps

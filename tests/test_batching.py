@@ -1,7 +1,7 @@
 """CPU tests of the host-side length bucketing (speechless_amd/batching.py; a new feature for BASELINE config 5)."""
 import numpy as np
 
-from speechless_amd.batching import balance_across_ranks, bucket_batches, padding_waste
+from speechless_amd.batching import bucket_batches, padding_waste, steps_for_ranks
 
 
 class Utt:
@@ -32,18 +32,16 @@ def test_drop_last_and_empty_input():
 
 def test_rank_balancing_is_even():
     rng = np.random.RandomState(4)
-    utts = [Utt(int(n)) for n in rng.randint(2000, 8001, size=512)]
-    batches = bucket_batches(utts, 8, seed=2)
-    per_rank = balance_across_ranks(batches, 8)
-    assert len(per_rank) == 8 and len({len(r) for r in per_rank}) == 1
+    utts = [Utt(int(n)) for n in rng.randint(2000, 8001, size=1024)]
+    steps = steps_for_ranks(utts, 8, 8, seed=2)
+    assert steps and all(len(step) == 8 and all(len(b) == 8 for b in step) for step in steps)
+    seen = [id(u) for step in steps for b in step for u in b]
+    assert len(seen) == len(set(seen))
+
     def cost(b):
         return max(u.n for u in b) * len(b)
-    frames = [sum(cost(b) for b in r) for r in per_rank]
-    assert max(frames) / min(frames) < 1.02
     # a data-parallel step is as slow as its most expensive rank: within every step the costs must be close
-    ratios = []
-    for step in range(len(per_rank[0])):
-        costs = [cost(per_rank[r][step]) for r in range(8)]
-        ratios.append(max(costs) / min(costs))
-    ratios.sort()
-    assert ratios[len(ratios) // 2] < 1.1 and ratios[-1] < 1.6  # only the step holding the partial batches is uneven
+    for step in steps:
+        costs = [cost(b) for b in step]
+        assert max(costs) / min(costs) < 1.03
+    assert padding_waste([b for step in steps for b in step]) < 0.08
