@@ -431,14 +431,17 @@ class Wav2Letter:
             for name, batches in grouped_labeled_spectrogram_batches.items()))
 
     # ------------------------------------------------------------------ training (net.py:541-576)
-    def train_on_batch(self, labeled_spectrogram_batch, reducer=None):
-        """One optimisation step; returns the mean CTC loss of the batch (what Keras' progress bar shows)."""
+    def train_on_batch(self, labeled_spectrogram_batch, reducer=None, lazy=False):
+        """One optimisation step; returns the mean CTC loss of the batch (what Keras' progress bar shows).
+        lazy=True returns it as a 0-d tensor still in flight on the GPU, so the host can pack the next batch
+        (net.py:578-607 is serial numpy work) while the step runs instead of blocking on `.item()`."""
         inputs = self._input_dictionary_for_loss_net(labeled_spectrogram_batch)
         names = Wav2Letter.InputNames
         losses = self.engine.train_step(inputs[names.input_batch], inputs[names.label_batch],
                                         inputs[names.label_lengths], inputs[names.prediction_lengths],
                                         reducer=reducer)
-        return float(losses.mean().item())
+        mean = losses.mean()  # new tensor: safe against the next step overwriting the loss buffer
+        return mean if lazy else float(mean.item())
 
     def train(self, labeled_spectrogram_batches, preview_labeled_spectrogram_batch, tensor_board_log_directory,
               net_directory, batches_per_epoch, max_epochs=100000000, reducer=None):
@@ -461,7 +464,8 @@ class Wav2Letter:
                 batch = next(batches, None)
                 if batch is None:
                     break
-                epoch_losses.append(self.train_on_batch(batch, reducer=reducer))
+                epoch_losses.append(self.train_on_batch(batch, reducer=reducer, lazy=True))
+            epoch_losses = [float(l.item()) for l in epoch_losses]  # one host<->device sync per epoch, not per step
             if len(epoch_losses) < batches_per_epoch:
                 break
             if log_path is not None:
