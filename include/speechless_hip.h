@@ -104,6 +104,15 @@ size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype, int 
 int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype, int cfg,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same weight gradient for `groups` layers of IDENTICAL geometry in one launch (bf16 only): layer q reads
+ * x + q*x_group_stride and g + q*g_group_stride (elements) and writes dw + q*dw_group_stride (floats).  The seven
+ * inner_conv_i (net.py:321-323) are such a group: one grid of 7 x 28 tiles needs 3 batch splits instead of 16 per
+ * layer, runs 80-step contractions instead of 16-step ones and one reduction instead of seven. */
+size_t sl_conv1d_wgrad_grouped_workspace_bytes(const sl_conv_geom* geom, int groups, int cfg);
+int sl_conv1d_wgrad_grouped(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int groups,
+                            int64_t x_group_stride, int64_t g_group_stride, int64_t dw_group_stride, int cfg,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* bias gradient db[co] = sum_{b,t} g[b][g_row0+t][co] (fp32 out, deterministic two-stage).  Same autodiff site. */
 size_t sl_bias_grad_workspace_bytes(const sl_conv_geom* geom);
 int sl_bias_grad(const void* g, float* db, const sl_conv_geom* geom, int dtype, void* workspace,

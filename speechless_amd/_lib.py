@@ -49,6 +49,9 @@ SIGNATURES = {
     "sl_conv1d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int]),
     "sl_conv1d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int, c_void_p, c_size_t,
                                 c_void_p]),
+    "sl_conv1d_wgrad_grouped_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int]),
+    "sl_conv1d_wgrad_grouped": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int64, c_int64,
+                                        c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "sl_bias_grad_workspace_bytes": (c_size_t, [POINTER(ConvGeom)]),
     "sl_bias_grad": (c_int, [c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_void_p, c_size_t, c_void_p]),
     "sl_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -58,7 +58,7 @@ extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int 
     if (!geom || geom->taps <= 0 || geom->cin <= 0 || geom->cout <= 0 || geom->batch <= 0) return 0;
     if (dtype == SL_BF16) {
         if (geom->cin % 128 || geom->cout % 128) return 0;
-        return wgrad_tn_bf16_workspace_bytes(geom, cfg);
+        return wgrad_tn_bf16_workspace_bytes(geom, cfg, 1);
     }
     if (geom->cin % 64 || geom->cout % 64) return 0;
     const int splits = wgrad_split_count(geom, 64);
@@ -74,7 +74,7 @@ extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl
     if (rc != SL_OK) return rc;
     SL_CHECK_ARG(x && g && dw, "sl_conv1d_wgrad: null tensor pointer");
     if (dtype == SL_BF16)
-        return wgrad_tn_bf16(x, g, dw, geom, cfg, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+        return wgrad_tn_bf16(x, g, dw, geom, cfg, 1, 0, 0, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
     const int splits = wgrad_split_count(geom, tile);
     const size_t need = sl_conv1d_wgrad_workspace_bytes(geom, dtype, 0);
     if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
@@ -82,4 +82,21 @@ extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl
         return SL_ERR_WORKSPACE_TOO_SMALL;
     }
     return wgrad_tn_f32(x, g, dw, geom, (float*)workspace, splits, (hipStream_t)stream);
+}
+
+extern "C" size_t sl_conv1d_wgrad_grouped_workspace_bytes(const sl_conv_geom* geom, int groups, int cfg) {
+    if (!geom || groups < 1 || geom->taps <= 0 || geom->cin <= 0 || geom->cout <= 0 || geom->batch <= 0) return 0;
+    if (geom->cin % 128 || geom->cout % 128) return 0;
+    return wgrad_tn_bf16_workspace_bytes(geom, cfg, groups);
+}
+
+extern "C" int sl_conv1d_wgrad_grouped(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int groups,
+                                       int64_t x_group_stride, int64_t g_group_stride, int64_t dw_group_stride, int cfg,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_geom(geom, "sl_conv1d_wgrad_grouped", 128, 128);
+    if (rc != SL_OK) return rc;
+    SL_CHECK_ARG(x && g && dw && groups >= 1, "sl_conv1d_wgrad_grouped: null tensor pointer or groups < 1");
+    SL_CHECK_ARG(dw_group_stride % 4 == 0, "sl_conv1d_wgrad_grouped: dw_group_stride must be a multiple of 4 floats");
+    return wgrad_tn_bf16(x, g, dw, geom, cfg, groups, (long)x_group_stride, (long)g_group_stride,
+                         (long)dw_group_stride, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }

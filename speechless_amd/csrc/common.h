@@ -62,7 +62,7 @@ size_t conv_nt_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
 int conv_nt_f32(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
                 int epilogue, hipStream_t s);
 int wgrad_split_count(const sl_conv_geom* g, int tile);
-int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, float* ws, size_t ws_bytes,
-                  hipStream_t s);
-size_t wgrad_tn_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
+int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, int groups, long x_gs,
+                  long g_gs, long dw_gs, float* ws, size_t ws_bytes, hipStream_t s);
+size_t wgrad_tn_bf16_workspace_bytes(const sl_conv_geom* g, int cfg, int groups);
 int wgrad_tn_f32(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits, hipStream_t s);

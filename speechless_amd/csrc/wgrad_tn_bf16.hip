@@ -33,6 +33,10 @@ struct TnArgs {
     int ci_tiles, co_tiles, tiles;
     int splits, b_per_split;
     long split_stride;
+    // grouped launch: `groups` independent layers of identical geometry (the seven inner_conv_i) in one grid;
+    // layer q uses x + q*x_gs, g + q*g_gs and writes dw + q*dw_gs (or workspace slice q*splits + split)
+    int groups;
+    long x_gs, g_gs, dw_gs;
 };
 
 __device__ __forceinline__ void glds16(const __bf16* gsrc, char* lds_wave_base) {
@@ -91,7 +95,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
     const int g = lane >> 4;
 
     // logical id = ((split * co_tiles + co_tile) * ci_tiles + ci_tile) * taps + tap
-    int wg = xcd_remap(blockIdx.x, a.tiles * a.splits);
+    int wg = xcd_remap(blockIdx.x, a.tiles * a.splits * a.groups);
+    const int group = wg / (a.tiles * a.splits);
+    wg -= group * (a.tiles * a.splits);
     const int tap = wg % a.taps;
     wg /= a.taps;
     const int ci_tile = wg % a.ci_tiles;
@@ -108,8 +114,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
     for (int q = 0; q < XPW; ++q) xoff[q] = dma_src_offset<WM>(wave * XPW + q, lane, a.x_rs);
 #pragma unroll
     for (int q = 0; q < GPW; ++q) goff_src[q] = dma_src_offset<WN>(wave * GPW + q, lane, a.g_rs);
-    const __bf16* xbase = a.x + (long)(a.x_row0 + tap) * a.x_rs + ci_tile * TCI;
-    const __bf16* gbase = a.g + (long)a.g_row0 * a.g_rs + co_tile * TCO;
+    const __bf16* xbase = a.x + group * a.x_gs + (long)(a.x_row0 + tap) * a.x_rs + ci_tile * TCI;
+    const __bf16* gbase = a.g + group * a.g_gs + (long)a.g_row0 * a.g_rs + co_tile * TCO;
 
     auto stage = [&](int step, int buf) {
         const int bb = step / a.t_chunks;
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
     }
 
     // ---- store: lane holds co = co_base + jn*16 + g*4 + {0..3} for ci = ci_base + it*16 + (lane & 15)
-    float* out = a.out + (long)split * a.split_stride;
+    float* out = a.splits > 1 ? a.out + ((long)group * a.splits + split) * a.split_stride : a.out + group * a.dw_gs;
     const int ci_base = ci_tile * TCI + wm * 64 + (lane & 15);
     const int co_base = co_tile * TCO + wn * 64 + g * 4;
 #pragma unroll
@@ -194,8 +200,8 @@ int launch(const TnArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<WM, WN, STAGES>), dim3(a.tiles * a.splits), dim3(64 * WM * WN), LDS_BYTES, s,
-                       a);
+    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<WM, WN, STAGES>), dim3(a.tiles * a.splits * a.groups), dim3(64 * WM * WN),
+                       LDS_BYTES, s, a);
     return sl_check_launch("sl_conv1d_wgrad(bf16)");
 }
 
@@ -205,24 +211,30 @@ struct WCfg {
 
 WCfg decode_wcfg(int cfg) { return WCfg{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 15, (cfg >> 12) & 255}; }
 
-int choose_splits(const sl_conv_geom* g, int tci, int tco, int target_wgs) {
-    const long tiles = (long)g->taps * (g->cin / tci) * (g->cout / tco);
+int choose_splits(const sl_conv_geom* g, int tci, int tco, int target_wgs, int groups = 1) {
+    const long tiles = (long)g->taps * (g->cin / tci) * (g->cout / tco) * groups;
     long want = (target_wgs + tiles - 1) / tiles;
     if (want < 1) want = 1;
     if (want > g->batch) want = g->batch;
+    // prefer a split count that divides the batch (equal work per work-group; measured: 4 x 8 utterances 0.144 ms vs
+    // 6 uneven splits 0.179 ms on the grouped inner-layer launch): the divisor closest to `want`, smaller one on ties
+    int best = 1;
+    for (int d = 1; d <= g->batch; ++d)
+        if (g->batch % d == 0 && labs(d - want) < labs(best - want)) best = d;
+    if (best * 2 >= want) return best;
     const int bps = (int)((g->batch + want - 1) / want);
     return (g->batch + bps - 1) / bps;
 }
 
-WCfg auto_wcfg(const sl_conv_geom* g) {
-    // measured on MI355X with tools/tune_kernels.py (profiles/r01_tune.json), see DESIGN.md "kernel tuning"
+WCfg auto_wcfg(const sl_conv_geom* g, int groups) {
+    // measured on MI355X with tools/tune_kernels.py (profiles/r01_tune_kernels.json), see DESIGN.md section 3
     if (g->cin % 256 == 0 && g->cout % 256 == 0) {
-        const long tiles256 = (long)g->taps * (g->cin / 256) * (g->cout / 256);
+        const long tiles256 = (long)g->taps * (g->cin / 256) * (g->cout / 256) * groups;
         // 256x256 tile, 16 waves: big_conv_1 1085 TFLOP/s (128x128: 890), big_conv_2 918, striding_conv 643
-        if (tiles256 >= 24) return WCfg{4, 4, 2, choose_splits(g, 256, 256, 256)};
+        if (tiles256 >= 24) return WCfg{4, 4, 2, choose_splits(g, 256, 256, 256, groups)};
     }
     // short layers: 128x128 tiles, batch split so that ~2 work-groups land on every CU (deeper rings measured no gain)
-    return WCfg{2, 2, 2, choose_splits(g, 128, 128, 512)};
+    return WCfg{2, 2, 2, choose_splits(g, 128, 128, 512, groups)};
 }
 
 bool valid_wcfg(const WCfg& c, const sl_conv_geom* g) {
@@ -233,11 +245,11 @@ bool valid_wcfg(const WCfg& c, const sl_conv_geom* g) {
     return shape && g->cin % (64 * c.wm) == 0 && g->cout % (64 * c.wn) == 0 && c.splits >= 1 && c.splits <= g->batch;
 }
 
-WCfg resolve_wcfg(const sl_conv_geom* g, int cfg) {
-    if (cfg == 0) return auto_wcfg(g);
+WCfg resolve_wcfg(const sl_conv_geom* g, int cfg, int groups) {
+    if (cfg == 0) return auto_wcfg(g, groups);
     WCfg c = decode_wcfg(cfg);
     if (c.splits == 0 && c.wm > 0 && c.wn > 0 && g->cin % (64 * c.wm) == 0 && g->cout % (64 * c.wn) == 0)
-        c.splits = choose_splits(g, 64 * c.wm, 64 * c.wn, c.wm * c.wn >= 16 ? 256 : 512);
+        c.splits = choose_splits(g, 64 * c.wm, 64 * c.wn, c.wm * c.wn >= 16 ? 256 : 512, groups);
     return c;
 }
 
@@ -265,18 +277,29 @@ int wgrad_reduce(const float* ws, float* dw, long n, int splits, hipStream_t s) 
     return sl_check_launch("wgrad_reduce");
 }
 
-size_t wgrad_tn_bf16_workspace_bytes(const sl_conv_geom* g, int cfg) {
-    const WCfg c = resolve_wcfg(g, cfg);
+// grouped tail: grid.y = group; sums that group's split partials in a fixed order into dw + group*dw_gs
+__global__ void wgrad_reduce_grouped_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits,
+                                            long dw_gs) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* p = (const f32x4*)ws + (long)blockIdx.y * splits * n4 + i;
+    f32x4 s = p[0];
+    for (int k = 1; k < splits; ++k) s += p[k * n4];
+    ((f32x4*)(dw + blockIdx.y * dw_gs))[i] = s;
+}
+
+size_t wgrad_tn_bf16_workspace_bytes(const sl_conv_geom* g, int cfg, int groups) {
+    const WCfg c = resolve_wcfg(g, cfg, groups);
     if (!valid_wcfg(c, g)) return 0;
     const int bps = (g->batch + c.splits - 1) / c.splits;
     const int splits = (g->batch + bps - 1) / bps;
-    return splits > 1 ? (size_t)splits * g->taps * g->cin * g->cout * sizeof(float) : 0;
+    return splits > 1 ? (size_t)groups * splits * g->taps * g->cin * g->cout * sizeof(float) : 0;
 }
 
-int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, float* ws, size_t ws_bytes,
-                  hipStream_t s) {
-    const WCfg c = resolve_wcfg(g, cfg);
-    if (!valid_wcfg(c, g)) {
+int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, int groups, long x_gs,
+                  long g_gs, long dw_gs, float* ws, size_t ws_bytes, hipStream_t s) {
+    const WCfg c = resolve_wcfg(g, cfg, groups);
+    if (!valid_wcfg(c, g) || groups < 1) {
         sl_set_error("sl_conv1d_wgrad(bf16): invalid tile configuration wm=%d wn=%d stages=%d splits=%d for cin=%d cout=%d",
                      c.wm, c.wn, c.stages, c.splits, g->cin, g->cout);
         return SL_ERR_INVALID_ARGUMENT;
@@ -301,7 +324,11 @@ int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* 
     a.b_per_split = (g->batch + c.splits - 1) / c.splits;
     a.splits = (g->batch + a.b_per_split - 1) / a.b_per_split;
     a.split_stride = (long)g->taps * g->cin * g->cout;
-    if (a.splits > 1 && (ws == nullptr || ws_bytes < (size_t)a.splits * a.split_stride * sizeof(float))) {
+    a.groups = groups;
+    a.x_gs = x_gs;
+    a.g_gs = g_gs;
+    a.dw_gs = dw_gs;
+    if (a.splits > 1 && (ws == nullptr || ws_bytes < (size_t)groups * a.splits * a.split_stride * sizeof(float))) {
         sl_set_error("sl_conv1d_wgrad(bf16): workspace too small");
         return SL_ERR_WORKSPACE_TOO_SMALL;
     }
@@ -319,6 +346,11 @@ int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* 
     SL_TN_CASE(4, 4, 2)
 #undef SL_TN_CASE
     if (rc != SL_OK) return rc;
-    if (a.splits > 1) return wgrad_reduce(ws, dw, a.split_stride, a.splits, s);
+    if (a.splits > 1) {
+        const long n4 = a.split_stride / 4;
+        hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)((n4 + 255) / 256), groups), dim3(256), 0, s, ws,
+                           dw, n4, a.splits, dw_gs);
+        return sl_check_launch("wgrad_reduce");
+    }
     return SL_OK;
 }

@@ -100,7 +100,16 @@ class _Buffers:
         self.rows0 = 2 * (self.tt_pad + p0.taps_view)
         self.x0 = torch.zeros((batch, self.rows0, p0.cin_pad), dtype=dt, device=dev)
         n = len(eng.plans)
-        self.y = [torch.zeros((batch, self.rows, p.cout_pad), dtype=dt, device=dev) for p in eng.plans[:-1]]
+        self.y = [None] * (n - 1)
+        # a run of identical layers (the seven inner_conv_i) keeps its inputs y[s-1..e-1] in ONE allocation so that
+        # the grouped weight-gradient launch can address layer q as base + q*stride
+        for (s0, e0) in eng.runs:
+            block = torch.zeros((e0 - s0 + 1, batch, self.rows, eng.plans[s0].cin_pad), dtype=dt, device=dev)
+            for q in range(e0 - s0 + 1):
+                self.y[s0 - 1 + q] = block[q]
+        for p in eng.plans[:-1]:
+            if self.y[p.index] is None:
+                self.y[p.index] = torch.zeros((batch, self.rows, p.cout_pad), dtype=dt, device=dev)
         self.logits = torch.zeros((batch, self.tt_pad, eng.plans[-1].cout_pad), dtype=torch.float32, device=dev)
         k = eng.grapheme_set_size
         self.probs = torch.zeros((batch, self.t_out, k), dtype=torch.float32, device=dev)
@@ -160,8 +169,15 @@ class _Buffers:
         self.dgrad_geom = [None] * n
         ws_bytes = 0
         bias_ws = 0
+        for (s0, e0) in eng.runs:  # gradients g[s..e] of a run of identical layers: one allocation (grouped wgrad)
+            lo = max(s0, first)
+            if e0 >= lo:
+                block = torch.zeros((e0 - lo + 1, self.batch, self.rows, eng.plans[lo].cout_pad), dtype=dt, device=dev)
+                for q in range(e0 - lo + 1):
+                    self.g[lo + q] = block[q]
         for p in eng.plans[first:]:
-            self.g[p.index] = torch.zeros((self.batch, self.rows, p.cout_pad), dtype=dt, device=dev)
+            if self.g[p.index] is None:
+                self.g[p.index] = torch.zeros((self.batch, self.rows, p.cout_pad), dtype=dt, device=dev)
             wg = ConvGeom()
             f = self.fwd_geom[p.index]
             for name, _ in ConvGeom._fields_:
@@ -188,6 +204,12 @@ class _Buffers:
                 dg.y_batch_stride = self.rows * p.cin_pad
                 self.dgrad_geom[p.index] = dg
         self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
+        if eng.dtype == "bf16":
+            for (s0, e0) in eng.runs:
+                lo = max(s0, first)
+                if e0 > lo:
+                    ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_grouped_workspace_bytes")(
+                        ctypes.byref(self.wgrad_geom[lo]), e0 - lo + 1, 0))
         self.wgrad_ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
         self.bias_ws = torch.empty((max(bias_ws, 16),), dtype=torch.uint8, device=dev)
         self.ctc_ws = None
@@ -252,6 +274,19 @@ class Engine:
             self.plans.append(LayerPlan(i, s, cin_pad, cout_pad, w_off, b_off))
             cin_pad = cout_pad
         self.param_numel = off
+        # runs of >= 2 consecutive stride-1 layers with identical padded geometry (net.py:321-323: inner_conv_1..7)
+        self.runs = []
+        i = 1
+        while i < len(self.plans):
+            j = i
+            key = lambda q: (q.spec.kernel_size, q.spec.stride, q.cin_pad, q.cout_pad)  # noqa: E731
+            while j + 1 < len(self.plans) and key(self.plans[j + 1]) == key(self.plans[i]) and \
+                    self.plans[i].cin_pad == self.plans[i].cout_pad:
+                j += 1
+            if j > i:
+                self.runs.append((i, j))
+            i = j + 1
+        self.group_wgrad = True
         dev = self.device
         self.params = torch.zeros((off,), dtype=torch.float32, device=dev)
         self.grads = torch.zeros((off,), dtype=torch.float32, device=dev)
@@ -468,6 +503,13 @@ class Engine:
         side = self._side_stream
         first = self.frozen_layer_count
         _, split = self.bucket_ranges()
+        grouped = {}  # layer index -> (lo, hi) of the run whose weight gradients are computed in one grouped launch
+        if self.group_wgrad and self.dtype == "bf16" and not self.overlap_wgrad:
+            for (s0, e0) in self.runs:
+                lo = max(s0, first)
+                if e0 > lo and not (lo <= split <= e0):  # keep the bucket boundary simple
+                    for q in range(lo, e0 + 1):
+                        grouped[q] = (lo, e0)
 
         def join_side():
             done = torch.cuda.Event()
@@ -493,7 +535,18 @@ class Engine:
                              buf.bias_ws.numel(), side.cuda_stream)
                 if self.overlap_wgrad and on_bucket_ready is not None and i == split:
                     on_bucket_ready(0)
-            if not self.overlap_wgrad:
+            if i in grouped:
+                lo, hi = grouped[i]
+                if i == lo:  # every g[lo..hi] is complete now: one launch for the whole run
+                    plo = self.plans[lo]
+                    dw_lo, _ = self.layer_param_views(self.grads, plo)
+                    stride_elems = buf.batch * buf.rows * plo.cin_pad
+                    self._launch("wgrad:{}..{}".format(plo.spec.name, self.plans[hi].spec.name),
+                                 "sl_conv1d_wgrad_grouped", buf.y[lo - 1].data_ptr(), buf.g[lo].data_ptr(),
+                                 dw_lo.data_ptr(), ctypes.byref(buf.wgrad_geom[lo]), hi - lo + 1, stride_elems,
+                                 stride_elems, plo.w_numel + plo.cout_pad, 0, buf.wgrad_ws.data_ptr(),
+                                 buf.wgrad_ws.numel(), main.cuda_stream)
+            elif not self.overlap_wgrad:
                 self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
                              dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
                              self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
