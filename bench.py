@@ -131,12 +131,13 @@ def main():
     eng.timeline = None
     avg_ms = {tag: float(np.mean(v)) for tag, v in per_tag.items()}
     names = [s.name for s in specs]
-    # Dominant kernel (largest share of GPU time in profiles/r01b_kernel_stats.csv, 22 %): wgrad_tn_bf16_kernel<4,4,2>,
-    # the 256x256-tile weight-gradient kernel.  Three launches per step use this instantiation (the library's measured
-    # table picks it for striding_conv, big_conv_1, big_conv_2); algorithmic FLOPs per launch = their average.
-    dom_layers = ["striding_conv", "big_conv_1", "big_conv_2"]
-    dom_tags = ["wgrad:" + n for n in dom_layers]
-    dom_flops = sum(fl[names.index(n)] for n in dom_layers) * BATCH_PER_GPU / len(dom_tags)
+    # Dominant kernel (largest share of GPU time in profiles/r01e_kernel_stats.csv, 26 %): wgrad_tn_bf16_kernel<4,4,2>,
+    # the 256x256-tile weight-gradient kernel.  FOUR launches per step use this instantiation (the library's measured
+    # table picks it for striding_conv, big_conv_1, big_conv_2 and for the grouped launch that covers the seven
+    # inner_conv_i); algorithmic FLOPs per launch = (sum of those ten layers' wgrad FLOPs) / 4.
+    dom_tags = [t for t in avg_ms if t.startswith("wgrad:") and t != "wgrad:output_conv"]
+    dom_layer_flops = sum(fl[i] for i, n in enumerate(names) if n != "output_conv")
+    dom_flops = dom_layer_flops * BATCH_PER_GPU / len(dom_tags)
     dom_ms = sum(avg_ms[t] for t in dom_tags) / len(dom_tags)
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12
     traffic = None
@@ -186,11 +187,13 @@ def main():
         "final_mean_loss": final_loss,
         "step_mfma_frac": utt_per_s * fwdbwd_flops_per_utt / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world),
         "roofline": {"bound": "mfma", "kernel": "wgrad_tn_bf16_kernel<4,4,2> (weight gradient of striding_conv, "
-                                                "big_conv_1, big_conv_2; average over its 3 launches per step)",
+                                                "big_conv_1, big_conv_2 and the grouped inner_conv_1..7 launch; "
+                                                "average over its {} launches per step)".format(len(dom_tags)),
                      "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits "
-                                     "included), from profiles/r01c_pmc_traffic_wgrad442.json",
+                                     "included), average of the three single-layer launches measured in "
+                                     "profiles/r01c_pmc_traffic_wgrad442.json",
                      "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms},
         "roofline_nt_256x256": {"bound": "mfma", "kernel": "conv_nt_bf16_kernel<M32=0,IT=4,WM=4,WN=4,STAGES=2,"
                                                            "BIAS_RELU,bf16> (forward of big_conv_1, big_conv_2)",

@@ -203,22 +203,33 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     const int32_t* lab = labels + (long)b * l_max;
     for (int i = tid; i < L; i += 256) s_lab[i] = lab[i];
     __syncthreads();
-    // per-class position lists in label order (counting sort, fixed order -> deterministic sums)
-    if (tid < k) {
-        int c = 0;
-        for (int i = 0; i < L; ++i) c += (s_lab[i] == tid);
-        s_start[tid + 1] = c;
+    // per-class position lists in label order (counting sort; the order inside a class is the label order, so the
+    // per-class sums below are deterministic).  One thread per label position: its rank inside its class is the number
+    // of earlier positions with the same grapheme (every lane reads the same LDS word per iteration -> broadcast),
+    // instead of 29 threads scanning the label twice.
+    if (tid <= k) s_start[tid] = 0;
+    __syncthreads();
+    int my_rank[2] = {0, 0};  // positions tid and tid + 256 (l_max <= 511)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = tid + h * 256;
+        if (i < L) {
+            const int c = s_lab[i];
+            int r = 0;
+            for (int j = 0; j < i; ++j) r += (s_lab[j] == c);
+            my_rank[h] = r;
+            atomicAdd(&s_start[c + 1], 1);  // integer count: order-independent
+        }
     }
-    if (tid == 0) s_start[0] = 0;
     __syncthreads();
     if (tid == 0) {
         for (int c = 0; c < k; ++c) s_start[c + 1] += s_start[c];
     }
     __syncthreads();
-    if (tid < k) {
-        int w = s_start[tid];
-        for (int i = 0; i < L; ++i)
-            if (s_lab[i] == tid) s_pos[w++] = i;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = tid + h * 256;
+        if (i < L) s_pos[s_start[s_lab[i]] + my_rank[h]] = i;
     }
     __syncthreads();
 
