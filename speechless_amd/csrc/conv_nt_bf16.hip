@@ -52,6 +52,7 @@ struct NtArgs {
     int taps, cin;
     int nsteps;  // taps * cin / 64
     int ksplit, steps_per_split;
+    int gm;  // tile raster: blocks of (all n_tiles) x gm m-tiles are numbered consecutively
 };
 
 __device__ __forceinline__ void glds16(const __bf16* gsrc, char* lds_wave_base) {
@@ -61,6 +62,44 @@ __device__ __forceinline__ void glds16(const __bf16* gsrc, char* lds_wave_base) 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS fragment reads the compiler does not track (it answers every LDS dependency in these kernels with lgkmcnt(0),
+// because the LDS-DMA loads leave a "flat access pending" mark): the hand-counted wait below releases the registers.
+template <int OFF>
+__device__ __forceinline__ void ds_read128(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int I, int N, int STRIDE>
+struct DsReadRun {
+    static __device__ __forceinline__ void go(bf16x8 (&f)[N], unsigned addr) {
+        ds_read128<I * STRIDE>(f[I], addr);
+        DsReadRun<I + 1, N, STRIDE>::go(f, addr);
+    }
+};
+template <int N, int STRIDE>
+struct DsReadRun<N, N, STRIDE> {
+    static __device__ __forceinline__ void go(bf16x8 (&)[N], unsigned) {}
+};
+// s_waitcnt lgkmcnt(CNT) that the MFMAs consuming these fragments cannot be hoisted above
+template <int CNT>
+__device__ __forceinline__ void wait_frags(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void wait_frags(bf16x8 (&a)[4], bf16x8 (&b)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                   "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+                 : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void wait_frags(bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])
+                 : "n"(CNT));
 }
 
 enum { MODE_PARTIAL = 100 };  // besides the SL_EPI_* values: raw fp32 accumulators to the split-K workspace
@@ -139,8 +178,13 @@ __device__ __forceinline__ void load_bias16(const float* bias, int co, float (&b
     }
 }
 
-template <bool M32, int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
+// STAGES_P: low 3 bits = ring slots, bit 3 = register-pipelined main loop (fragments of the next tile's first half are
+// read from LDS while the MFMAs of the current tile's second half run, see the loop)
+template <bool M32, int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_bf16_kernel(NtArgs a) {
+    constexpr int STAGES = STAGES_P & 7;
+    constexpr bool PIPE = (STAGES_P & 8) != 0;
+    static_assert(STAGES >= 2, "ring too shallow");
     constexpr int NW = WM * WN;
     constexpr int WROWS = M32 ? 64 : 16 * IT;  // time rows per wave
     constexpr int BM = WROWS * WM;
@@ -164,8 +208,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     const int id = xcd_remap(blockIdx.x, tiles * a.ksplit);
     const int split = id / tiles;
     const int tile = id - split * tiles;
-    const int n_tile = tile / m_tiles;
-    const int m_tile = tile - n_tile * m_tiles;
+    // raster: consecutive ids (= one XCD's concurrently resident work-groups, see xcd_remap) cover a 2-D block of
+    // n_tiles x gm tiles, so that the activation rows AND the weight panels an XCD streams both stay within its 4 MiB
+    // L2.  With gm = m_tiles (1-D, weight-panel-major) big_conv_1's 32 resident activation tiles per XCD (4.7 MB) are
+    // evicted between taps: 1.25 GB per launch re-fetched from the Infinity Cache (profiles/r01c_pmc_*.json).
+    const int span = a.n_tiles * a.gm;
+    const int blk = tile / span;
+    const int rem = tile - blk * span;
+    int cnt = m_tiles - blk * a.gm;
+    if (cnt > a.gm) cnt = a.gm;
+    const int n_tile = rem / cnt;
+    const int m_tile = blk * a.gm + (rem - n_tile * cnt);
     const int b = m_tile / a.t_tiles;
     const int t0 = (m_tile - b * a.t_tiles) * BM;
     const int co0 = n_tile * BN;
@@ -248,64 +301,131 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc32[i][r] = 0.f;
 
-#pragma unroll
-    for (int i = 0; i < STAGES - 1; ++i)
-        if (i < n) stage(s_begin + i, i);
-    int cur = 0;            // ring slot of tile i
-    int nxt = STAGES - 1;   // ring slot tile i+STAGES-1 goes to
-    for (int i = 0; i < n; ++i) {
-        if (i + STAGES - 1 <= n)
-            wait_vmcnt<NI*(STAGES - 2)>();  // tile i has landed; the STAGES-2 younger tiles stay in flight
-        else
-            wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();       // everyone's share of tile i landed; everyone finished reading slot nxt
-        asm volatile("" ::: "memory");
-#ifndef SL_NT_LATE_DMA
-        if (i + STAGES - 1 < n) stage(s_begin + i + STAGES - 1, nxt);
-#endif
-        const char* sl = smem + cur * STAGE_BYTES;
+    // one 64-channel step = two halves of 32 channels; a half's fragments: NA weight vectors + NB activation vectors
+    constexpr int NA = M32 ? 4 : 4;
+    constexpr int NB = M32 ? 4 : IT;
+    auto load_half = [&](int slot, int h, bf16x8 (&af)[NA], bf16x8 (&bfr)[NB]) {
+        const char* sl = smem + slot * STAGE_BYTES;
         if (M32) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 af[2], bfr[2];
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int ks = h * 2 + k2;
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) af[jn] = *(const bf16x8*)(sl + ((aoff + jn * 4096) ^ (ks << 5)));
+                for (int jn = 0; jn < 2; ++jn) af[k2 * 2 + jn] = *(const bf16x8*)(sl + ((aoff + jn * 4096) ^ (ks << 5)));
 #pragma unroll
-                for (int it = 0; it < 2; ++it) bfr[it] = *(const bf16x8*)(sl + ((boff + it * 4096) ^ (ks << 5)));
+                for (int it = 0; it < 2; ++it) bfr[k2 * 2 + it] = *(const bf16x8*)(sl + ((boff + it * 4096) ^ (ks << 5)));
+            }
+        } else {
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) af[jn] = *(const bf16x8*)(sl + ((aoff + jn * 512) ^ (h << 6)));
+#pragma unroll
+            for (int it = 0; it < IT; ++it) bfr[it] = *(const bf16x8*)(sl + ((boff + it * 2048) ^ (h << 6)));
+        }
+    };
+    auto mma_half = [&](const bf16x8 (&af)[NA], const bf16x8 (&bfr)[NB]) {
+        if (M32) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
-                        acc32[jn * 2 + it] =
-                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[jn], bfr[it], acc32[jn * 2 + it], 0, 0, 0);
-            }
+                        acc32[jn * 2 + it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2 * 2 + jn], bfr[k2 * 2 + it],
+                                                                                     acc32[jn * 2 + it], 0, 0, 0);
         } else {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[4], bfr[IT];
+            for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-                for (int jn = 0; jn < 4; ++jn) af[jn] = *(const bf16x8*)(sl + ((aoff + jn * 512) ^ (kk << 6)));
-#pragma unroll
-                for (int it = 0; it < IT; ++it) bfr[it] = *(const bf16x8*)(sl + ((boff + it * 2048) ^ (kk << 6)));
-#ifdef SL_NT_LATE_DMA
-                if (kk == 0 && i + STAGES - 1 < n) stage(s_begin + i + STAGES - 1, nxt);
-#endif
-#ifdef SL_NT_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-                    for (int it = 0; it < IT; ++it)
-                        acc[jn * IT + it] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn * IT + it], 0, 0, 0);
-#ifdef SL_NT_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
+                for (int it = 0; it < IT; ++it)
+                    acc[jn * IT + it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn * IT + it], 0, 0, 0);
         }
-        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
-        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+    };
+
+    // Everything the epilogue needs from the kernel arguments is pulled into SGPRs HERE.  Left alone, the compiler parks
+    // those scalar loads in the loop pre-header without waiting for them, and a scalar load pending at the loop head
+    // forces it to emit lgkmcnt(0) instead of counted waits in front of every MFMA group inside the loop (LDS and
+    // scalar loads share the counter and return out of order with respect to each other).
+    NtArgs e = a;
+    asm volatile("" : "+s"(e.y), "+s"(e.mask), "+s"(e.bias), "+s"(e.partial), "+s"(e.y_bs));
+    asm volatile("" : "+s"(e.y_row0), "+s"(e.y_rs), "+s"(e.t_out), "+s"(e.cout), "+s"(e.batch), "+s"(e.t_tiles));
+
+    if constexpr (PIPE && !M32) {
+        // Register-pipelined ring.  All STAGES slots are filled up front; tile i's slot is refilled with tile
+        // i+STAGES at the barrier in the MIDDLE of iteration i, by which time every wave has its whole tile i in
+        // registers.  That same barrier publishes tile i+1, whose first-half fragments are then read from LDS while
+        // the MFMAs of tile i's second half run; the second-half reads overlap the first-half MFMAs.  The LDS read
+        // latency, which the plain loop exposes after every barrier (all waves read, then all waves multiply), is
+        // hidden behind MFMA work: measured step time on the 250-channel layers 0.61 us -> see DESIGN.md section 3.1.
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i)
+            if (i < n) stage(s_begin + i, i);
+        if (n >= STAGES)
+            wait_vmcnt<NI*(STAGES - 1)>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 a0[NA], b0[NB], a1[NA], b1[NB];
+        constexpr int NF = NA + NB;  // LDS reads per half
+        // per-half read addresses (the 64-B half flips bit 6 of the swizzled slot); + slot * STAGE_BYTES per tile
+        const unsigned a_addr0 = (unsigned)(size_t)smem + aoff, a_addr1 = a_addr0 ^ 64u;
+        const unsigned b_addr0 = (unsigned)(size_t)smem + boff, b_addr1 = b_addr0 ^ 64u;
+        auto read_half = [&](int slot, int h, bf16x8 (&af)[NA], bf16x8 (&bfr)[NB]) {
+            const unsigned so = slot * STAGE_BYTES;
+            DsReadRun<0, NA, 512>::go(af, (h ? a_addr1 : a_addr0) + so);
+            DsReadRun<0, NB, 2048>::go(bfr, (h ? b_addr1 : b_addr0) + so);
+        };
+        read_half(0, 0, a0, b0);
+        int cur = 0;
+        // the last tile is peeled off so that the loop body is branch-free around the LDS reads
+        for (int i = 0; i + 1 < n; ++i) {
+            const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
+            read_half(cur, 1, a1, b1);
+            wait_frags<NF>(a0, b0);  // first half in registers, second half in flight
+            mma_half(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_frags<0>(a1, b1);  // my reads of slot cur are complete
+            if (i + STAGES <= n)
+                wait_vmcnt<NI*(STAGES - 2)>();  // tile i+1 has landed; the younger ones stay in flight
+            else
+                wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (i + STAGES < n) stage(s_begin + i + STAGES, cur);
+            read_half(nxt, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);  // all reads are issued before the MFMAs they hide behind
+            mma_half(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        read_half(cur, 1, a1, b1);
+        wait_frags<NF>(a0, b0);
+        mma_half(a0, b0);
+        wait_frags<0>(a1, b1);
+        mma_half(a1, b1);
+    } else {
+        // plain ring: wait for tile i, barrier, refill the slot consumed one iteration earlier, consume tile i
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; ++i)
+            if (i < n) stage(s_begin + i, i);
+        int cur = 0;           // ring slot of tile i
+        int nxt = STAGES - 1;  // ring slot tile i+STAGES-1 goes to
+        for (int i = 0; i < n; ++i) {
+            if (i + STAGES - 1 <= n)
+                wait_vmcnt<NI*(STAGES - 2)>();  // tile i has landed; the younger ones stay in flight
+            else
+                wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // everyone's share landed; everyone finished reading the slot refilled below
+            asm volatile("" ::: "memory");
+            if (i + STAGES - 1 < n) stage(s_begin + i + STAGES - 1, nxt);
+            bf16x8 a0[NA], b0[NB], a1[NA], b1[NB];
+            load_half(cur, 0, a0, b0);
+            load_half(cur, 1, a1, b1);
+            mma_half(a0, b0);
+            mma_half(a1, b1);
+            cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+            nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+        }
     }
 
     // ---- epilogue: the lane holds runs of 16 consecutive channels of a time row
@@ -320,7 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         const int co_base = co0 + wn * 64 + jc * 32 + lane_c;
         float bias_v[16];
         if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU || MODE == SL_EPI_BIAS_ELU)
-            load_bias16(a.bias, co_base, bias_v);
+            load_bias16(e.bias, co_base, bias_v);
 #pragma unroll
         for (int it = 0; it < NRUN_T; ++it) {
             const int trow = wm * WROWS + it * (M32 ? 32 : 16) + lane_t;
@@ -335,15 +455,267 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
                     for (int r = 0; r < 4; ++r) v[jn * 4 + r] = acc[jn * IT + it][r];
             }
             if (MODE == MODE_PARTIAL) {
-                float* out = a.partial + ((long)(split * a.batch + b) * (a.t_tiles * BM) + t0 + trow) * a.cout + co_base;
+                float* out = e.partial + ((long)(split * e.batch + b) * (e.t_tiles * BM) + t0 + trow) * e.cout + co_base;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *(f32x4*)(out + i * 4) = (f32x4){v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
             } else {
                 const int t = t0 + trow;
-                if (t < a.t_out) {
-                    const long yidx = (long)b * a.y_bs + (long)(a.y_row0 + t) * a.y_rs + co_base;
-                    store_run16<MODE, OUT_F32>(a, v, bias_v, yidx);
+                if (t < e.t_out) {
+                    const long yidx = (long)b * e.y_bs + (long)(e.y_row0 + t) * e.y_rs + co_base;
+                    store_run16<MODE, OUT_F32>(e, v, bias_v, yidx);
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Slab variant (16x16x32 shape only).  Contraction order chunk OUTER, tap INNER: for one 64-channel chunk the BM + taps - 1
+// activation rows a tile needs for ALL taps are brought into LDS ONCE (the "slab", double buffered) and every tap reads its
+// B fragments from the slab at a row offset, so that a step only streams the BN x 64 weight tile.  L2 -> LDS bytes per
+// step drop from (BM + BN) * 128 to BN * 128 + BM * 128 / taps (inner layers, taps = 7: 32 -> 18.3 KB; big_conv_1, taps =
+// 32, 256x256 tile: 64 -> 33 KB) and the activation re-reads that used to miss the L2 between taps (big_conv_1 dgrad:
+// ~2 GB per launch out of the Infinity Cache) disappear.  The XOR swizzle key is the SLAB row & 7, so a fragment read at
+// row offset `tap` stays bank-conflict free for every tap (checked exhaustively).
+//   LDS: [slab 0][slab 1][weight ring: STAGES slots];   slab rows = BM + 32  (taps <= 33)
+//   vmcnt bookkeeping: the slab of chunk c+1 is issued in step (c, tap 0) BEFORE that step's weight tile, so it is older
+//   than every weight tile of chunk c+1 (needs taps >= STAGES) and only the steps with tap in [1, STAGES-2] see it among
+//   the instructions that may stay in flight.
+template <int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_slab_bf16_kernel(NtArgs a) {
+    constexpr int STAGES = STAGES_P & 7;
+    constexpr bool PIPE = (STAGES_P & 8) != 0;
+    static_assert(STAGES >= 2, "ring too shallow");
+    constexpr int NW = WM * WN;
+    constexpr int WROWS = 16 * IT;
+    constexpr int BM = WROWS * WM;
+    constexpr int BN = 64 * WN;
+    constexpr int SLAB_GROUPS = BM / 8 + 4;  // 8-row DMA groups per slab
+    constexpr int SLAB_BYTES = SLAB_GROUPS * 1024;
+    constexpr int W_BYTES = BN * 128;
+    constexpr int XPW = (SLAB_GROUPS + NW - 1) / NW;  // slab DMA instructions per wave per chunk
+    constexpr int WPW = (BN / 8) / NW;                // weight-tile DMA instructions per wave per step
+    static_assert((BN / 8) % NW == 0, "weight tile rows must split evenly over the waves");
+    constexpr int RING0 = 2 * SLAB_BYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const int m_tiles = a.batch * a.t_tiles;
+    const int tiles = m_tiles * a.n_tiles;
+    const int id = xcd_remap(blockIdx.x, tiles * a.ksplit);
+    const int split = id / tiles;
+    const int tile = id - split * tiles;
+    const int span = a.n_tiles * a.gm;  // 2-D raster, see conv_nt_bf16_kernel
+    const int blk = tile / span;
+    const int rem = tile - blk * span;
+    int cnt = m_tiles - blk * a.gm;
+    if (cnt > a.gm) cnt = a.gm;
+    const int n_tile = rem / cnt;
+    const int m_tile = blk * a.gm + (rem - n_tile * cnt);
+    const int b = m_tile / a.t_tiles;
+    const int t0 = (m_tile - b * a.t_tiles) * BM;
+    const int co0 = n_tile * BN;
+    const int s_begin = split * a.steps_per_split;  // a multiple of taps (whole chunks per split)
+    int n = a.nsteps - s_begin;
+    if (n > a.steps_per_split) n = a.steps_per_split;
+    const int taps = a.taps;
+    const int c0 = s_begin / taps;
+    const int nchunks = n / taps;
+
+    const __bf16* xbase = a.x + (long)b * a.x_bs + (long)(a.x_row0 + t0) * a.x_rs;
+    const __bf16* wbase = a.w + (long)co0 * a.w_rs;
+    int xoff[XPW], xdst[XPW], woff[WPW];
+    const int last_row = BM + taps - 2;  // last slab row any tap reads; rows behind it are clamped (never read from LDS)
+#pragma unroll
+    for (int q = 0; q < XPW; ++q) {
+        int j = wave * XPW + q;
+        if (j > SLAB_GROUPS - 1) j = SLAB_GROUPS - 1;
+        int row = j * 8 + (lane >> 3);
+        if (row > last_row) row = last_row;
+        xoff[q] = row * a.x_rs + (((lane & 7) ^ (lane >> 3)) << 3);
+        xdst[q] = j * 1024;
+    }
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+        const int j = wave * WPW + q;
+        const int row = j * 8 + (lane >> 3);
+        const int key = ((lane >> 4) & 1) | (((j >> 1) & 3) << 1);
+        woff[q] = row * a.w_rs + (((lane & 7) ^ key) << 3);
+    }
+    auto issue_slab = [&](int cc, int par) {
+        const __bf16* xs = xbase + cc * BK;
+#pragma unroll
+        for (int q = 0; q < XPW; ++q) glds16(xs + xoff[q], smem + par * SLAB_BYTES + xdst[q]);
+    };
+    auto issue_w = [&](int tap, int cc, int slot) {
+        const __bf16* ws = wbase + (long)tap * a.cin + cc * BK;
+        char* wl = smem + RING0 + slot * W_BYTES + (wave * WPW) * 1024;
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) glds16(ws + woff[q], wl + q * 1024);
+    };
+
+    const int g = lane >> 4;
+    const int brow = wm * WROWS + (lane & 15);                        // + it*16 + tap
+    const int arow = wn * 64 + ((lane & 15) >> 2) * 16 + (lane & 3);  // + jn*4
+    const int akey = ((lane >> 1) & 1) | (((lane >> 2) & 3) << 1);
+    const int aoff = RING0 + arow * 128 + ((g ^ akey) << 4);
+    auto b_offset = [&](int par, int tap) {  // byte offset of this lane's B fragment (it = 0, first half) in LDS
+        const int r = brow + tap;
+        return par * SLAB_BYTES + (r << 7) + (((g ^ r) & 7) << 4);
+    };
+
+    f32x4 acc[4 * IT];
+#pragma unroll
+    for (int i = 0; i < 4 * IT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma_half = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[IT]) {
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+                acc[jn * IT + it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn * IT + it], 0, 0, 0);
+    };
+
+    NtArgs e = a;  // epilogue arguments pinned in SGPRs before the loop, see conv_nt_bf16_kernel
+    asm volatile("" : "+s"(e.y), "+s"(e.mask), "+s"(e.bias), "+s"(e.partial), "+s"(e.y_bs));
+    asm volatile("" : "+s"(e.y_row0), "+s"(e.y_rs), "+s"(e.t_out), "+s"(e.cout), "+s"(e.batch), "+s"(e.t_tiles));
+
+    // issue-side counters (the next weight tile to request) and compute-side counters (the step being multiplied)
+    int tap_i = 0, cc_i = c0;
+    auto issue_next_w = [&](int slot) {
+        issue_w(tap_i, cc_i, slot);
+        if (++tap_i == taps) {
+            tap_i = 0;
+            ++cc_i;
+        }
+    };
+    int tap_c = 0, par_c = 0, chunk_c = 0;  // chunk_c counts chunks of this split
+
+    if constexpr (PIPE) {
+        issue_slab(c0, 0);
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i)
+            if (i < n) issue_next_w(i);
+        if (n >= STAGES)
+            wait_vmcnt<WPW*(STAGES - 1)>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 a0[4], b0[IT], a1[4], b1[IT];
+        constexpr int NF = 4 + IT;
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        auto read_half = [&](int slot, int par, int tap, int h, bf16x8 (&af)[4], bf16x8 (&bfr)[IT]) {
+            DsReadRun<0, 4, 512>::go(af, lds0 + ((aoff + slot * W_BYTES) ^ (h << 6)));
+            DsReadRun<0, IT, 2048>::go(bfr, lds0 + (b_offset(par, tap) ^ (h << 6)));
+        };
+        read_half(0, 0, 0, 0, a0, b0);
+        int cur = 0;
+        for (int i = 0; i + 1 < n; ++i) {
+            const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
+            read_half(cur, par_c, tap_c, 1, a1, b1);
+            wait_frags<NF>(a0, b0);
+            mma_half(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_frags<0>(a1, b1);  // my reads of weight slot cur (and, on a chunk's last tap, of its slab) are complete
+            const bool has_next_chunk = chunk_c + 1 < nchunks;
+            if (i + STAGES <= n) {
+                if (STAGES > 2 && has_next_chunk && tap_c >= 1 && tap_c <= STAGES - 2)
+                    wait_vmcnt<WPW*(STAGES - 2) + XPW>();  // the next chunk's slab may stay in flight as well
+                else
+                    wait_vmcnt<WPW*(STAGES - 2)>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tap_c == 0 && has_next_chunk) issue_slab(c0 + chunk_c + 1, par_c ^ 1);
+            if (i + STAGES < n) issue_next_w(cur);
+            if (++tap_c == taps) {
+                tap_c = 0;
+                par_c ^= 1;
+                ++chunk_c;
+            }
+            read_half(nxt, par_c, tap_c, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        read_half(cur, par_c, tap_c, 1, a1, b1);
+        wait_frags<NF>(a0, b0);
+        mma_half(a0, b0);
+        wait_frags<0>(a1, b1);
+        mma_half(a1, b1);
+    } else {
+        issue_slab(c0, 0);
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; ++i)
+            if (i < n) issue_next_w(i);
+        int cur = 0;
+        int nxt = STAGES - 1;
+        for (int i = 0; i < n; ++i) {
+            const bool has_next_chunk = chunk_c + 1 < nchunks;
+            if (i + STAGES - 1 <= n) {
+                if (STAGES > 2 && has_next_chunk && tap_c >= 1 && tap_c <= STAGES - 2)
+                    wait_vmcnt<WPW*(STAGES - 2) + XPW>();
+                else
+                    wait_vmcnt<WPW*(STAGES - 2)>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tap_c == 0 && has_next_chunk) issue_slab(c0 + chunk_c + 1, par_c ^ 1);
+            if (i + STAGES - 1 < n) issue_next_w(nxt);
+            const char* wl = smem + cur * W_BYTES;
+            const char* xl = smem + b_offset(par_c, tap_c);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[4], bfr[IT];
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) af[jn] = *(const bf16x8*)(wl + ((aoff + jn * 512) ^ (kk << 6)));
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+                    bfr[it] = *(const bf16x8*)(smem + ((b_offset(par_c, tap_c) + it * 2048) ^ (kk << 6)));
+                mma_half(af, bfr);
+            }
+            (void)xl;
+            if (++tap_c == taps) {
+                tap_c = 0;
+                par_c ^= 1;
+                ++chunk_c;
+            }
+            cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+            nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+        }
+    }
+
+    // ---- epilogue (identical to conv_nt_bf16_kernel's 16x16 path)
+    const int co_base = co0 + wn * 64 + (lane >> 4) * 16;
+    float bias_v[16];
+    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU || MODE == SL_EPI_BIAS_ELU) load_bias16(e.bias, co_base, bias_v);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int trow = wm * WROWS + it * 16 + (lane & 15);
+        float v[16];
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[jn * 4 + r] = acc[jn * IT + it][r];
+        if (MODE == MODE_PARTIAL) {
+            float* out = e.partial + ((long)(split * e.batch + b) * (e.t_tiles * BM) + t0 + trow) * e.cout + co_base;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(out + i * 4) = (f32x4){v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+        } else {
+            const int t = t0 + trow;
+            if (t < e.t_out) {
+                const long yidx = (long)b * e.y_bs + (long)(e.y_row0 + t) * e.y_rs + co_base;
+                store_run16<MODE, OUT_F32>(e, v, bias_v, yidx);
             }
         }
     }
@@ -423,18 +795,33 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
 
 template <bool M32, int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
 int launch_main(const NtArgs& a, hipStream_t s) {
-    constexpr int LDS_BYTES = STAGES * ((M32 ? 64 : 16 * IT) * WM + 64 * WN) * 128;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_nt_bf16_kernel<M32, IT, WM, WN, STAGES, MODE, OUT_F32>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
     const int grid = a.batch * a.t_tiles * a.n_tiles * a.ksplit;
-    hipLaunchKernelGGL((conv_nt_bf16_kernel<M32, IT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid), dim3(64 * WM * WN),
-                       LDS_BYTES, s, a);
-    return sl_check_launch("sl_conv1d_nt(bf16)");
+    if constexpr (!M32 && IT >= 100) {  // slab variant: IT - 100 is the real IT
+        constexpr int RIT = IT - 100;
+        constexpr int LDS_BYTES = 2 * (16 * RIT * WM / 8 + 4) * 1024 + (STAGES & 7) * 64 * WN * 128;
+        static_assert(LDS_BYTES <= 160 * 1024, "slabs + weight ring exceed the 160 KiB of a CU");
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_nt_slab_bf16_kernel<RIT, WM, WN, STAGES, MODE, OUT_F32>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_nt_slab_bf16_kernel<RIT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid),
+                           dim3(64 * WM * WN), LDS_BYTES, s, a);
+        return sl_check_launch("sl_conv1d_nt(bf16, slab)");
+    } else {
+        constexpr int LDS_BYTES = (STAGES & 7) * ((M32 ? 64 : 16 * IT) * WM + 64 * WN) * 128;
+        static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds the 160 KiB of a CU");
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_nt_bf16_kernel<M32, IT, WM, WN, STAGES, MODE, OUT_F32>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_nt_bf16_kernel<M32, IT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid), dim3(64 * WM * WN),
+                           LDS_BYTES, s, a);
+        return sl_check_launch("sl_conv1d_nt(bf16)");
+    }
 }
 
 template <int MODE, bool OUT_F32>
@@ -447,7 +834,7 @@ int launch_tail(const NtArgs& a, int rows_per_batch, hipStream_t s) {
 
 template <bool M32, int IT, int WM, int WN, int STAGES>
 int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
-    constexpr int BM = (M32 ? 64 : 16 * IT) * WM;
+    constexpr int BM = (M32 ? 64 : 16 * (IT >= 100 ? IT - 100 : IT)) * WM;
     a.t_tiles = (a.t_out + BM - 1) / BM;
     a.n_tiles = a.cout / (64 * WN);
     if (a.ksplit > 1) {
@@ -486,12 +873,18 @@ int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
 
 struct Cfg {
     int wm, wn, stages, ksplit, it, m32;
+    int gm = 0;  // m-tiles per raster block (0 = automatic)
+    int slab = 0;  // chunk-major contraction with the activation slab kept in LDS (conv_nt_slab_bf16_kernel)
     int bm() const { return (m32 ? 64 : 16 * it) * wm; }
 };
 
-// cfg word: wm | wn << 4 | stages << 8 | ksplit << 12 | it << 20 (it = 0 means 4) | m32 << 24; 0 = choose automatically
+// cfg word: wm | wn << 4 | stages << 8 | ksplit << 12 | it << 20 (it = 0 means 4) | m32 << 24 | (1 + log2 gm) << 25 (0 = auto)
+// | slab << 29;  0 = choose everything automatically
 Cfg decode_cfg(int cfg) {
     Cfg c{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 15, (cfg >> 12) & 255, (cfg >> 20) & 15, (cfg >> 24) & 1};
+    const int gml = (cfg >> 25) & 15;
+    c.gm = gml ? 1 << (gml - 1) : 0;
+    c.slab = (cfg >> 29) & 1;
     if (c.it == 0) c.it = 4;
     if (c.m32) c.it = 4;
     return c;
@@ -502,20 +895,30 @@ Cfg auto_cfg(const sl_conv_geom* g) {
     const long nsteps = (long)g->taps * (g->cin / BK);
     if (g->cout % 256 == 0) {
         const long tiles256 = (long)g->batch * ((g->t_out + 255) / 256) * (g->cout / 256);
-        // 256x256 tile, 16 waves, one work-group per CU: 1.35 PFLOP/s on big_conv_1 (vs 1.03 for 128x128)
-        if (tiles256 >= 192) return Cfg{4, 4, 2, 1, 4, 0};
+        const bool slab_ok = g->taps >= 2 && g->taps <= 33;
+        // 256x256 tile, one work-group per CU.  With taps the slab variant (8 waves of 128x64, register-pipelined):
+        // big_conv_1 forward 0.348 ms = 1.47 PFLOP/s against 0.372 for the 16-wave tap-major kernel; 1x1 layers keep
+        // the 16-wave kernel (1.19 PFLOP/s on big_conv_2)
+        if (tiles256 >= 192) return slab_ok ? Cfg{2, 4, 10, 1, 8, 0, 0, 1} : Cfg{4, 4, 2, 1, 4, 0};
         if (nsteps >= 256) {  // long contraction but few tiles (dgrad of big_conv_1: 64 tiles, K = 65536): split K
             long ks = (256 + tiles256 - 1) / tiles256;
             if (ks > 8) ks = 8;
+            const long chunks = g->cin / BK;
+            if (slab_ok && chunks % ks == 0) return Cfg{2, 4, 10, (int)ks, 8, 0, 0, 1};
             return Cfg{4, 4, 2, (int)ks, 4, 0};
         }
     }
-    // short layers (one 128x128 tile per CU at most): 8 waves of 32x64 per tile so that each SIMD holds two waves and
-    // one wave's DMA issue overlaps the other's MFMAs; 3-deep ring
-    return Cfg{4, 2, 3, 1, 2, 0};
+    // short layers (one 128x128 tile per CU at most): 8 waves of 32x64 per tile (two waves per SIMD), 3-slot ring,
+    // register-pipelined loop with hand-counted LDS waits: 18.8 us per 250-channel layer against 20.7 for the plain loop
+    return Cfg{4, 2, 11, 1, 2, 0};
 }
 
-bool valid_cfg(const Cfg& c, const sl_conv_geom* g) {
+bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
+    Cfg c = full;
+    c.stages = full.stages & 7;  // bit 3 selects the register-pipelined loop, instantiated for the shapes listed below
+    if ((full.stages & 8) && (c.m32 || !((c.it == 4 && c.wm * c.wn >= 4 && c.wm * c.wn <= 8) || c.it == 8 ||
+                                         (c.it == 2 && c.wm == 4 && c.wn == 2))))
+        return false;
     bool shape;
     if (c.m32)
         shape = (c.wm == 2 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) || (c.wm == 4 && c.wn == 4 && c.stages == 2) ||
@@ -529,10 +932,21 @@ bool valid_cfg(const Cfg& c, const sl_conv_geom* g) {
                 (c.it == 4 && c.wm == 2 && c.wn == 2 && (c.stages >= 2 && c.stages <= 4)) ||
                 (c.it == 4 && c.wm == 4 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
                 (c.it == 4 && c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
-                (c.it == 4 && c.wm == 4 && c.wn == 4 && c.stages == 2);
+                (c.it == 4 && c.wm == 4 && c.wn == 4 && c.stages == 2) ||
+                (c.it == 8 && c.wm == 2 && c.wn == 4 && c.stages == 2) ||  // 256x256 tile, 8 waves of 128x64
+                (c.it == 8 && c.wm == 2 && c.wn == 2 && (c.stages == 2 || c.stages == 3));  // 256x128
     if (!shape || c.ksplit < 1) return false;
     if (g->cout % (64 * c.wn)) return false;
     const long nsteps = (long)g->taps * (g->cin / BK);
+    if (c.slab) {
+        // instantiated slab shapes; the slab holds BM + 32 rows and its DMA must be older than the next chunk's tiles
+        const bool inst = !c.m32 && ((c.it == 4 && c.wm == 4 && c.wn == 4 && full.stages == 2) ||
+                                     (c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10) ||
+                                     (c.it == 2 && c.wm == 4 && c.wn == 2 && (full.stages == 11 || full.stages == 3)) ||
+                                     (c.it == 4 && c.wm == 2 && c.wn == 2 && (full.stages == 11 || full.stages == 12)));
+        if (!inst || g->taps > 33 || g->taps < c.stages) return false;
+        return c.ksplit <= g->cin / BK;  // whole chunks per split
+    }
     return c.ksplit <= nsteps;
 }
 
@@ -575,7 +989,16 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
     a.cin = g->cin;
     a.nsteps = g->taps * (g->cin / BK);
     a.ksplit = c.ksplit;
+    {
+        const int bm = c.bm();
+        const int m_tiles = g->batch * ((g->t_out + bm - 1) / bm);
+        const int n_tiles = g->cout / (64 * c.wn);
+        int gm = c.gm;
+        if (gm == 0) gm = n_tiles >= 4 ? 16 : m_tiles;
+        a.gm = gm < m_tiles ? gm : m_tiles;
+    }
     a.steps_per_split = (a.nsteps + c.ksplit - 1) / c.ksplit;
+    if (c.slab) a.steps_per_split = ((g->cin / BK + c.ksplit - 1) / c.ksplit) * g->taps;  // whole chunks per split
     a.ksplit = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;  // no empty splits
     if (a.ksplit > 1) {
         const size_t need = conv_nt_bf16_workspace_bytes(g, cfg);
@@ -584,9 +1007,37 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
             return SL_ERR_WORKSPACE_TOO_SMALL;
         }
     }
+#define SL_NT_SLAB_CASE(IT_, WM_, WN_, ST_)                                      \
+    if (c.slab && c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
+        return launch_cfg<false, 100 + IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);
+    SL_NT_SLAB_CASE(4, 4, 4, 2)
+    SL_NT_SLAB_CASE(8, 2, 4, 10)
+    SL_NT_SLAB_CASE(2, 4, 2, 11)
+    SL_NT_SLAB_CASE(2, 4, 2, 3)
+    SL_NT_SLAB_CASE(4, 2, 2, 11)
+    SL_NT_SLAB_CASE(4, 2, 2, 12)
+#undef SL_NT_SLAB_CASE
+    if (c.slab) {
+        sl_set_error("sl_conv1d_nt(bf16): slab configuration not instantiated");
+        return SL_ERR_UNSUPPORTED;
+    }
 #define SL_NT_CASE(M32_, IT_, WM_, WN_, ST_)                                                \
     if (c.m32 == M32_ && c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
         return launch_cfg<(M32_ != 0), IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);
+    SL_NT_CASE(0, 4, 2, 2, 10)
+    SL_NT_CASE(0, 4, 2, 2, 11)
+    SL_NT_CASE(0, 4, 2, 2, 12)
+    SL_NT_CASE(0, 2, 4, 2, 10)
+    SL_NT_CASE(0, 2, 4, 2, 11)
+    SL_NT_CASE(0, 2, 4, 2, 12)
+    SL_NT_CASE(0, 4, 4, 2, 10)
+    SL_NT_CASE(0, 4, 4, 2, 11)
+    SL_NT_CASE(0, 4, 2, 4, 10)
+    SL_NT_CASE(0, 4, 2, 4, 11)
+    SL_NT_CASE(0, 8, 2, 4, 10)
+    SL_NT_CASE(0, 8, 2, 4, 2)
+    SL_NT_CASE(0, 8, 2, 2, 10)
+    SL_NT_CASE(0, 8, 2, 2, 11)
     SL_NT_CASE(0, 4, 2, 2, 2)
     SL_NT_CASE(0, 4, 2, 2, 3)
     SL_NT_CASE(0, 4, 2, 2, 4)

@@ -46,6 +46,21 @@ class GradBucketReducer:
             work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append(work)
 
+    def run_after_reduce(self, fn):
+        """Enqueues fn(raw_stream) on the communication stream, i.e. behind every all-reduce issued so far, after the
+        kernels enqueued on the current stream up to now; wait_all() also waits for it.  (The engine puts the Adam
+        update of a finished bucket here so that it runs underneath the rest of backward.)"""
+        if not self.overlap:
+            raise RuntimeError("run_after_reduce needs the overlapped (device) reducer")
+        issued = torch.cuda.Event()
+        issued.record(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(issued)
+            fn(self.comm_stream.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+        self._pending.append(done)
+
     def wait_all(self):
         """Makes the current stream (or the host, on CPU) wait for every outstanding bucket."""
         for p in self._pending:

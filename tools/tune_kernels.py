@@ -17,8 +17,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def cfg_word(wm, wn, stages, ksplit, it=4, m32=0):
-    return wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20) | (m32 << 24)
+def cfg_word(wm, wn, stages, ksplit, it=4, m32=0, gml=0, slab=0):
+    return wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20) | (m32 << 24) | (gml << 25) | (slab << 29)
 
 
 def main():
@@ -59,9 +59,15 @@ def main():
     shapes = [(2, 2, 2, 4), (2, 2, 3, 4), (2, 2, 4, 4), (4, 2, 2, 4), (4, 2, 3, 4), (2, 4, 2, 4), (2, 4, 3, 4), (4, 4, 2, 4),
               (4, 2, 2, 2), (4, 2, 3, 2), (4, 2, 4, 2), (8, 2, 2, 2), (8, 2, 3, 2),
               (2, 2, 2, 2), (2, 2, 3, 2), (2, 2, 4, 2), (2, 4, 2, 2), (2, 4, 3, 2),  # 64-row tiles: 2+ work-groups per CU
+              # stages | 8 = register-pipelined loop
+              (2, 2, 10, 4), (2, 2, 11, 4), (2, 2, 12, 4), (4, 2, 10, 2), (4, 2, 11, 2), (4, 2, 12, 2),
+              (4, 2, 10, 4), (4, 2, 11, 4), (2, 4, 10, 4), (2, 4, 11, 4),
+              (2, 4, 10, 8), (2, 4, 2, 8), (2, 2, 10, 8), (2, 2, 11, 8),  # it = 8: 128x64 wave patches, 8 waves per 256-row tile
               # it = 32: the v_mfma_f32_32x32x16_bf16 variant (64x64 wave patch)
               (2, 2, 2, 32), (2, 2, 3, 32), (2, 2, 4, 32), (4, 2, 2, 32), (4, 2, 3, 32), (2, 4, 2, 32), (2, 4, 3, 32),
               (4, 4, 2, 32)]
+    # slab variant (chunk-major, activation slab kept in LDS): it + 100
+    shapes += [(4, 4, 2, 104), (2, 4, 10, 108), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
     results = {}
     n = len(eng.plans)
 
@@ -93,10 +99,16 @@ def main():
         for (wm, wn, stg, it) in shapes:
             if geom.cout % (64 * wn):
                 continue
+            slab = it >= 100
+            if slab and (geom.taps < (stg & 7) or geom.taps > 33):
+                continue
             for ks in (1, 2, 4, 8):
                 if ks > 1 and nsteps < 12 * ks:
                     continue
-                cfg = cfg_word(wm, wn, stg, ks, 4, 1) if it == 32 else cfg_word(wm, wn, stg, ks, it)
+                if slab and ks > geom.cin // 64:
+                    continue
+                cfg = (cfg_word(wm, wn, stg, ks, 4, 1) if it == 32 else
+                       cfg_word(wm, wn, stg, ks, it - 100, slab=1) if slab else cfg_word(wm, wn, stg, ks, it))
                 try:
                     out = run(kind, p, cfg)
                     torch.cuda.synchronize()
