@@ -19,13 +19,41 @@ def _newest_source_mtime():
     return max(f.stat().st_mtime for f in files)
 
 
+# These files read LDS fragments through inline asm with hand-counted s_waitcnt (the compiler does not know the
+# registers are still being filled).  A register spill would store such a register before its data has arrived, so a
+# kernel of these files that needs scratch memory is a BUILD ERROR, not a slow kernel.
+NO_SCRATCH = {"conv_nt_bf16.hip", "wgrad_tn_bf16.hip"}
+
+
+def _scratch_users(remarks):
+    """kernel names with ScratchSize > 0 in hipcc -Rpass-analysis=kernel-resource-usage output"""
+    bad, name = [], None
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[-Rpass")[0].strip()
+        elif "ScratchSize [bytes/lane]:" in line:
+            size = int(line.split("ScratchSize [bytes/lane]:")[1].split("[-Rpass")[0].strip())
+            if size > 0:
+                bad.append("{} ({} bytes/lane)".format(name, size))
+    return bad
+
+
 def _compile(src):
     obj = CSRC / (src.replace(".hip", ".o"))
     cmd = [HIPCC] + FLAGS + ["-c", str(CSRC / src), "-o", str(obj)]
+    if src in NO_SCRATCH:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for {}:\n{}\n{}".format(src, res.stdout, res.stderr))
-    return obj, res.stderr
+    err = res.stderr
+    if src in NO_SCRATCH:
+        bad = _scratch_users(err)
+        if bad:
+            raise RuntimeError("{}: kernels with asm-tracked LDS reads must not spill, but these use scratch: {}".format(
+                src, "; ".join(bad)))
+        err = "\n".join(l for l in err.splitlines() if "-Rpass-analysis" not in l)
+    return obj, err
 
 
 def build(force=False, verbose=False):

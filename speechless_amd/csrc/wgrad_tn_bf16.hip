@@ -17,6 +17,8 @@
 //     workspace and are summed in a fixed order by wgrad_reduce_kernel (deterministic, no float atomics).
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TK = 64;  // time rows per step
@@ -48,15 +50,35 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int RB>
-__device__ __forceinline__ bf16x8 tr_read8(const char* p0) {
-    // two 4x16 transpose reads: rows t..t+3 and t+4..t+7 (the +4 rows sit 4 LDS rows further, same swizzle key)
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SL_LDS s16x4*)(p0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SL_LDS s16x4*)(p0 + 4 * RB));
-    s16x8 v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+// Transpose reads are issued through inline asm with a hand-counted s_waitcnt.  Through the builtin the compiler cannot
+// tell that the read does not alias the LDS-DMA loads in flight and puts s_waitcnt vmcnt(0) in front of the first
+// read of every step -- AFTER the DMA of the next tile has been issued -- which serialises the HBM/L2 latency of every
+// tile with its MFMAs (measured: 1.9 us per 64-row step where the MFMAs need 1.0).
+template <int OFF>
+__device__ __forceinline__ void ds_tr(s16x4& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// one 8(t) x 16(channel) fragment = two 4x16 transpose reads: rows t..t+3 and t+4..t+7 (4 LDS rows further)
+template <int OFF, int RB>
+__device__ __forceinline__ void tr_read8(s16x4& lo, s16x4& hi, unsigned addr) {
+    ds_tr<OFF>(lo, addr);
+    ds_tr<OFF + 4 * RB>(hi, addr);
+}
+__device__ __forceinline__ bf16x8 frag8(s16x4 lo, s16x4 hi) {
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
+}
+// s_waitcnt lgkmcnt(CNT) the MFMAs consuming these half-fragments cannot be hoisted above
+template <int CNT>
+__device__ __forceinline__ void wait_ba(s16x4 (&bl)[4], s16x4 (&bh)[4], s16x4 (&al)[2], s16x4 (&ah)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]), "+v"(bh[3]),
+                   "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1])
+                 : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void wait_a(s16x4 (&al)[2], s16x4 (&ah)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]) : "n"(CNT));
 }
 
 // per-lane source offset (elements) of DMA instruction j for a [64][W*64] bf16 tile whose LDS rows are RB = 128*W bytes:
@@ -148,6 +170,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    // One 64-row step = 2 k-halves x 2 channel-halves = 4 quarters of 8 MFMAs; the fragments of the next quarter are
+    // requested before the MFMAs of the current one (hand-counted waits), within the 128-VGPR budget of 16 waves:
+    //   x fragments (all 4 of a k-half): xl/xh[k-half]; gradient fragments: two at a time in two alternating pairs
+    auto read_x = [&](unsigned sl, auto kk_c, s16x4 (&bl)[4], s16x4 (&bh)[4]) {
+        constexpr int KK = decltype(kk_c)::value;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) tr_read8<KK * 32 * XRB, XRB>(bl[it], bh[it], sl + xoffr[it]);
+    };
+    auto read_g = [&](unsigned sl, auto kk_c, int jh, s16x4 (&al)[2], s16x4 (&ah)[2]) {
+        constexpr int KK = decltype(kk_c)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tr_read8<KK * 32 * GRB, GRB>(al[j], ah[j], sl + goffr[jh * 2 + j]);
+    };
+    auto mma_q = [&](int jh, s16x4 (&al)[2], s16x4 (&ah)[2], s16x4 (&bl)[4], s16x4 (&bh)[4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x8 af = frag8(al[j], ah[j]);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                acc[jh * 2 + j][it] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag8(bl[it], bh[it]), acc[jh * 2 + j][it], 0, 0, 0);
+        }
+    };
+    const std::integral_constant<int, 0> K0{};
+    const std::integral_constant<int, 1> K1{};
+    auto compute_step = [&](unsigned sl) {
+        s16x4 xl[4], xh[4], pl[2], ph[2], ql[2], qh[2];
+        read_x(sl, K0, xl, xh);
+        read_g(sl, K0, 0, pl, ph);  // 12 reads
+        read_g(sl, K0, 1, ql, qh);  // +4
+        wait_ba<4>(xl, xh, pl, ph);
+        mma_q(0, pl, ph, xl, xh);
+        __builtin_amdgcn_sched_barrier(0);
+        read_g(sl, K1, 0, pl, ph);  // p is free: its MFMAs have been issued
+        wait_a<4>(ql, qh);
+        mma_q(1, ql, qh, xl, xh);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(sl, K1, xl, xh);     // x fragments are single-buffered (128-VGPR budget): this read is the exposed one
+        read_g(sl, K1, 1, ql, qh);
+        wait_ba<4>(xl, xh, pl, ph);
+        mma_q(0, pl, ph, xl, xh);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_a<0>(ql, qh);
+        mma_q(1, ql, qh, xl, xh);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
 #pragma unroll
     for (int i = 0; i < STAGES - 1; ++i)
         if (i < n) stage(i, i);
@@ -160,20 +230,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (i + STAGES - 1 < n) stage(i + STAGES - 1, nxt);
-        const char* sl = smem + cur * STAGE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn) af[jn] = tr_read8<GRB>(sl + goffr[jn] + kk * (32 * GRB));
-#pragma unroll
-            for (int it = 0; it < 4; ++it) bfr[it] = tr_read8<XRB>(sl + xoffr[it] + kk * (32 * XRB));
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    acc[jn][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn][it], 0, 0, 0);
-        }
+        const unsigned sl = lds0 + cur * STAGE_BYTES;
+        compute_step(sl);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
         nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
