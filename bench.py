@@ -121,33 +121,36 @@ def main():
     # ---- roofline leg: a few more steps with HIP events around every launch (same stream as the kernels)
     t_out = FRAMES // 2
     fl = layer_flops_per_utt(specs, t_out)
-    eng.timeline = []
-    for _ in range(args.profile_steps):
-        eng.train_step_resident(reducer)
-    torch.cuda.synchronize()
-    per_tag = {}
-    for tag, start, stop in eng.timeline:
-        per_tag.setdefault(tag, []).append(start.elapsed_time(stop))
-    eng.timeline = None
-    avg_ms = {tag: float(np.mean(v)) for tag, v in per_tag.items()}
+    def timeline_pass():
+        eng.timeline = []
+        for _ in range(args.profile_steps):
+            eng.train_step_resident(reducer)
+        torch.cuda.synchronize()
+        per_tag = {}
+        for tag, start, stop in eng.timeline:
+            per_tag.setdefault(tag, []).append(start.elapsed_time(stop))
+        eng.timeline = None
+        return {tag: float(np.mean(v)) for tag, v in per_tag.items()}
+
+    live_ms = timeline_pass()  # same conditions as the timed region (bias gradients overlapped on the side stream)
     names = [s.name for s in specs]
-    # Dominant kernel (largest share of GPU time in profiles/r01e_kernel_stats.csv, 26 %): wgrad_tn_bf16_kernel<4,4,2>,
-    # the 256x256-tile weight-gradient kernel.  FOUR launches per step use this instantiation (the library's measured
-    # table picks it for striding_conv, big_conv_1, big_conv_2 and for the grouped launch that covers the seven
-    # inner_conv_i); algorithmic FLOPs per launch = (sum of those ten layers' wgrad FLOPs) / 4.
-    dom_tags = [t for t in avg_ms if t.startswith("wgrad:") and t != "wgrad:output_conv"]
-    dom_layer_flops = sum(fl[i] for i, n in enumerate(names) if n != "output_conv")
+    # Dominant kernel (largest share of GPU time in profiles/r01f_kernel_stats.csv): wgrad_tn_bf16_kernel<4,4,2>, the
+    # 256x256-tile weight-gradient kernel.  THREE launches per step use this instantiation (the library's measured table
+    # picks it for big_conv_1, big_conv_2 and for the grouped launch that covers the seven inner_conv_i);
+    # algorithmic FLOPs per launch = (sum of those nine layers' wgrad FLOPs) / 3.
+    dom_tags = [t for t in live_ms if t.startswith("wgrad:") and t not in ("wgrad:output_conv", "wgrad:striding_conv")]
+    dom_layer_flops = sum(fl[i] for i, n in enumerate(names) if n not in ("output_conv", "striding_conv"))
     dom_flops = dom_layer_flops * BATCH_PER_GPU / len(dom_tags)
-    dom_ms = sum(avg_ms[t] for t in dom_tags) / len(dom_tags)
+    dom_ms = sum(live_ms[t] for t in dom_tags) / len(dom_tags)
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+    avg_ms = live_ms
     traffic = None
     pmc = ROOT / "profiles" / "r01c_pmc_traffic_wgrad442.json"
     if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 read correction)
         traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
     # second kernel by time: the 256x256 forward/dgrad NT kernel (fwd of big_conv_1 and big_conv_2)
-    nt_tags = ["fwd:big_conv_1", "fwd:big_conv_2"]
-    nt_flops = (fl[names.index("big_conv_1")] + fl[names.index("big_conv_2")]) * BATCH_PER_GPU / 2
-    nt_ms = sum(avg_ms[t] for t in nt_tags) / 2
+    nt_flops = fl[names.index("big_conv_1")] * BATCH_PER_GPU
+    nt_ms = live_ms["fwd:big_conv_1"]
     groups = {}
     for prefix, flops_of in (("fwd", lambda i: fl[i]), ("dgrad", lambda i: fl[i]), ("wgrad", lambda i: fl[i])):
         tags = [(i, prefix + ":" + n) for i, n in enumerate(names) if prefix + ":" + n in avg_ms]
@@ -186,17 +189,17 @@ def main():
                    "parallelism": "dp{}".format(world)},
         "final_mean_loss": final_loss,
         "step_mfma_frac": utt_per_s * fwdbwd_flops_per_utt / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world),
-        "roofline": {"bound": "mfma", "kernel": "wgrad_tn_bf16_kernel<4,4,2> (weight gradient of striding_conv, "
-                                                "big_conv_1, big_conv_2 and the grouped inner_conv_1..7 launch; "
-                                                "average over its {} launches per step)".format(len(dom_tags)),
+        "roofline": {"bound": "mfma", "kernel": "wgrad_tn_bf16_kernel<4,4,2> (weight gradient of big_conv_1, "
+                                                "big_conv_2 and the grouped inner_conv_1..7 launch; average over "
+                                                "its {} launches per step)".format(len(dom_tags)),
                      "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits "
                                      "included), average of the three single-layer launches measured in "
                                      "profiles/r01c_pmc_traffic_wgrad442.json",
                      "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms},
-        "roofline_nt_256x256": {"bound": "mfma", "kernel": "conv_nt_bf16_kernel<M32=0,IT=4,WM=4,WN=4,STAGES=2,"
-                                                           "BIAS_RELU,bf16> (forward of big_conv_1, big_conv_2)",
+        "roofline_nt_256x256": {"bound": "mfma", "kernel": "conv_nt_slab_bf16_kernel<IT=8,WM=2,WN=4,STAGES=2|pipelined,"
+                                                           "BIAS_RELU,bf16> (forward of big_conv_1)",
                                 "achieved": nt_flops / (nt_ms * 1e-3) / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": nt_flops / (nt_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
                                 "flops_per_launch": nt_flops, "avg_launch_ms": nt_ms},

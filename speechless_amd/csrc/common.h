@@ -51,9 +51,12 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __u
 // XCD-aware work-group remap: the dispatcher places block b on XCD b % 8 (speed only, never correctness).
 // Gives each XCD a contiguous range of logical ids so that neighbouring tiles share the XCD's private L2.
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
-    if ((total & 7) != 0) return bid;
-    return (bid & 7) * (total >> 3) + (bid >> 3);
+    // launch grids are padded to a multiple of 8 (xcd_grid); XCD k = bid % 8 takes the contiguous id range
+    // [k * per, (k + 1) * per), ids >= total have no work (the caller returns)
+    const int per = (total + 7) >> 3;
+    return (bid & 7) * per + (bid >> 3);
 }
+static inline int xcd_grid(int total) { return ((total + 7) >> 3) << 3; }
 
 // kernels' C++ entry points (called from capi.hip)
 int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     const int m_tiles = a.batch * a.t_tiles;
     const int tiles = m_tiles * a.n_tiles;
     const int id = xcd_remap(blockIdx.x, tiles * a.ksplit);
+    if (id >= tiles * a.ksplit) return;  // grid padding (xcd_grid)
     const int split = id / tiles;
     const int tile = id - split * tiles;
     // raster: consecutive ids (= one XCD's concurrently resident work-groups, see xcd_remap) cover a 2-D block of
@@ -508,6 +509,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     const int m_tiles = a.batch * a.t_tiles;
     const int tiles = m_tiles * a.n_tiles;
     const int id = xcd_remap(blockIdx.x, tiles * a.ksplit);
+    if (id >= tiles * a.ksplit) return;  // grid padding (xcd_grid)
     const int split = id / tiles;
     const int tile = id - split * tiles;
     const int span = a.n_tiles * a.gm;  // 2-D raster, see conv_nt_bf16_kernel
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
 
 template <bool M32, int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
 int launch_main(const NtArgs& a, hipStream_t s) {
-    const int grid = a.batch * a.t_tiles * a.n_tiles * a.ksplit;
+    const int grid = xcd_grid(a.batch * a.t_tiles * a.n_tiles * a.ksplit);
     if constexpr (!M32 && IT >= 100) {  // slab variant: IT - 100 is the real IT
         constexpr int RIT = IT - 100;
         constexpr int LDS_BYTES = 2 * (16 * RIT * WM / 8 + 4) * 1024 + (STAGES & 7) * 64 * WN * 128;

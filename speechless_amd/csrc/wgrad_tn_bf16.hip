@@ -118,6 +118,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
 
     // logical id = ((split * co_tiles + co_tile) * ci_tiles + ci_tile) * taps + tap
     int wg = xcd_remap(blockIdx.x, a.tiles * a.splits * a.groups);
+    if (wg >= a.tiles * a.splits * a.groups) return;  // grid padding (xcd_grid)
     const int group = wg / (a.tiles * a.splits);
     wg -= group * (a.tiles * a.splits);
     const int tap = wg % a.taps;
@@ -258,7 +259,7 @@ int launch(const TnArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<WM, WN, STAGES>), dim3(a.tiles * a.splits * a.groups), dim3(64 * WM * WN),
+    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<WM, WN, STAGES>), dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(64 * WM * WN),
                        LDS_BYTES, s, a);
     return sl_check_launch("sl_conv1d_wgrad(bf16)");
 }
@@ -288,8 +289,9 @@ WCfg auto_wcfg(const sl_conv_geom* g, int groups) {
     // measured on MI355X with tools/tune_kernels.py (profiles/r01_tune_kernels.json), see DESIGN.md section 3
     if (g->cin % 256 == 0 && g->cout % 256 == 0) {
         const long tiles256 = (long)g->taps * (g->cin / 256) * (g->cout / 256) * groups;
-        // 256x256 tile, 16 waves: big_conv_1 1085 TFLOP/s (128x128: 890), big_conv_2 918, striding_conv 643
-        if (tiles256 >= 24) return WCfg{4, 4, 2, choose_splits(g, 256, 256, 256, groups)};
+        // 256x256 tile, 16 waves: big_conv_1 1376 TFLOP/s (128x128: 1140), big_conv_2 1105 (128x128: 1121);
+        // striding_conv (24 such tiles) is better off with 128x128 tiles and 4 batch splits: 0.061 vs 0.065 ms
+        if (tiles256 >= 48) return WCfg{4, 4, 2, choose_splits(g, 256, 256, 256, groups)};
     }
     // short layers: 128x128 tiles, batch split so that ~2 work-groups land on every CU (deeper rings measured no gain)
     return WCfg{2, 2, 2, choose_splits(g, 128, 128, 512, groups)};

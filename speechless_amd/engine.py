@@ -302,7 +302,10 @@ class Engine:
         self.timeline = None
         self._side_stream = None
         self.overlap_wgrad = False
-        self.early_adam = True  # train_step_resident: Adam of a layer runs under the rest of backward (see backward())
+        # train_step_resident: Adam of a layer runs under the rest of backward (see backward()).  Measured on MI355X
+        # (tools/step_ab.py): 2.546 ms/step either way -- the HBM-bound update slows the MFMA kernels it overlaps by as
+        # much as it costs alone -- so it is off by default, which also keeps per-kernel timings clean.
+        self.early_adam = False
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
 
     # ------------------------------------------------------------------ plumbing

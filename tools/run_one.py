@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Runs ONE conv launch of the config-3 step repeatedly (for rocprofv3 --pmc passes on a single kernel).
 
-    python tools/run_one.py --kind fwd|dgrad|wgrad --layer big_conv_1 [--cfg 0] [--reps 20]
+    python tools/run_one.py --kind fwd|dgrad|wgrad|wgrad_grouped --layer big_conv_1 [--cfg 0] [--reps 20]
 """
 import argparse
 import ctypes
@@ -68,6 +68,13 @@ def main():
             eng.lib.call("sl_conv1d_nt", buf.g[i].data_ptr(), eng.w_dgrad[i].data_ptr(), None, buf.y[i - 1].data_ptr(),
                          buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_RELU_MASK, eng.dtype_code, 0,
                          args.cfg, ws.data_ptr(), ws.numel(), st)
+        elif args.kind == "wgrad_grouped":  # --layer = first layer of a run of identical layers (inner_conv_1)
+            lo, hi = [r for r in eng.runs if r[0] == i][0]
+            dw_lo, _ = eng.layer_param_views(eng.grads, p)
+            stride_elems = buf.batch * buf.rows * p.cin_pad
+            eng.lib.call("sl_conv1d_wgrad_grouped", buf.y[lo - 1].data_ptr(), buf.g[lo].data_ptr(), dw_lo.data_ptr(),
+                         ctypes.byref(buf.wgrad_geom[lo]), hi - lo + 1, stride_elems, stride_elems,
+                         p.w_numel + p.cout_pad, args.cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
         else:
             xin = buf.x0 if i == 0 else buf.y[i - 1]
             dw, _ = eng.layer_param_views(eng.grads, p)

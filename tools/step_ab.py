@@ -20,30 +20,37 @@ for i, n in enumerate(lab_len):
     labels[i, :n] = rng.randint(0, 28, size=n)
 eng.load_input(x)
 eng.set_labels(labels, lab_len, np.full(B, 500))
-def timed(label, steps=30):
-    for _ in range(5): eng.train_step_resident()
+import statistics
+def timed(steps=40):
+    for _ in range(3): eng.train_step_resident()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(steps): eng.train_step_resident()
     b.record(); torch.cuda.synchronize()
-    print("%-40s %.4f ms/step" % (label, a.elapsed_time(b) / steps))
-eng.early_adam = False; timed("adam after backward")
-eng.early_adam = True; timed("early adam (side stream)")
-real = eng._adam_layers
-eng._adam_layers = lambda layers, st: None
-timed("no adam at all")
-eng._adam_layers = real
+    return a.elapsed_time(b) / steps
+real_adam = eng._adam_layers
 real_launch = eng._launch
 def no_bias(tag, name, *args):
     if name == "sl_bias_grad": return
     real_launch(tag, name, *args)
-eng._launch = no_bias
-timed("early adam, no bias grads")
-eng._adam_layers = lambda layers, st: None
-timed("no adam, no bias grads")
 def only_conv(tag, name, *args):
     if name in ("sl_bias_grad", "sl_ctc_loss_grad", "sl_softmax_logq"): return
     real_launch(tag, name, *args)
-eng._launch = only_conv
-timed("convs only")
+variants = {
+    "A adam after backward (main)": dict(early=False, adam=True, launch=real_launch),
+    "B early adam (side)": dict(early=True, adam=True, launch=real_launch),
+    "C no adam": dict(early=True, adam=False, launch=real_launch),
+    "D early adam, no bias grads": dict(early=True, adam=True, launch=no_bias),
+    "E no adam, no bias grads": dict(early=True, adam=False, launch=no_bias),
+    "F convs only": dict(early=True, adam=False, launch=only_conv),
+}
+res = {k: [] for k in variants}
+for rep in range(4):
+    for k, v in variants.items():
+        eng.early_adam = v["early"]
+        eng._adam_layers = real_adam if v["adam"] else (lambda layers, st: None)
+        eng._launch = v["launch"]
+        res[k].append(timed())
+for k, v in res.items():
+    print("%-34s median %.4f  min %.4f  all %s" % (k, statistics.median(v), min(v), [round(x, 3) for x in v]))
