@@ -145,7 +145,7 @@ def main():
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12
     avg_ms = live_ms
     traffic = None
-    pmc = ROOT / "profiles" / "r01c_pmc_traffic_wgrad442.json"
+    pmc = ROOT / "profiles" / "r01g_pmc_traffic_wgrad442.json"
     if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 read correction)
         traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
     # second kernel by time: the 256x256 forward/dgrad NT kernel (fwd of big_conv_1 and big_conv_2)
@@ -195,8 +195,12 @@ def main():
                      "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits "
-                                     "included), average of the three single-layer launches measured in "
-                                     "profiles/r01c_pmc_traffic_wgrad442.json",
+                                     "included), average of its three launches per step, "
+                                     "profiles/r01g_pmc_traffic_wgrad442.json (tools/pmc_traffic.sh)",
+                     "duration_note": "HIP events around the sl_conv1d_wgrad call on its stream: the kernel plus, for "
+                                      "batch-split launches, the deterministic wgrad_reduce_grouped_kernel tail "
+                                      "(rocprofv3: 196.6 us kernel + 17 us reduce per launch in "
+                                      "profiles/r01g_kernel_stats.csv)",
                      "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms},
         "roofline_nt_256x256": {"bound": "mfma", "kernel": "conv_nt_slab_bf16_kernel<IT=8,WM=2,WN=4,STAGES=2|pipelined,"
                                                            "BIAS_RELU,bf16> (forward of big_conv_1)",
