@@ -5,7 +5,7 @@
 // q = (p + eps) / sum(p + eps)); greedy decode :417-436,:452-454 and grapheme_enconding.py:34-57.
 //
 // Kernels:
-//   softmax_logq_kernel : one thread per (b,t) frame: p = softmax(logits), logq = log q.            (HBM-bound, tiny)
+//   softmax_logq_kernel : one wave per (b,t) frame, lane = class: p = softmax(logits), logq = log q.   (HBM-bound, tiny)
 //   ctc_lattice_kernel  : grid (B, 2).  Work-group (b,0) runs the alpha recursion t = 0..T-1, work-group (b,1) the
 //                         beta recursion t = T-1..0, concurrently.  One thread per extended-label state
 //                         (S = 2L+1 <= 1024), log-space fp32, previous row double-buffered in LDS (one barrier per
@@ -34,32 +34,41 @@ __device__ __forceinline__ float lse3_2(float a, float b, float c) {
                                      __builtin_amdgcn_exp2f(c - m));
 }
 
-__global__ void softmax_logq_kernel(const float* __restrict__ logits, float* __restrict__ probs,
-                                    float* __restrict__ logq, long frames, int t_out, int k, int logit_stride,
-                                    long logit_batch_stride, float eps) {
-    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// one wave per frame, lane = class (k <= 64): a frame's logits are one coalesced 4*k-byte read; the four reductions
+// are wave butterflies.  (One THREAD per frame with strided rows took 31 us for 16000 frames; this takes ~4.)
+__global__ __launch_bounds__(256) void softmax_logq_kernel(const float* __restrict__ logits, float* __restrict__ probs,
+                                                           float* __restrict__ logq, long frames, int t_out, int k,
+                                                           int logit_stride, long logit_batch_stride, float eps) {
+    const long f = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (f >= frames) return;
+    const int lane = threadIdx.x & 63;
     const long b = f / t_out;
-    const float* z = logits + b * logit_batch_stride + (f - b * t_out) * logit_stride;
-    float m = -INFINITY;
-    for (int i = 0; i < k; ++i) m = fmaxf(m, z[i]);
-    float sum = 0.f;
-    for (int i = 0; i < k; ++i) sum += expf(z[i] - m);
-    float* p = probs + f * k;
-    float* lq = logq + f * k;
+    const bool on = lane < k;
+    const float z = on ? logits[b * logit_batch_stride + (f - b * t_out) * logit_stride + lane] : -INFINITY;
+    const float m = wave_max(z);
+    const float e = on ? expf(z - m) : 0.f;
+    const float sum = wave_sum(e);
+    const float pi = e / sum;
     // q = (p + eps) / sum_j (p_j + eps); computed the way TF does: log-softmax of u = log(p + eps)
-    float um = -INFINITY;
-    for (int i = 0; i < k; ++i) {
-        const float pi = expf(z[i] - m) / sum;
-        p[i] = pi;
-        const float u = logf(pi + eps);
-        lq[i] = u;
-        um = fmaxf(um, u);
-    }
-    float usum = 0.f;
-    for (int i = 0; i < k; ++i) usum += expf(lq[i] - um);
+    const float u = on ? logf(pi + eps) : -INFINITY;
+    const float um = wave_max(u);
+    const float usum = wave_sum(on ? expf(u - um) : 0.f);
     const float lz = um + logf(usum);
-    for (int i = 0; i < k; ++i) lq[i] -= lz;
+    if (on) {
+        probs[f * k + lane] = pi;
+        logq[f * k + lane] = u - lz;
+    }
 }
 
 // workspace layout: alpha [B][T][SP], beta [B][T][SP]  (SP = S rounded up to 64)
@@ -68,13 +77,43 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
                                                            const int32_t* __restrict__ label_len,
                                                            const int32_t* __restrict__ input_len,
                                                            float* __restrict__ alpha, float* __restrict__ beta,
-                                                           float* __restrict__ loss, int t_out, int k, int l_max,
-                                                           int sp, int blank) {
-    extern __shared__ float rowbuf[];  // 2 x (blockDim + 4)
+                                                           float* __restrict__ loss, int32_t* __restrict__ cls,
+                                                           int t_out, int k, int l_max, int sp, int blank) {
+    extern __shared__ float rowbuf[];  // 2 x (blockDim + 4)   (list builder: l_max + k + 1 ints)
     const int b = blockIdx.x;
     const int dir = blockIdx.y;
     const int s = threadIdx.x;
     const int L = label_len[b];
+    if (dir == 2) {
+        // Third role, off the recursion's critical path: per-class position lists of this utterance's label for
+        // ctc_grad_kernel (counting sort; inside a class the positions stay in label order, which fixes the summation
+        // order of the per-class occupancies -> deterministic).  cls[b] = pos[l_max] | start[k + 1].
+        int* s_lab = (int*)rowbuf;
+        int* s_start = s_lab + l_max;
+        int32_t* pos_out = cls + (long)b * (l_max + k + 1);
+        int32_t* start_out = pos_out + l_max;
+        for (int i = s; i < L; i += blockDim.x) s_lab[i] = labels[(long)b * l_max + i];
+        for (int i = s; i <= k; i += blockDim.x) s_start[i] = 0;
+        __syncthreads();
+        // rank of position i inside its class = number of earlier positions with the same grapheme
+        int ranks[16];  // blockDim >= 64, l_max <= 511 -> at most 8 positions per thread
+        int nmine = 0;
+        for (int i = s; i < L; i += blockDim.x) {
+            const int c = s_lab[i];
+            int r = 0;
+            for (int j = 0; j < i; ++j) r += (s_lab[j] == c);
+            ranks[nmine++] = r;
+            atomicAdd(&s_start[c + 1], 1);  // integer count: order-independent
+        }
+        __syncthreads();
+        if (s == 0)
+            for (int c = 0; c < k; ++c) s_start[c + 1] += s_start[c];
+        __syncthreads();
+        nmine = 0;
+        for (int i = s; i < L; i += blockDim.x) pos_out[s_start[s_lab[i]] + ranks[nmine++]] = i;
+        for (int i = s; i <= k; i += blockDim.x) start_out[i] = s_start[i];
+        return;
+    }
     const int S = 2 * L + 1;
     int T = input_len[b];
     if (T > t_out) T = t_out;
@@ -176,22 +215,25 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
     }
 }
 
-// one wave per frame; block = 256 threads = 4 frames per iteration
+// one wave per frame; work-group = 4 waves x FRAMES_PER_WAVE frames.  NJ = SP / 64 lattice columns per lane: all of a
+// frame's alpha / beta loads are issued before the first one is used (one HBM/L2 round trip per frame instead of NJ).
+template <int NJ>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ probs, const float* __restrict__ logq,
                                                        const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ label_len,
                                                        const int32_t* __restrict__ input_len,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                       const float* __restrict__ loss, void* __restrict__ dlogits,
-                                                       int t_out, int k, int l_max, int sp, int blank, int frames_per_wg,
-                                                       int g_row0, int g_rs, long g_bs, int out_f32, float eps,
-                                                       float grad_scale) {
-    // LDS: labels[l_max] | class_start[k+1] | class_pos[l_max] | gamma[4][l_max]
+                                                       const float* __restrict__ loss, const int32_t* __restrict__ cls,
+                                                       void* __restrict__ dlogits, int t_out, int k, int l_max, int sp,
+                                                       int blank, int frames_per_wg, int g_row0, int g_rs, long g_bs,
+                                                       int out_f32, float eps, float grad_scale) {
+    // LDS: labels[l_max] | class_pos[l_max] | class_start[k+1] | lq[4][64] | gamma[4][l_max]
     extern __shared__ int lds_i[];
     int* s_lab = lds_i;
-    int* s_start = s_lab + l_max;
-    int* s_pos = s_start + (k + 1);
-    float* s_gam = (float*)(s_pos + l_max);
+    int* s_pos = s_lab + l_max;
+    int* s_start = s_pos + l_max;
+    float* s_lq = (float*)(s_start + (k + 1));
+    float* s_gam = s_lq + 4 * 64;
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -201,42 +243,19 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     int T = input_len[b];
     if (T > t_out) T = t_out;
     const int32_t* lab = labels + (long)b * l_max;
-    for (int i = tid; i < L; i += 256) s_lab[i] = lab[i];
-    __syncthreads();
-    // per-class position lists in label order (counting sort; the order inside a class is the label order, so the
-    // per-class sums below are deterministic).  One thread per label position: its rank inside its class is the number
-    // of earlier positions with the same grapheme (every lane reads the same LDS word per iteration -> broadcast),
-    // instead of 29 threads scanning the label twice.
-    if (tid <= k) s_start[tid] = 0;
-    __syncthreads();
-    int my_rank[2] = {0, 0};  // positions tid and tid + 256 (l_max <= 511)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int i = tid + h * 256;
-        if (i < L) {
-            const int c = s_lab[i];
-            int r = 0;
-            for (int j = 0; j < i; ++j) r += (s_lab[j] == c);
-            my_rank[h] = r;
-            atomicAdd(&s_start[c + 1], 1);  // integer count: order-independent
-        }
+    const int32_t* cpos = cls + (long)b * (l_max + k + 1);
+    for (int i = tid; i < L; i += 256) {
+        s_lab[i] = lab[i];
+        s_pos[i] = cpos[i];
     }
-    __syncthreads();
-    if (tid == 0) {
-        for (int c = 0; c < k; ++c) s_start[c + 1] += s_start[c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int i = tid + h * 256;
-        if (i < L) s_pos[s_start[s_lab[i]] + my_rank[h]] = i;
-    }
+    if (tid <= k) s_start[tid] = cpos[l_max + tid];
     __syncthreads();
 
     const float nll = loss[b];
     const bool feasible = nll < INFINITY;
     const float log_p = -nll * LOG2E;  // lattice units are log2
     float* gam = s_gam + wave * l_max;
+    float* wlq = s_lq + wave * 64;
     const int t_begin = blockIdx.x * frames_per_wg;
     for (int tt = wave; tt < frames_per_wg; tt += 4) {
         const int t = t_begin + tt;
@@ -244,28 +263,42 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         const long fidx = (long)b * t_out + t;
         float dz = 0.f;
         if (t < T) {
-            const float* lq = logq + fidx * k;
-            const float* pr = probs + fidx * k;
+            const float lqv = lane < k ? logq[fidx * k + lane] : 0.f;
+            const float pk = lane < k ? probs[fidx * k + lane] : 0.f;
             float occ = 0.f;
             if (feasible) {
                 const float* al = alpha + fidx * sp;
                 const float* be = beta + fidx * sp;
-                const float lq_blank = lq[blank] * LOG2E;
+                float av[NJ], bv[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {  // rows are sp (a multiple of 64) wide: a wave-uniform bound
+                    const bool in = 64 * j < sp;
+                    av[j] = in ? al[lane + 64 * j] : -INFINITY;
+                    bv[j] = in ? be[lane + 64 * j] : -INFINITY;
+                }
+                wlq[lane] = lqv * LOG2E;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const float lq_blank = wlq[blank];
                 // blank states (even s) -> butterfly sum; grapheme states (odd s) -> gamma[] in LDS
                 float blank_part = 0.f;
-                for (int s = lane; s < S; s += 64) {
-                    const float ab = al[s] + be[s];
-                    if (s & 1) {
-                        const int pos = s >> 1;
-                        const float lg = ab - lq[s_lab[pos]] * LOG2E - log_p;
-                        gam[pos] = (ab == -INFINITY) ? 0.f : exp2f(lg);
-                    } else {
-                        const float lg = ab - lq_blank - log_p;
-                        blank_part += (ab == -INFINITY) ? 0.f : exp2f(lg);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int s = lane + 64 * j;
+                    if (s < S) {
+                        const float ab = av[j] + bv[j];
+                        if (s & 1) {
+                            const int pos = s >> 1;
+                            const float lg = ab - wlq[s_lab[pos]] - log_p;
+                            gam[pos] = (ab == -INFINITY) ? 0.f : exp2f(lg);
+                        } else {
+                            const float lg = ab - lq_blank - log_p;
+                            blank_part += (ab == -INFINITY) ? 0.f : exp2f(lg);
+                        }
                     }
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) blank_part += __shfl_xor(blank_part, off);
+                blank_part = wave_sum(blank_part);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -281,15 +314,9 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                 __builtin_amdgcn_wave_barrier();
             }
             // du_k = q_k - occ_k ; dp_k = du_k / (p_k + eps) ; dz_k = p_k * (dp_k - sum_j p_j dp_j)
-            float pk = 0.f, dp = 0.f;
-            if (lane < k) {
-                pk = pr[lane];
-                const float qk = expf(lq[lane]);
-                dp = (qk - occ) / (pk + eps);
-            }
-            float inner = pk * dp;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) inner += __shfl_xor(inner, off);
+            float dp = 0.f;
+            if (lane < k) dp = (expf(lqv) - occ) / (pk + eps);
+            const float inner = wave_sum(pk * dp);
             dz = pk * (dp - inner) * grad_scale;
         }
         if (lane < k) {
@@ -372,14 +399,16 @@ extern "C" int sl_softmax_logq(const float* logits, float* probs, float* logq, i
                                int logit_stride, int64_t logit_batch_stride, float eps, void* stream) {
     SL_CHECK_ARG(batch > 0 && t_out > 0 && k > 0 && logit_stride >= k, "sl_softmax_logq: bad sizes");
     const long frames = (long)batch * t_out;
-    hipLaunchKernelGGL(softmax_logq_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    SL_CHECK_ARG(k <= 64, "sl_softmax_logq: at most 64 classes (one lane per class)");
+    hipLaunchKernelGGL(softmax_logq_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        logits, probs, logq, frames, t_out, k, logit_stride, (long)logit_batch_stride, eps);
     return sl_check_launch("sl_softmax_logq");
 }
 
 extern "C" size_t sl_ctc_workspace_bytes(int batch, int t_out, int l_max) {
     if (batch <= 0 || t_out <= 0 || l_max < 0) return 0;
-    return (size_t)2 * batch * t_out * lattice_sp(l_max) * sizeof(float);
+    // alpha + beta lattices, then per utterance the class position lists: pos[l_max] | start[k + 1], k <= 64
+    return (size_t)2 * batch * t_out * lattice_sp(l_max) * sizeof(float) + (size_t)batch * (l_max + 65) * sizeof(int32_t);
 }
 
 extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* labels, const int32_t* label_len,
@@ -400,18 +429,30 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
     hipStream_t s = (hipStream_t)stream;
     float* alpha = (float*)workspace;
     float* beta = alpha + (size_t)batch * t_out * sp;
+    int32_t* cls = (int32_t*)(beta + (size_t)batch * t_out * sp);
     const int threads = sp;  // multiple of 64, >= S
-    const size_t lds = 2 * (threads + 4) * sizeof(float);
-    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(batch, 2), dim3(threads), lds, s, logq, labels, label_len, input_len,
-                       alpha, beta, loss, t_out, k, l_max, sp, k - 1);
+    size_t lds = 2 * (threads + 4) * sizeof(float);
+    const size_t lds_lists = (size_t)(l_max + k + 1) * sizeof(int);
+    if (lds < lds_lists) lds = lds_lists;
+    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(batch, 3), dim3(threads), lds, s, logq, labels, label_len, input_len,
+                       alpha, beta, loss, cls, t_out, k, l_max, sp, k - 1);
     int rc = sl_check_launch("sl_ctc_loss_grad(lattice)");
     if (rc != SL_OK) return rc;
-    const int frames_per_wg = 32;
-    const size_t lds2 = (size_t)(l_max + (k + 1) + l_max) * sizeof(int) + (size_t)4 * l_max * sizeof(float);
-    hipLaunchKernelGGL(ctc_grad_kernel, dim3((t_out + frames_per_wg - 1) / frames_per_wg, batch), dim3(256), lds2, s,
-                       probs, logq, labels, label_len, input_len, alpha, beta, loss, dlogits, t_out, k, l_max, sp,
-                       k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, dtype == SL_F32 ? 1 : 0, eps,
-                       grad_scale);
+    const int frames_per_wg = 8;  // two frames per wave: 16000 frames -> 8000 waves in flight
+    const size_t lds2 = (size_t)(2 * l_max + (k + 1)) * sizeof(int) + (size_t)(4 * 64 + 4 * l_max) * sizeof(float);
+    const dim3 grid((t_out + frames_per_wg - 1) / frames_per_wg, batch);
+#define SL_CTC_GRAD(NJ_)                                                                                              \
+    hipLaunchKernelGGL(ctc_grad_kernel<NJ_>, grid, dim3(256), lds2, s, probs, logq, labels, label_len, input_len, alpha, \
+                       beta, loss, cls, dlogits, t_out, k, l_max, sp, k - 1, frames_per_wg, g_row0, g_row_stride,     \
+                       (long)g_batch_stride, dtype == SL_F32 ? 1 : 0, eps, grad_scale)
+    if (sp <= 256) {
+        SL_CTC_GRAD(4);
+    } else if (sp <= 512) {
+        SL_CTC_GRAD(8);
+    } else {
+        SL_CTC_GRAD(16);
+    }
+#undef SL_CTC_GRAD
     return sl_check_launch("sl_ctc_loss_grad(grad)");
 }
 
