@@ -15,6 +15,8 @@
  *   rows     = halo_top + padded_time + halo_bottom   (halo rows and rows >= valid time are ZERO, always)
  *   channels = channel count padded to a multiple of 128 (padded lanes are ZERO, always)
  * so a SAME-padded conv tap is a plain row-shifted view and no kernel needs bounds checks on reads.
+ * padded_time must be a multiple of SL_TIME_TILE (256): the conv kernels read whole time tiles of up to 256 rows, i.e.
+ * rows x_row0 .. x_row0 + ceil(t_out / 256) * 256 + taps - 2 of every utterance must lie inside its `rows`.
  */
 #ifndef SPEECHLESS_HIP_H
 #define SPEECHLESS_HIP_H
@@ -27,6 +29,7 @@ extern "C" {
 #endif
 
 #define SL_VERSION 1
+#define SL_TIME_TILE 256
 
 typedef enum sl_status {
     SL_OK = 0,

@@ -936,7 +936,7 @@ bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
                 (c.it == 4 && c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
                 (c.it == 4 && c.wm == 4 && c.wn == 4 && c.stages == 2) ||
                 (c.it == 8 && c.wm == 2 && c.wn == 4 && c.stages == 2) ||  // 256x256 tile, 8 waves of 128x64
-                (c.it == 8 && c.wm == 2 && c.wn == 2 && (c.stages == 2 || c.stages == 3));  // 256x128
+                (c.it == 8 && c.wm == 2 && c.wn == 2 && (full.stages == 10 || full.stages == 11));  // 256x128, pipelined only
     if (!shape || c.ksplit < 1) return false;
     if (g->cout % (64 * c.wn)) return false;
     const long nsteps = (long)g->taps * (g->cin / BK);

@@ -20,7 +20,7 @@ from . import _lib
 from ._lib import ConvGeom, lib
 
 HALO = 16
-TIME_TILE = 128
+TIME_TILE = 256  # SL_TIME_TILE: the conv kernels read whole time tiles of up to 256 rows
 
 
 def _round_up(x, m):

@@ -615,3 +615,140 @@ def test_power_spectrogram_shape_with_ragged_lengths(dtype):
         np.testing.assert_allclose(losses, ref["losses"], rtol=2e-3)
         for name, i in (("output_conv", 10), ("big_conv_2", 9), ("big_conv_1", 8)):
             assert rel_l2(grads[i][0], ref["grads"][i][0]) < 3e-2, name
+
+
+# ------------------------------------------------------------------------------------------ every NT tile configuration
+def _nt_cfg(wm, wn, stages, ksplit=1, it=4, m32=0, gm_log2p1=0, slab=0):
+    """cfg word of sl_conv1d_nt (see conv_nt_bf16.hip:decode_cfg)."""
+    return wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20) | (m32 << 24) | (gm_log2p1 << 25) | (slab << 29)
+
+
+NT_CONFIGS = (
+    # plain ring
+    [(wm, wn, st, 1, it, 0, 0, 0) for (wm, wn, st, it) in
+     [(2, 2, 2, 4), (2, 2, 4, 4), (4, 2, 3, 4), (2, 4, 2, 4), (4, 4, 2, 4), (2, 2, 3, 2), (4, 2, 4, 2), (8, 2, 2, 2),
+      (2, 4, 2, 8)]] +
+    # register-pipelined ring (stages | 8)
+    [(wm, wn, st, 1, it, 0, 0, 0) for (wm, wn, st, it) in
+     [(2, 2, 10, 4), (2, 2, 12, 4), (4, 2, 11, 2), (4, 2, 12, 2), (4, 2, 10, 4), (2, 4, 11, 4), (2, 4, 10, 8), (2, 2, 10, 8), (2, 2, 11, 8)]] +
+    # 32x32x16 MFMA shape
+    [(2, 2, 3, 1, 4, 1, 0, 0), (4, 4, 2, 1, 4, 1, 0, 0)] +
+    # slab (chunk-major) variants, with and without split-K, and an explicit 2-D raster
+    [(4, 4, 2, 1, 4, 0, 0, 1), (2, 4, 10, 1, 8, 0, 0, 1), (4, 2, 11, 1, 2, 0, 0, 1), (4, 2, 3, 1, 2, 0, 0, 1),
+     (2, 2, 11, 1, 4, 0, 0, 1), (2, 2, 12, 1, 4, 0, 0, 1), (2, 4, 10, 2, 8, 0, 0, 1), (4, 2, 11, 4, 2, 0, 0, 1),
+     (2, 4, 10, 1, 8, 0, 2, 1), (4, 4, 2, 1, 4, 0, 1, 0), (4, 2, 11, 1, 2, 0, 3, 0)] +
+    # split-K of the tap-major kernels
+    [(4, 4, 2, 3, 4, 0, 0, 0), (4, 2, 11, 2, 2, 0, 0, 0)])
+
+
+@pytest.mark.parametrize("taps,t_out,batch", [(7, 300, 3), (32, 140, 2), (5, 129, 5)])
+def test_every_nt_tile_configuration_against_float64(hip_lib, taps, t_out, batch):
+    """sl_conv1d_nt with EVERY instantiated tile configuration (plain / register-pipelined / slab / 32x32 MFMA /
+    split-K / 2-D raster) on one geometry with bf16-exact operands, against a float64 evaluation of the same sum.
+    Odd batches make the launch grid a non-multiple of 8 (padded grid + XCD remap)."""
+    import ctypes
+    import torch
+    from speechless_amd import _lib
+    rng = np.random.RandomState(taps * 1000 + t_out)
+    cin, cout, halo = 256, 256, 48
+    rows = halo + ((t_out + 255) // 256) * 256 + halo
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    x = np.zeros((batch, rows, cin), dtype=np.float32)
+    x[:, halo:halo + t_out] = _bf16_exact(rng, (batch, t_out, cin))
+    w = _bf16_exact(rng, (taps, cin, cout), 0.05)
+    bias = _bf16_exact(rng, (cout,), 0.1)
+    pad_l = (taps - 1) // 2
+    xt = torch.tensor(x).to(torch.bfloat16).to(dev)
+    wm_t = torch.tensor(w).to(dev)
+    w_fwd = torch.zeros((cout, taps, cin), dtype=torch.bfloat16, device=dev)
+    hip_lib.call("sl_pack_weights", wm_t.data_ptr(), w_fwd.data_ptr(), None, taps, cin, cout, _lib.SL_BF16, st)
+    bias_t = torch.tensor(bias).to(dev)
+    geom = _lib.ConvGeom()
+    geom.batch, geom.t_out, geom.taps, geom.cin, geom.cout = batch, t_out, taps, cin, cout
+    geom.x_row0, geom.x_row_stride, geom.x_batch_stride = halo - pad_l, cin, rows * cin
+    geom.y_row0, geom.y_row_stride, geom.y_batch_stride = halo, cout, rows * cout
+    # float64 reference: y[b,t,co] = bias + sum_{tap,ci} x[b, t + tap - pad_l, ci] w[tap, ci, co]
+    xp = x.astype(np.float64)
+    want = np.zeros((batch, t_out, cout))
+    for tap in range(taps):
+        want += xp[:, halo - pad_l + tap: halo - pad_l + tap + t_out] @ w[tap].astype(np.float64)
+    want += bias
+    ran = 0
+    for (wm, wn, stg, ks, it, m32, gml, slab) in NT_CONFIGS:
+        cfg = _nt_cfg(wm, wn, stg, ks, it, m32, gml, slab)
+        need = hip_lib.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(geom), _lib.SL_BF16, cfg)
+        ws = torch.empty((max(int(need), 16),), dtype=torch.uint8, device=dev)
+        y = torch.full((batch, rows, cout), 7.0, dtype=torch.float32, device=dev)
+        rc = hip_lib.raw("sl_conv1d_nt")(xt.data_ptr(), w_fwd.data_ptr(), bias_t.data_ptr(), None, y.data_ptr(),
+                                         ctypes.byref(geom), _lib.EPI_BIAS, _lib.SL_BF16, 1, cfg, ws.data_ptr(),
+                                         ws.numel(), st)
+        if rc != 0:  # a configuration the geometry rules out (taps < ring depth, split-K > chunks): must say so cleanly
+            assert rc == -1 and "invalid tile configuration" in hip_lib.last_error(), (cfg, rc, hip_lib.last_error())
+            continue
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        err = rel_l2(got[:, halo:halo + t_out], want)
+        assert err < 2e-6, ("cfg", (wm, wn, stg, ks, it, m32, gml, slab), err)
+        assert (got[:, :halo] == 7.0).all() and (got[:, halo + t_out:] == 7.0).all(), "rows outside [0, t_out) written"
+        ran += 1
+    assert ran >= len(NT_CONFIGS) - 8
+
+
+WGRAD_CONFIGS = [(2, 2, 2), (2, 2, 3), (2, 2, 4), (4, 2, 2), (4, 2, 3), (2, 4, 2), (2, 4, 3), (4, 4, 2)]
+
+
+@pytest.mark.parametrize("taps,t_out,batch,groups", [(7, 200, 6, 1), (3, 130, 5, 3), (1, 64, 4, 1)])
+def test_every_wgrad_tile_configuration_against_float64(hip_lib, taps, t_out, batch, groups):
+    """sl_conv1d_wgrad / sl_conv1d_wgrad_grouped with every tile shape, ring depth and batch split (padded launch
+    grids included) on bf16-exact operands against a float64 evaluation of the same sum; each configuration is run
+    twice and must reproduce itself bit for bit (deterministic split reduction)."""
+    import ctypes
+    import torch
+    from speechless_amd import _lib
+    rng = np.random.RandomState(taps * 100 + batch)
+    cin, cout, halo = 256, 256, 16
+    rows = halo + ((t_out + 63) // 64) * 64 + halo
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    pad_l = (taps - 1) // 2
+    x = np.zeros((groups, batch, rows, cin), dtype=np.float32)
+    g = np.zeros((groups, batch, rows, cout), dtype=np.float32)
+    x[:, :, halo:halo + t_out] = _bf16_exact(rng, (groups, batch, t_out, cin))
+    g[:, :, halo:halo + t_out] = _bf16_exact(rng, (groups, batch, t_out, cout), 0.05)
+    xt = torch.tensor(x).to(torch.bfloat16).to(dev)
+    gt = torch.tensor(g).to(torch.bfloat16).to(dev)
+    geom = _lib.ConvGeom()
+    geom.batch, geom.t_out, geom.taps, geom.cin, geom.cout = batch, t_out, taps, cin, cout
+    geom.x_row0, geom.x_row_stride, geom.x_batch_stride = halo - pad_l, cin, rows * cin
+    geom.y_row0, geom.y_row_stride, geom.y_batch_stride = halo, cout, rows * cout
+    want = np.zeros((groups, taps, cin, cout))
+    for q in range(groups):
+        for tap in range(taps):
+            xs = x[q, :, halo - pad_l + tap: halo - pad_l + tap + t_out].astype(np.float64).reshape(-1, cin)
+            want[q, tap] = xs.T @ g[q, :, halo:halo + t_out].astype(np.float64).reshape(-1, cout)
+    dw_stride = taps * cin * cout + 64  # a gap between the groups' outputs, as in the engine (bias block)
+    for (wm, wn, stg) in WGRAD_CONFIGS:
+        for splits in (0, 1, 2, 3, batch):
+            cfg = wm | (wn << 4) | (stg << 8) | (splits << 12)
+            outs = []
+            for _ in range(2):
+                dw = torch.full((groups * dw_stride,), 3.0, dtype=torch.float32, device=dev)
+                if groups == 1:
+                    need = hip_lib.raw("sl_conv1d_wgrad_workspace_bytes")(ctypes.byref(geom), _lib.SL_BF16, cfg)
+                    ws = torch.empty((max(int(need), 16),), dtype=torch.uint8, device=dev)
+                    hip_lib.call("sl_conv1d_wgrad", xt.data_ptr(), gt.data_ptr(), dw.data_ptr(), ctypes.byref(geom),
+                                 _lib.SL_BF16, cfg, ws.data_ptr(), ws.numel(), st)
+                else:
+                    need = hip_lib.raw("sl_conv1d_wgrad_grouped_workspace_bytes")(ctypes.byref(geom), groups, cfg)
+                    ws = torch.empty((max(int(need), 16),), dtype=torch.uint8, device=dev)
+                    hip_lib.call("sl_conv1d_wgrad_grouped", xt.data_ptr(), gt.data_ptr(), dw.data_ptr(),
+                                 ctypes.byref(geom), groups, batch * rows * cin, batch * rows * cout, dw_stride, cfg,
+                                 ws.data_ptr(), ws.numel(), st)
+                torch.cuda.synchronize()
+                outs.append(dw.cpu().numpy().reshape(groups, dw_stride))
+            assert np.array_equal(outs[0], outs[1]), ("not deterministic", wm, wn, stg, splits)
+            got = outs[0][:, :taps * cin * cout].reshape(groups, taps, cin, cout)
+            err = rel_l2(got, want)
+            assert err < 2e-6, ("cfg", (wm, wn, stg, splits), err)
+            assert (outs[0][:, taps * cin * cout:] == 3.0).all(), "wrote past a group's weight block"
