@@ -530,7 +530,7 @@ class Engine:
             if self._packed_dirty:
                 self.repack_weights()
             self.adam_iterations += 1
-        dp = reducer is not None and reducer.world_size > 1
+        dp = reducer is not None and (reducer.world_size > 1 or reducer.force)
         bucket_layers = []  # data parallel: layers of the gradient bucket being completed
 
         def adam_after_this_layer(layers):

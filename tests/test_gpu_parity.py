@@ -752,3 +752,44 @@ def test_every_wgrad_tile_configuration_against_float64(hip_lib, taps, t_out, ba
             err = rel_l2(got, want)
             assert err < 2e-6, ("cfg", (wm, wn, stg, splits), err)
             assert (outs[0][:, taps * cin * cout:] == 3.0).all(), "wrote past a group's weight block"
+
+
+@pytest.mark.parametrize("early_adam", [False, True])
+def test_data_parallel_step_through_rccl_single_rank(early_adam):
+    """The data-parallel step (bucketed all-reduce on the communication stream, overlapped with backward, optionally
+    with Adam queued behind each bucket) on ONE rank through the real RCCL backend: a sum over a world of one is the
+    identity, so weights and losses must equal the plain step bit for bit.  (World size 2 runs on CPU/gloo in
+    tests/test_parallel.py; the 8-GPU run is the driver's.)"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from speechless_amd.parallel import GradBucketReducer
+    case = make_case(b=4, t=96, seed=5)
+    results = []
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        for use_reducer in (False, True):
+            eng = make_engine(case, "bf16")
+            eng.early_adam = early_adam
+            reducer = None
+            if use_reducer:
+                ranges, _ = eng.bucket_ranges()
+                reducer = GradBucketReducer(eng.grads, ranges, force=True)
+            losses = []
+            for _ in range(3):
+                loss = eng.train_step(case["x"], case["labels"], np.array(case["label_lengths"]),
+                                      np.array(case["prediction_lengths"]), reducer)
+                losses.append(loss.cpu().numpy().copy())
+            torch.cuda.synchronize()
+            results.append((np.stack(losses), [w.copy() for w, _ in eng.get_weights()]))
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert np.array_equal(results[0][0], results[1][0])
+    for a, b in zip(results[0][1], results[1][1]):
+        assert np.array_equal(a, b)
+    assert np.isfinite(results[0][0]).all() and (results[0][0][2] != results[0][0][0]).any()  # the weights did move
