@@ -189,6 +189,11 @@ def main():
                    "parallelism": "dp{}".format(world)},
         "final_mean_loss": final_loss,
         "step_mfma_frac": utt_per_s * fwdbwd_flops_per_utt / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world),
+        # the 1-D conv stack alone (north_star's 40 % target): algorithmic fwd+bwd FLOPs of this rank's batch over the
+        # summed live durations of its forward / dgrad / wgrad launches
+        "conv_stack_mfma_frac": (fwdbwd_flops_per_utt * BATCH_PER_GPU / 1e12) /
+                                ((groups["fwd"]["ms_per_step"] + groups["dgrad"]["ms_per_step"] +
+                                  groups["wgrad"]["ms_per_step"]) * 1e-3) / BF16_DENSE_PEAK_TFLOPS,
         "roofline": {"bound": "mfma", "kernel": "wgrad_tn_bf16_kernel<4,4,2> (weight gradient of big_conv_1, "
                                                 "big_conv_2 and the grouped inner_conv_1..7 launch; average over "
                                                 "its {} launches per step)".format(len(dom_tags)),
