@@ -93,3 +93,22 @@ def test_product_code_never_imports_the_oracle():
     for path in (ROOT / "speechless_amd").rglob("*.py"):
         text = path.read_text()
         assert "import oracle" not in text and "from oracle" not in text, path
+
+
+def test_batchnorm_folds_into_the_fused_conv_bias_relu_epilogue():
+    """relu(BN(conv(x, W) + b)) == relu(conv(x, W') + b') with the folded parameters (speechless_amd/fold.py)."""
+    from oracle import w2l_oracle as o
+    from speechless_amd.fold import fold_batchnorm_into_conv
+    rng = np.random.RandomState(3)
+    x = rng.randn(2, 40, 6)
+    w = rng.randn(5, 6, 9) * 0.2
+    b = rng.randn(9) * 0.1
+    gamma, beta = rng.uniform(0.5, 1.5, 9), rng.randn(9) * 0.1
+    mean, var, eps = rng.randn(9) * 0.3, rng.uniform(0.2, 2.0, 9), 1e-3
+    z = o.conv1d_preactivation(x, w, b, 1)
+    want = np.maximum(gamma * (z - mean) / np.sqrt(var + eps) + beta, 0)
+    w2, b2 = fold_batchnorm_into_conv(w, b, gamma, beta, mean, var, eps)
+    got = np.maximum(o.conv1d_preactivation(x, w2, b2, 1), 0)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    with pytest.raises(ValueError):
+        fold_batchnorm_into_conv(w, b, gamma[:3], beta, mean, var)
