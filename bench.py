@@ -10,6 +10,11 @@ Inputs, labels and lengths are resident in HBM when the timed region starts.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
 
+--config 2 / --config 5 run BASELINE.json's other GPU configurations with the same contract (they are not the headline
+line): 2 = forward + greedy decode only on the same batch; 5 = long-form 257-bin power spectrograms, 8 utterances per
+GPU, lengths U{2000..8000} frames in length-bucketed batches, full training step, reported with the achieved GB/s of
+its HBM-bound kernels next to the MFMA fraction.
+
 Rank 0 prints ONE JSON line (see the contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
 import argparse
@@ -44,6 +49,35 @@ def synthetic_batch(rank, batch):
     return x, labels, lab_len.astype(np.int32), np.full((batch,), FRAMES // 2, dtype=np.int32)
 
 
+LONG_BINS, LONG_BATCH, LONG_CORPUS = 257, 8, 64  # config 5: 257-bin power spectrograms, 8 utterances per GPU and step
+
+
+def long_form_batches(rank):
+    """Config 5 generator: per rank 64 utterances, T_i ~ U{2000..8000} frames (seed 3 + rank),
+    L_i <= min(200, T_i / 4), cut into length-bucketed batches of 8 (speechless_amd.batching.bucket_batches).
+    Returns [(x (8, Tmax, 257) float32 zero padded, labels, label_lengths, prediction_lengths, true_lengths)]."""
+    from speechless_amd.batching import bucket_batches, padding_waste
+    rng = np.random.RandomState(3 + rank)
+    lengths = rng.randint(2000, 8001, size=LONG_CORPUS)
+    corpus = list(range(LONG_CORPUS))
+    batches = bucket_batches(corpus, LONG_BATCH, length_of=lambda i: int(lengths[i]), shuffle=False)
+    out = []
+    for members in batches:
+        t_max = max(int(lengths[i]) for i in members)
+        x = np.zeros((len(members), t_max, LONG_BINS), dtype=np.float32)
+        lab_len = np.zeros(len(members), dtype=np.int32)
+        for j, i in enumerate(members):
+            x[j, :lengths[i]] = np.random.RandomState(5000 + 100 * rank + i).randn(int(lengths[i]), LONG_BINS)
+            lab_len[j] = rng.randint(20, min(200, int(lengths[i]) // 4) + 1)
+        labels = -np.ones((len(members), int(lab_len.max())), dtype=np.int32)
+        for j, n in enumerate(lab_len):
+            labels[j, :n] = rng.randint(0, K_CLASSES - 1, size=n)
+        true_len = np.array([int(lengths[i]) for i in members], dtype=np.int32)
+        out.append((x, labels, lab_len, (true_len // 2).astype(np.int32), true_len))
+    waste = padding_waste([[int(lengths[i]) for i in members] for members in batches], length_of=lambda n: n)
+    return out, waste
+
+
 def cpu_baseline(specs_oracle, weights, sample_utts=4, steps=2):
     """The torch-CPU fp32 port of the same step (oracle/w2l_torch_cpu.py) timed on this node's host cores."""
     import torch
@@ -62,14 +96,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 5),
+                    help="BASELINE.json configuration: 3 = headline training step (default), 2 = forward + greedy "
+                         "decode only, 5 = long-form 257-bin x 2000..8000-frame bucketed batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra event-instrumented steps for the roofline leg")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from oracle import w2l_oracle as o
     from speechless_amd.engine import Engine, wav2letter_layer_specs
+    from speechless_amd.net import Wav2Letter
     from speechless_amd.parallel import GradBucketReducer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,18 +122,51 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
-    specs = wav2letter_layer_specs(MEL, K_CLASSES)
-    ospecs = o.layer_specs(MEL, K_CLASSES)
-    weights = o.glorot_uniform_weights(ospecs, seed=2, dtype=np.float32)  # same init on every rank
+    bins = LONG_BINS if args.config == 5 else MEL
+    specs = wav2letter_layer_specs(bins, K_CLASSES)
+    weights = Wav2Letter._glorot_uniform(specs, 2)  # Keras default init, same on every rank
     eng = Engine(specs, K_CLASSES, dtype="bf16", device=device)
     eng.set_weights(weights)
-    x, labels, lab_len, pred_len = synthetic_batch(rank, BATCH_PER_GPU)
-    eng.load_input(torch.from_numpy(x).to(device))
-    eng.set_labels(labels, lab_len, pred_len)
     reducer = None
-    if world > 1:
+    if world > 1 and args.config != 2:
         ranges, _ = eng.bucket_ranges()
         reducer = GradBucketReducer(eng.grads, ranges)
+
+    # ---- the step of this configuration (inputs, labels and lengths resident in HBM before the timed region)
+    waste = 0.0
+    if args.config == 5:
+        eng.max_cached_shapes = 16
+        host_batches, waste = long_form_batches(rank)
+        resident = [(torch.from_numpy(x).to(device), lab, ll, pl, tl) for (x, lab, ll, pl, tl) in host_batches]
+        batch_per_gpu = LONG_BATCH
+        cursor = [0]
+
+        def step():
+            x_dev, lab, ll, pl, _ = resident[cursor[0] % len(resident)]
+            cursor[0] += 1
+            eng.load_input(x_dev)  # fp32 -> bf16 halo'd layout on the GPU (sl_pack_input), part of the step
+            eng.set_labels(lab, ll, pl)
+            return eng.train_step_resident(reducer)
+        frames_per_step = float(np.mean([tl.sum() for (_, _, _, _, tl) in host_batches]))
+        flops_per_step = float(np.mean([sum(3 * sum(layer_flops_per_utt(specs, -(-int(t) // 2))) -
+                                            layer_flops_per_utt(specs, -(-int(t) // 2))[0] for t in tl)
+                                        for (_, _, _, _, tl) in host_batches]))
+    else:
+        x, labels, lab_len, pred_len = synthetic_batch(rank, BATCH_PER_GPU)
+        eng.load_input(torch.from_numpy(x).to(device))
+        eng.set_labels(labels, lab_len, pred_len)
+        batch_per_gpu = BATCH_PER_GPU
+        fl = layer_flops_per_utt(specs, FRAMES // 2)
+        if args.config == 3:
+            def step():
+                return eng.train_step_resident(reducer)
+            flops_per_step = (3 * sum(fl) - fl[0]) * BATCH_PER_GPU
+        else:
+            def step():
+                eng.forward()
+                return eng.greedy_decode()
+            flops_per_step = sum(fl) * BATCH_PER_GPU
+        frames_per_step = float(BATCH_PER_GPU * FRAMES)
 
     def sync():
         torch.cuda.synchronize()
@@ -105,73 +175,66 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        loss = eng.train_step_resident(reducer)
+        out = step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = eng.train_step_resident(reducer)
+        out = step()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss.mean().item())
+    final_loss = float(out.mean().item()) if args.config != 2 else None
 
     # ---- roofline leg: a few more steps with HIP events around every launch (same stream as the kernels)
-    t_out = FRAMES // 2
-    fl = layer_flops_per_utt(specs, t_out)
     def timeline_pass():
         eng.timeline = []
-        for _ in range(args.profile_steps):
-            eng.train_step_resident(reducer)
+        n_steps = args.profile_steps if args.config != 5 else len(resident)
+        for _ in range(n_steps):
+            step()
         torch.cuda.synchronize()
         per_tag = {}
         for tag, start, stop in eng.timeline:
             per_tag.setdefault(tag, []).append(start.elapsed_time(stop))
         eng.timeline = None
-        return {tag: float(np.mean(v)) for tag, v in per_tag.items()}
+        return {tag: float(np.sum(v)) / n_steps for tag, v in per_tag.items()}  # ms per step and tag
 
     live_ms = timeline_pass()  # same conditions as the timed region (bias gradients overlapped on the side stream)
     names = [s.name for s in specs]
-    # Dominant kernel (largest share of GPU time in profiles/r01f_kernel_stats.csv): wgrad_tn_bf16_kernel<4,4,2>, the
-    # 256x256-tile weight-gradient kernel.  THREE launches per step use this instantiation (the library's measured table
-    # picks it for big_conv_1, big_conv_2 and for the grouped launch that covers the seven inner_conv_i);
-    # algorithmic FLOPs per launch = (sum of those nine layers' wgrad FLOPs) / 3.
-    dom_tags = [t for t in live_ms if t.startswith("wgrad:") and t not in ("wgrad:output_conv", "wgrad:striding_conv")]
-    dom_layer_flops = sum(fl[i] for i, n in enumerate(names) if n not in ("output_conv", "striding_conv"))
-    dom_flops = dom_layer_flops * BATCH_PER_GPU / len(dom_tags)
-    dom_ms = sum(live_ms[t] for t in dom_tags) / len(dom_tags)
-    achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-    avg_ms = live_ms
-    traffic = None
-    pmc = ROOT / "profiles" / "r01g_pmc_traffic_wgrad442.json"
-    if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 read correction)
-        traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
-    # second kernel by time: the 256x256 forward/dgrad NT kernel (fwd of big_conv_1 and big_conv_2)
-    nt_flops = fl[names.index("big_conv_1")] * BATCH_PER_GPU
-    nt_ms = live_ms["fwd:big_conv_1"]
     groups = {}
-    for prefix, flops_of in (("fwd", lambda i: fl[i]), ("dgrad", lambda i: fl[i]), ("wgrad", lambda i: fl[i])):
-        tags = [(i, prefix + ":" + n) for i, n in enumerate(names) if prefix + ":" + n in avg_ms]
-        ms = sum(avg_ms[t] for _, t in tags)
-        groups[prefix] = {"ms_per_step": ms, "tflops": sum(flops_of(i) for i, _ in tags) * BATCH_PER_GPU / (ms * 1e-3) / 1e12}
-    for other in ("ctc", "softmax"):
-        groups[other] = {"ms_per_step": avg_ms.get(other, 0.0)}
-    groups["adam_and_repack"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("adam"))}
-    groups["bias_grad"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("bgrad:"))}
-    groups["pack_weights"] = {"ms_per_step": sum(v for t, v in avg_ms.items() if t.startswith("pack:"))}
-    groups["big_conv_1"] = {k: avg_ms.get(k + ":big_conv_1") for k in ("fwd", "dgrad", "wgrad")}
-    groups["per_launch_ms"] = {t: round(v, 4) for t, v in sorted(avg_ms.items())}
+    for prefix in ("fwd", "dgrad", "wgrad"):
+        ms = sum(v for t, v in live_ms.items() if t.startswith(prefix + ":"))
+        if ms:
+            groups[prefix] = {"ms_per_step": ms}
+    for other in ("ctc", "softmax", "decode"):
+        if other in live_ms:
+            groups[other] = {"ms_per_step": live_ms[other]}
+    groups["adam_and_repack"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("adam"))}
+    groups["bias_grad"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("bgrad:"))}
+    groups["per_launch_ms"] = {t: round(v, 4) for t, v in sorted(live_ms.items())}
+    conv_ms = sum(groups[g]["ms_per_step"] for g in ("fwd", "dgrad", "wgrad") if g in groups)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    utt_per_s = BATCH_PER_GPU * world * args.steps / elapsed
-    fwdbwd_flops_per_utt = 3 * sum(fl) - fl[0]
+    utt_per_s = batch_per_gpu * world * args.steps / elapsed
+    step_tflops = flops_per_step * world * args.steps / elapsed / 1e12
+    workloads = {
+        3: "BASELINE config 3: Wav2Letter fwd+CTC+bwd+Adam step, random-init, 128-mel x 1000 frames, 32 "
+           "utterances/GPU, labels U{20..200}, bf16 storage / fp32 accumulate / fp32 CTC",
+        2: "BASELINE config 2: Wav2Letter forward + greedy CTC decode only, random-init, 128-mel x 1000 frames, 32 "
+           "utterances/GPU, bf16 storage / fp32 accumulate",
+        5: "BASELINE config 5: long-form fwd+CTC+bwd+Adam step, 257-bin power spectrograms, 8 utterances/GPU per step, "
+           "T ~ U{2000..8000} frames in length-bucketed batches (64 utterances per GPU cycled), bf16 / fp32 CTC",
+    }
+    metrics = {3: "utterances/sec (fwd+bwd+CTC), 128-mel x 1000-frame batch",
+               2: "utterances/sec (fwd-only + greedy decode), 128-mel x 1000-frame batch",
+               5: "utterances/sec (fwd+bwd+CTC), 257-bin x 2000..8000-frame bucketed batches"}
     result = {
-        "metric": "utterances/sec (fwd+bwd+CTC), 128-mel x 1000-frame batch",
+        "metric": metrics[args.config],
         "value": utt_per_s,
         "unit": "utterances/sec",
         "n_gpus": world,
@@ -183,39 +246,82 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": "BASELINE config 3: Wav2Letter fwd+CTC+bwd+Adam step, random-init, 128-mel x 1000 "
-                               "frames, 32 utterances/GPU, labels U{20..200}, bf16 storage / fp32 accumulate / fp32 CTC",
-                   "global_batch": BATCH_PER_GPU * world, "frames": FRAMES, "mel": MEL,
+        "config": {"workload": workloads[args.config], "global_batch": batch_per_gpu * world,
+                   "frames": FRAMES if args.config != 5 else "2000..8000", "mel": bins,
                    "parallelism": "dp{}".format(world)},
         "final_mean_loss": final_loss,
-        "step_mfma_frac": utt_per_s * fwdbwd_flops_per_utt / 1e12 / (BF16_DENSE_PEAK_TFLOPS * world),
-        # the 1-D conv stack alone (north_star's 40 % target): algorithmic fwd+bwd FLOPs of this rank's batch over the
-        # summed live durations of its forward / dgrad / wgrad launches
-        "conv_stack_mfma_frac": (fwdbwd_flops_per_utt * BATCH_PER_GPU / 1e12) /
-                                ((groups["fwd"]["ms_per_step"] + groups["dgrad"]["ms_per_step"] +
-                                  groups["wgrad"]["ms_per_step"]) * 1e-3) / BF16_DENSE_PEAK_TFLOPS,
-        "roofline": {"bound": "mfma", "kernel": "wgrad_tn_bf16_kernel<4,4,2> (weight gradient of big_conv_1, "
-                                                "big_conv_2 and the grouped inner_conv_1..7 launch; average over "
-                                                "its {} launches per step)".format(len(dom_tags)),
-                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits "
-                                     "included), average of its three launches per step, "
-                                     "profiles/r01g_pmc_traffic_wgrad442.json (tools/pmc_traffic.sh)",
-                     "duration_note": "HIP events around the sl_conv1d_wgrad call on its stream: the kernel plus, for "
-                                      "batch-split launches, the deterministic wgrad_reduce_grouped_kernel tail "
-                                      "(rocprofv3: 196.6 us kernel + 17 us reduce per launch in "
-                                      "profiles/r01g_kernel_stats.csv)",
-                     "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms},
-        "roofline_nt_256x256": {"bound": "mfma", "kernel": "conv_nt_slab_bf16_kernel<IT=8,WM=2,WN=4,STAGES=2|pipelined,"
-                                                           "BIAS_RELU,bf16> (forward of big_conv_1)",
-                                "achieved": nt_flops / (nt_ms * 1e-3) / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": nt_flops / (nt_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
-                                "flops_per_launch": nt_flops, "avg_launch_ms": nt_ms},
+        "frames_per_sec": frames_per_step * world * args.steps / elapsed,
+        "step_mfma_frac": step_tflops / (BF16_DENSE_PEAK_TFLOPS * world),
+        # the 1-D conv stack alone (north_star's 40 % target): algorithmic FLOPs of this rank's step over the summed
+        # live durations of its forward / dgrad / wgrad launches
+        "conv_stack_mfma_frac": (flops_per_step / 1e12) / (conv_ms * 1e-3) / BF16_DENSE_PEAK_TFLOPS,
         "kernels": groups,
     }
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(ospecs, weights)
+    if args.config == 3:
+        # Dominant kernel (largest share of GPU time in profiles/r01g_kernel_stats.csv): wgrad_tn_bf16_kernel<4,4,2>,
+        # the 256x256-tile weight-gradient kernel.  THREE launches per step use this instantiation (the library's
+        # measured table picks it for big_conv_1, big_conv_2 and for the grouped launch that covers the seven
+        # inner_conv_i); algorithmic FLOPs per launch = (sum of those nine layers' wgrad FLOPs) / 3.
+        dom_tags = [t for t in live_ms if t.startswith("wgrad:") and
+                    t not in ("wgrad:output_conv", "wgrad:striding_conv")]
+        dom_flops = sum(fl[i] for i, n in enumerate(names) if n not in ("output_conv", "striding_conv")) * \
+            BATCH_PER_GPU / len(dom_tags)
+        dom_ms = sum(live_ms[t] for t in dom_tags) / len(dom_tags)
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = ROOT / "profiles" / "r01g_pmc_traffic_wgrad442.json"
+        if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 correction)
+            traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "wgrad_tn_bf16_kernel<4,4,2> (weight gradient of big_conv_1, big_conv_2 and the "
+                                       "grouped inner_conv_1..7 launch; average over its {} launches per "
+                                       "step)".format(len(dom_tags)),
+            "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits included), "
+                            "average of its three launches per step, profiles/r01g_pmc_traffic_wgrad442.json "
+                            "(tools/pmc_traffic.sh)",
+            "duration_note": "HIP events around the sl_conv1d_wgrad call on its stream: the kernel plus, for "
+                             "batch-split launches, the deterministic wgrad_reduce_grouped_kernel tail (rocprofv3: "
+                             "196.6 us kernel + 17 us reduce per launch in profiles/r01g_kernel_stats.csv)",
+            "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms}
+    if args.config in (2, 3):
+        nt_flops = fl[names.index("big_conv_1")] * BATCH_PER_GPU
+        nt_ms = live_ms["fwd:big_conv_1"]
+        nt = {"bound": "mfma", "kernel": "conv_nt_slab_bf16_kernel<IT=8,WM=2,WN=4,STAGES=2|pipelined,BIAS_RELU,bf16> "
+                                         "(forward of big_conv_1)",
+              "achieved": nt_flops / (nt_ms * 1e-3) / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "frac": nt_flops / (nt_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+              "flops_per_launch": nt_flops, "avg_launch_ms": nt_ms}
+        result["roofline_nt_256x256" if args.config == 3 else "roofline"] = nt
+    if args.config == 5:
+        # HBM-bound kernels of the step: output_conv (AI 29 flop/B) in all three passes, softmax,
+        # CTC, bias gradients, Adam.  Algorithmic bytes: every operand / result of those kernels moved once.
+        t_sum = frames_per_step / 2.0  # output frames per step (all utterances of a batch)
+        t_pad = float(np.mean([len(tl) * (-(-int(tl.max()) // 2)) for (_, _, _, _, tl) in host_batches]))
+        n_param = sum(s.kernel_size * s.cin * s.cout + s.cout for s in specs)
+        ch = {s.name: s.cout for s in specs}
+        hbm_bytes = (
+            3 * t_pad * (2000 * 2 + 64 * 4) +                  # output_conv fwd / dgrad / wgrad: activation + logits
+            t_pad * K_CLASSES * 4 * 3 +                        # softmax: logits in, probs + log q out
+            t_pad * K_CLASSES * 4 * 2 + 2 * 2 * t_pad * 401 * 4 +  # CTC: log q, probs; alpha/beta written and read
+            sum(t_pad * ch[n] * 2 for n in names) +            # bias gradients: each layer's g read once
+            n_param * 32.0)                                    # Adam + repack: 4 fp32 reads, 3 fp32 + 2 bf16 writes
+        hbm_tags = [t for t in live_ms if t in ("softmax", "ctc") or t.endswith(":output_conv") or
+                    t.startswith("adam") or t.startswith("bgrad:")]
+        hbm_ms = sum(live_ms[t] for t in hbm_tags)
+        result["roofline"] = {"bound": "hbm", "kernel": "the step's HBM-bound kernels together: output_conv fwd/dgrad/"
+                                                        "wgrad, softmax, CTC lattice+gradient, bias gradients, Adam",
+                              "achieved": hbm_bytes / (hbm_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": hbm_bytes / (hbm_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                              "bytes_per_step": hbm_bytes, "ms_per_step": hbm_ms,
+                              "note": "algorithmic bytes (each operand / result once, padded frames included) over "
+                                      "the summed live durations of those launches; the CTC lattice is latency- not "
+                                      "bandwidth-bound (4000 sequential frames), which is what holds this number down"}
+        result["padding_waste"] = waste
+    if world == 1 and not args.no_cpu_baseline and args.config == 3:
+        from oracle import w2l_oracle as o
+        result["cpu_baseline"] = cpu_baseline(o.layer_specs(MEL, K_CLASSES), weights)
     else:
         result["cpu_baseline"] = None
     print(json.dumps(result))

@@ -298,6 +298,7 @@ class Engine:
                         if p.index > 0 else None for p in self.plans]
         self._packed_dirty = True
         self._buffers = {}
+        self.max_cached_shapes = 4  # (batch, frames) geometries kept allocated (length-bucketed corpora: raise it)
         self.cur = None
         self.timeline = None
         self._side_stream = None
@@ -329,7 +330,7 @@ class Engine:
         key = (batch, t_in)
         buf = self._buffers.get(key)
         if buf is None:
-            if len(self._buffers) >= 4:  # bound HBM use when many batch shapes are seen
+            if len(self._buffers) >= self.max_cached_shapes:  # bound HBM use when many batch shapes are seen
                 self._buffers.pop(next(iter(self._buffers)))
             buf = _Buffers(self, batch, t_in)
             self._buffers[key] = buf
