@@ -443,37 +443,69 @@ class Wav2Letter:
         mean = losses.mean()  # new tensor: safe against the next step overwriting the loss buffer
         return mean if lazy else float(mean.item())
 
+    def _pack_for_staging(self, labeled_spectrogram_batch):
+        """The host half of train_on_batch for pipeline.BatchStager: everything but the padded input array."""
+        spectrograms = [np.asarray(x.z_normalized_transposed_spectrogram()) for x in labeled_spectrogram_batch]
+        labels = [x.label for x in labeled_spectrogram_batch]
+        ratio = self.input_to_prediction_length_ratio
+        return (spectrograms, self.grapheme_encoding.encode_label_batch(labels),
+                np.array([len(l) for l in labels], dtype=np.int32),
+                np.array([s.shape[0] // ratio for s in spectrograms], dtype=np.int32))
+
+    def train_on_staged_batch(self, staged, stager, reducer=None):
+        """train_on_batch for a pipeline.StagedBatch (input already in HBM, arrival ordered by an event)."""
+        self.engine.load_input(staged.x_dev)
+        stager.release(staged)
+        self.engine.set_labels(staged.labels, staged.label_lengths, staged.prediction_lengths)
+        return self.engine.train_step_resident(reducer).mean()
+
     def train(self, labeled_spectrogram_batches, preview_labeled_spectrogram_batch, tensor_board_log_directory,
-              net_directory, batches_per_epoch, max_epochs=100000000, reducer=None):
+              net_directory, batches_per_epoch, max_epochs=100000000, reducer=None, prefetch_depth=2):
         """Epoch loop of reference net.py:541-576: preview, then epochs of `batches_per_epoch` steps starting at
         `load_epoch or 0`; after every epoch the preview is logged and (epoch > 0) the weights are saved as
-        weights-epoch{N}.  Ends when the batch iterable is exhausted or after max_epochs (Keras: 1e8)."""
+        weights-epoch{N}.  Ends when the batch iterable is exhausted or after max_epochs (Keras: 1e8).
+        prefetch_depth > 0: batches are packed on a worker thread and copied to HBM on a side stream
+        (speechless_amd/pipeline.py) while the previous steps run; 0 = the reference's serial behaviour."""
         def print_preview_batch():
             log(self.test_and_predict_batch(preview_labeled_spectrogram_batch))
 
         print_preview_batch()
-        batches = iter(labeled_spectrogram_batches)
+        stager = None
+        if prefetch_depth > 0:
+            from .pipeline import BatchStager
+            stager = BatchStager(labeled_spectrogram_batches, self._pack_for_staging, self.engine.device,
+                                 depth=prefetch_depth)
+            batches = iter(stager)
+        else:
+            batches = iter(labeled_spectrogram_batches)
         epoch = self.load_epoch if self.load_epoch is not None else 0
         log_path = None
         if tensor_board_log_directory is not None:
             Path(tensor_board_log_directory).mkdir(parents=True, exist_ok=True)
             log_path = Path(tensor_board_log_directory) / "loss.csv"
-        while epoch < max_epochs:
-            epoch_losses = []
-            for _ in range(batches_per_epoch):
-                batch = next(batches, None)
-                if batch is None:
+        try:
+            while epoch < max_epochs:
+                epoch_losses = []
+                for _ in range(batches_per_epoch):
+                    batch = next(batches, None)
+                    if batch is None:
+                        break
+                    if stager is not None:
+                        epoch_losses.append(self.train_on_staged_batch(batch, stager, reducer=reducer))
+                    else:
+                        epoch_losses.append(self.train_on_batch(batch, reducer=reducer, lazy=True))
+                epoch_losses = [float(l.item()) for l in epoch_losses]  # one host<->device sync per epoch, not per step
+                if len(epoch_losses) < batches_per_epoch:
                     break
-                epoch_losses.append(self.train_on_batch(batch, reducer=reducer, lazy=True))
-            epoch_losses = [float(l.item()) for l in epoch_losses]  # one host<->device sync per epoch, not per step
-            if len(epoch_losses) < batches_per_epoch:
-                break
-            if log_path is not None:
-                with log_path.open("a") as f:
-                    f.write("{},{}\n".format(epoch, _average_or_nan(epoch_losses)))
-            log("Epoch {}: loss {:.4f}".format(epoch, _average_or_nan(epoch_losses)))
-            print_preview_batch()
-            if epoch > 0:
-                Path(net_directory).mkdir(parents=True, exist_ok=True)
-                self.predictive_net.save_weights(Path(net_directory) / self.model_file_name(epoch))
-            epoch += 1
+                if log_path is not None:
+                    with log_path.open("a") as f:
+                        f.write("{},{}\n".format(epoch, _average_or_nan(epoch_losses)))
+                log("Epoch {}: loss {:.4f}".format(epoch, _average_or_nan(epoch_losses)))
+                print_preview_batch()
+                if epoch > 0:
+                    Path(net_directory).mkdir(parents=True, exist_ok=True)
+                    self.predictive_net.save_weights(Path(net_directory) / self.model_file_name(epoch))
+                epoch += 1
+        finally:
+            if stager is not None:
+                stager.close()

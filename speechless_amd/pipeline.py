@@ -1,0 +1,130 @@
+"""Host input pipeline of the training step: packing on a worker thread, H2D on a copy stream.
+
+The reference packs every batch serially with numpy on the training thread (speechless/net.py:578-607, fed by
+`fit_generator` with one worker, net.py:550) and hands pageable host arrays to the session.  Once the step itself takes
+2.5 ms for 32 utterances that serial part (zero-pad 16 MB + pageable H2D) is several times longer than the step, so it
+moves off the critical path:
+
+    worker thread : next(batches) -> labels/lengths encoded, spectrograms converted (float64 -> float32) and zero-padded
+                    in ONE pass into a host staging buffer -> H2D on a dedicated copy stream -> event
+    training loop : waits for the event on the compute stream (no host sync), packs fp32 -> bf16 halo'd layout on the
+                    GPU (sl_pack_input) and runs the step while the worker stages the following batches.
+
+Slots are recycled only after (a) their H2D copy finished and (b) the step that read the device tensor has issued its
+pack kernel (event recorded on the compute stream), so `depth` batches can be in flight.
+
+The staging buffer is deliberately PAGEABLE: on this platform CPU stores into hipHostMalloc'ed (pinned, coherent) memory
+drop to ~3 GB/s while the GPU is busy (5.5 ms to fill 16 MB, against 0.4 ms idle and 0.7 ms for pageable memory), and
+the pageable H2D costs the worker 0.7 ms instead of 0.3 -- measured with tools/e2e_train_throughput.py.
+"""
+import threading
+
+import numpy as np
+import torch
+
+
+class StagedBatch:
+    """One batch resident (or arriving) in HBM.  `ready` is recorded on the copy stream behind the H2D copy."""
+
+    def __init__(self, slot, x_dev, labels, label_lengths, prediction_lengths, ready):
+        self.slot = slot
+        self.x_dev = x_dev
+        self.labels = labels
+        self.label_lengths = label_lengths
+        self.prediction_lengths = prediction_lengths
+        self.ready = ready
+
+
+class _Slot:
+    def __init__(self):
+        self.pinned = None   # flat host float32 staging buffer (grown on demand; pageable, see the module docstring)
+        self.device = None   # flat device float32 buffer
+        self.copied = None   # event: H2D of the last use finished
+        self.consumed = None  # event on the compute stream: the last reader has been enqueued
+
+
+class BatchStager:
+    """Iterates `batches` (an iterable of List[LabeledSpectrogram]) ahead of the training loop.
+
+    pack(batch) -> (spectrogram list, label_batch int32 (B, Lmax), label_lengths, prediction_lengths) is the net's own
+    packer, so the staged tensors are exactly what train_on_batch would have built.  `depth` batches are in flight on
+    `workers` threads (numpy's conversion loops release the GIL); the batch iterable itself is only ever advanced by
+    the consuming thread, and batches are delivered in order."""
+
+    def __init__(self, batches, pack, device, depth=2, workers=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.device = torch.device(device)
+        self.pack = pack
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.depth = max(1, depth)
+        self.slots = [_Slot() for _ in range(self.depth + 1)]
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="speechless-stager")
+        self.source = iter(batches)
+        self.pending = []  # futures, oldest first
+        self.submitted = 0
+        self.exhausted = False
+        self.copy_lock = threading.Lock()  # one H2D at a time on the copy stream, in submission order per slot
+
+    # ---- worker threads
+    def _stage(self, slot, batch):
+        torch.cuda.set_device(self.device)
+        spectrograms, labels, label_lengths, prediction_lengths = self.pack(batch)
+        b = len(spectrograms)
+        t_max = max(s.shape[0] for s in spectrograms)
+        f = spectrograms[0].shape[1]
+        n = b * t_max * f
+        if slot.copied is not None:
+            slot.copied.synchronize()      # the previous H2D out of this staging buffer is done
+        if slot.consumed is not None:
+            slot.consumed.synchronize()    # ... and the previous reader of the device buffer has run
+        if slot.pinned is None or slot.pinned.numel() < n:
+            slot.pinned = torch.empty((n,), dtype=torch.float32)
+            slot.device = torch.empty((n,), dtype=torch.float32, device=self.device)
+        host = slot.pinned[:n].view(b, t_max, f)
+        host_np = host.numpy()
+        for row, s in zip(host_np, spectrograms):  # convert + zero-pad in one pass (net.py:583-586)
+            row[:s.shape[0]] = s
+            row[s.shape[0]:] = 0
+        x_dev = slot.device[:n].view(b, t_max, f)
+        with self.copy_lock, torch.cuda.stream(self.copy_stream):
+            x_dev.copy_(host, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        slot.copied = ready
+        slot.consumed = None
+        return StagedBatch(slot, x_dev, labels, label_lengths, prediction_lengths, ready)
+
+    def _fill(self):
+        while not self.exhausted and len(self.pending) < self.depth:
+            batch = next(self.source, None)  # errors of the corpus reader surface here, in the training loop
+            if batch is None:
+                self.exhausted = True
+                break
+            slot = self.slots[self.submitted % len(self.slots)]
+            self.submitted += 1
+            self.pending.append(self.pool.submit(self._stage, slot, batch))
+
+    # ---- training loop side
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        self._fill()
+        if not self.pending:
+            raise StopIteration
+        item = self.pending.pop(0).result()  # re-raises a worker's exception
+        self._fill()
+        torch.cuda.current_stream(self.device).wait_event(item.ready)
+        return item
+
+    def release(self, staged):
+        """Call once the kernels reading staged.x_dev have been enqueued on the current stream."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        staged.slot.consumed = ev
+
+    def close(self):
+        for f in self.pending:
+            f.cancel()
+        self.pool.shutdown(wait=True)
+        self.pending = []

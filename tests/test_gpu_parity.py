@@ -793,3 +793,28 @@ def test_data_parallel_step_through_rccl_single_rank(early_adam):
     for a, b in zip(results[0][1], results[1][1]):
         assert np.array_equal(a, b)
     assert np.isfinite(results[0][0]).all() and (results[0][0][2] != results[0][0][0]).any()  # the weights did move
+
+
+def test_prefetch_pipeline_trains_exactly_like_the_serial_loop(tmp_path):
+    """train(prefetch_depth=2) -- worker-thread packing, H2D on a copy stream, slot recycling --
+    must produce bit-identical weights to the reference's serial loop (prefetch_depth=0) on ragged batches."""
+    from speechless_amd import Wav2Letter, english_frequent_characters
+    from speechless_amd.net import Adam
+    rng = np.random.RandomState(21)
+    batches = [synthetic_examples(int(rng.randint(2, 6)), rng) for _ in range(14)]
+    finals = []
+    for depth in (0, 2):
+        net = Wav2Letter(128, english_frequent_characters, optimizer=Adam(1e-3), seed=4)
+        net.train(batches, preview_labeled_spectrogram_batch=batches[0][:2], tensor_board_log_directory=None,
+                  net_directory=tmp_path / "n{}".format(depth), batches_per_epoch=4)
+        finals.append([w.copy() for w, _ in net.predictive_net.get_weights()])
+    for a, b in zip(*finals):
+        assert np.array_equal(a, b)
+
+    def failing():
+        yield batches[0]
+        raise RuntimeError("corpus reader died")
+    net = Wav2Letter(128, english_frequent_characters, seed=4)
+    with pytest.raises(RuntimeError, match="corpus reader died"):  # worker errors surface in the training loop
+        net.train(failing(), preview_labeled_spectrogram_batch=batches[0][:2], tensor_board_log_directory=None,
+                  net_directory=tmp_path / "x", batches_per_epoch=4)

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""End-to-end utterances/s of Wav2Letter.train_on_batch on HOST batches (List[LabeledSpectrogram], float64 spectrograms
+as the reference produces them): the reference's serial loop (pack -> pageable H2D -> step) against the staged pipeline
+(speechless_amd/pipeline.py).  BASELINE config-3 shape: 32 utterances x 1000 frames x 128 mel.
+
+    python tools/e2e_train_throughput.py [--steps 40]
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=40)
+    args = ap.parse_args()
+    import torch
+    from speechless_amd import Wav2Letter, english_frequent_characters
+    from speechless_amd.net import LabeledSpectrogram
+    from speechless_amd.pipeline import BatchStager
+    rng = np.random.RandomState(0)
+    chars = "abcdefghijklmnopqrstuvwxyz '"
+    pool = []
+    for i in range(64):
+        label = "".join(rng.choice(list(chars), size=rng.randint(20, 201))).strip() or "a"
+        pool.append(LabeledSpectrogram(id=str(i), label=" ".join(label.split()), spectrogram=rng.randn(1000, 128)))
+    batches = [[pool[(j * 7 + i) % 64] for i in range(32)] for j in range(args.steps + 8)]
+    net = Wav2Letter(128, english_frequent_characters, seed=0)
+    for b in batches[:4]:
+        net.train_on_batch(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[4:4 + args.steps]:
+        loss = net.train_on_batch(b, lazy=True)
+    float(loss.item())
+    serial = time.perf_counter() - t0
+    stager = BatchStager(batches[4:4 + args.steps], net._pack_for_staging, net.engine.device, depth=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for staged in stager:
+        loss = net.train_on_staged_batch(staged, stager)
+    float(loss.item())
+    piped = time.perf_counter() - t0
+    stager.close()
+    print("serial loop   : {:8.1f} utt/s ({:.2f} ms per batch of 32, host packing + pageable H2D on the critical path)".format(
+        32 * args.steps / serial, serial / args.steps * 1e3))
+    print("staged (worker thread, copy stream): {:8.1f} utt/s ({:.2f} ms per batch)".format(
+        32 * args.steps / piped, piped / args.steps * 1e3))
+
+
+if __name__ == "__main__":
+    main()
