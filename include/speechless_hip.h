@@ -170,6 +170,17 @@ int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* label
 int sl_greedy_decode(const float* probs, const int32_t* input_len, int32_t* out, int32_t* out_len,
                      int32_t* frame_argmax, int batch, int t_out, int k, int blank, void* stream);
 
+/* ---- Dropout (net.py:301-303: a Keras Dropout(rate) layer in front of every conv except the last three; training
+ * phase only, `dropout=None` in every reference configuration) ------------------------------------------------------
+ * sl_dropout: dst[i] = keep_i ? src[i] / (1 - rate) : 0 over n elements (dst may be src), keep_i a pure function of
+ * (seed, i) -> a step is reproducible from its seed.  Zero halo / padding elements stay zero, so it can run over a
+ * whole halo'd tensor.  Because the activation is stored AFTER dropout, the ReLU-mask epilogue of the next dgrad
+ * (mask = stored value > 0) applies the keep mask for free; sl_scale supplies the remaining 1 / (1 - rate) factor of
+ * the backward pass (x[i] *= scale).
+ */
+int sl_dropout(const void* src, void* dst, size_t n, int dtype, float rate, uint64_t seed, void* stream);
+int sl_scale(void* x, size_t n, int dtype, float scale, void* stream);
+
 /* ---- Keras-2.0 Adam (net.py:132): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps) ------------------- */
 int sl_adam_step(float* param, const float* grad, float* m, float* v, size_t n, int step, float lr, float beta1,
                  float beta2, float eps, void* stream);

@@ -159,9 +159,13 @@ def conv1d_backward(x, w, stride, dz):
 # ----------------------------------------------------------------------------------------------
 # forward stack
 # ----------------------------------------------------------------------------------------------
-def forward_stack(specs, weights, input_batch, bf16_mirror=False, keep=False):
+def forward_stack(specs, weights, input_batch, bf16_mirror=False, keep=False, input_scales=None):
     """Runs the 11 conv layers.  Returns probabilities (B,T',K) (and, with keep=True, the list of layer
     inputs and pre-activations needed for backprop).
+
+    input_scales: optional list (one entry per layer, None = identity) of arrays multiplied onto that layer's INPUT:
+    Keras' training-phase Dropout in front of a conv (net.py:301-303) with the mask made explicit, i.e.
+    keep_mask / (1 - rate) (inverted dropout: kept activations are scaled up, the rest are zero).
 
     bf16_mirror=True models the HIP bf16 path: weights and every stored activation are rounded to bf16
     (accumulation stays fp32/fp64); the output layer's logits are kept in fp32 (never stored as bf16)."""
@@ -172,6 +176,10 @@ def forward_stack(specs, weights, input_batch, bf16_mirror=False, keep=False):
     for spec, (w, b) in zip(specs, weights):
         if bf16_mirror:
             w = round_to_bf16(w).astype(w.dtype)
+        if input_scales is not None and input_scales[len(xs)] is not None:
+            x = x * input_scales[len(xs)]
+            if bf16_mirror:
+                x = round_to_bf16(x).astype(w.dtype)
         z = conv1d_preactivation(x, w, b, spec.stride)
         xs.append(x)
         zs.append(z)
@@ -305,9 +313,12 @@ def ctc_brute_force(probs_t_k, label, blank, eps=1e-8):
 # loss + all 22 gradients (net.py:359-390: mean over the batch of per-utterance CTC loss)
 # ----------------------------------------------------------------------------------------------
 def loss_and_gradients(specs, weights, input_batch, labels, prediction_lengths, label_lengths, eps=1e-8,
-                       bf16_mirror=False, frozen_layer_count=0):
-    """Returns dict(probs, losses (B,), mean_loss, grads [(dW, db)] * n_layers, dlogits)."""
-    probs, xs, zs = forward_stack(specs, weights, input_batch, bf16_mirror=bf16_mirror, keep=True)
+                       bf16_mirror=False, frozen_layer_count=0, input_scales=None):
+    """Returns dict(probs, losses (B,), mean_loss, grads [(dW, db)] * n_layers, dlogits).
+    input_scales: see forward_stack (explicit dropout masks); the input gradient of a layer passes through the same
+    multiplier on its way to the previous layer's activation."""
+    probs, xs, zs = forward_stack(specs, weights, input_batch, bf16_mirror=bf16_mirror, keep=True,
+                                  input_scales=input_scales)
     bsz = input_batch.shape[0]
     losses, dprobs = ctc_batch_cost(probs, labels, prediction_lengths, label_lengths, eps)
     assert specs[-1].activation == "softmax"
@@ -328,6 +339,8 @@ def loss_and_gradients(specs, weights, input_batch, labels, prediction_lengths, 
         dzs[li] = dz
         if li == frozen_layer_count:
             break
+        if input_scales is not None and input_scales[li] is not None:
+            dx = dx * input_scales[li]
         prev_spec = specs[li - 1]
         if prev_spec.activation == "relu":
             dz = dx * (zs[li - 1] > 0)

@@ -55,6 +55,8 @@ SIGNATURES = {
     "sl_bias_grad_workspace_bytes": (c_size_t, [POINTER(ConvGeom)]),
     "sl_bias_grad": (c_int, [c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_void_p, c_size_t, c_void_p]),
     "sl_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sl_dropout": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, ctypes.c_uint64, c_void_p]),
+    "sl_scale": (c_int, [c_void_p, c_size_t, c_int, c_float, c_void_p]),
     "sl_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "sl_softmax_logq": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float,
                                 c_void_p]),

@@ -266,6 +266,89 @@ extern "C" int sl_bias_grad(const void* g, float* db, const sl_conv_geom* geom, 
     return sl_check_launch("sl_bias_grad(final)");
 }
 
+namespace {
+
+// counter-based generator: one 64-bit mix (splitmix64 finaliser) of (seed, element index) -> 32 uniform bits.  The
+// mask of an element depends only on (seed, index), so a step is reproducible from its seed and no state is kept.
+__device__ __forceinline__ unsigned int dropout_bits(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned int)(z >> 32);
+}
+
+// y = keep ? x * 1/(1-rate) : 0   (Keras inverted dropout, training phase).  4 elements per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ src, T* __restrict__ dst, long n,
+                                                      unsigned int threshold, float scale, unsigned long long seed) {
+    const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long i = i0 + j;
+        if (i < n) {
+            const bool keep = dropout_bits(seed, (unsigned long long)i) >= threshold;
+            float v;
+            if (sizeof(T) == 2)
+                v = bf16_bits_to_f32((unsigned short)src[i]);
+            else
+                v = (float)src[i];
+            dst[i] = cvt_out<T>(keep ? v * scale : 0.f);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ x, long n, float scale) {
+    const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long i = i0 + j;
+        if (i < n) {
+            float v;
+            if (sizeof(T) == 2)
+                v = bf16_bits_to_f32((unsigned short)x[i]);
+            else
+                v = (float)x[i];
+            x[i] = cvt_out<T>(v * scale);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sl_dropout(const void* src, void* dst, size_t n, int dtype, float rate, uint64_t seed, void* stream) {
+    SL_CHECK_ARG(src && dst, "sl_dropout: null pointer");
+    SL_CHECK_ARG(rate >= 0.f && rate < 1.f, "sl_dropout: rate %f outside [0, 1)", (double)rate);
+    SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32, "sl_dropout: unknown dtype %d", dtype);
+    if (n == 0) return SL_OK;
+    const unsigned int threshold = (unsigned int)((double)rate * 4294967296.0);
+    const float scale = 1.f / (1.f - rate);
+    const unsigned blocks = (unsigned)((n + 1023) / 1024);
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL(dropout_kernel<unsigned short>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)src, (unsigned short*)dst, (long)n, threshold, scale,
+                           (unsigned long long)seed);
+    else
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)src,
+                           (float*)dst, (long)n, threshold, scale, (unsigned long long)seed);
+    return sl_check_launch("sl_dropout");
+}
+
+extern "C" int sl_scale(void* x, size_t n, int dtype, float scale, void* stream) {
+    SL_CHECK_ARG(x, "sl_scale: null pointer");
+    SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32, "sl_scale: unknown dtype %d", dtype);
+    if (n == 0) return SL_OK;
+    const unsigned blocks = (unsigned)((n + 1023) / 1024);
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL(scale_kernel<unsigned short>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (unsigned short*)x, (long)n, scale);
+    else
+        hipLaunchKernelGGL(scale_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)x, (long)n,
+                           scale);
+    return sl_check_launch("sl_scale");
+}
+
 extern "C" int sl_adam_step(float* param, const float* grad, float* m, float* v, size_t n, int step, float lr,
                             float beta1, float beta2, float eps, void* stream) {
     SL_CHECK_ARG(param && grad && m && v, "sl_adam_step: null pointer");

@@ -99,6 +99,8 @@ class _Buffers:
         self.rows = HALO + self.tt_pad + HALO
         self.rows0 = 2 * (self.tt_pad + p0.taps_view)
         self.x0 = torch.zeros((batch, self.rows0, p0.cin_pad), dtype=dt, device=dev)
+        self.x0_dropped = None  # dropout(x0), allocated by the first training forward with dropout
+        self.dropped = False    # the activations of the last forward are post-dropout
         n = len(eng.plans)
         self.y = [None] * (n - 1)
         # a run of identical layers (the seven inner_conv_i) keeps its inputs y[s-1..e-1] in ONE allocation so that
@@ -299,6 +301,11 @@ class Engine:
         self._packed_dirty = True
         self._buffers = {}
         self.max_cached_shapes = 4  # (batch, frames) geometries kept allocated (length-bucketed corpora: raise it)
+        # Keras Dropout(rate) in front of every conv except the last three (net.py:301-303, 326-330); training steps
+        # only.  None = off (every reference configuration).
+        self.dropout_rate = None
+        self.dropout_seed = 0
+        self._dropout_steps = 0
         self.cur = None
         self.timeline = None
         self._side_stream = None
@@ -410,14 +417,34 @@ class Engine:
         self._src_keepalive = src
         return buf
 
-    def forward(self, input_batch=None):
-        """Runs the 11 conv layers + softmax.  Returns the probability tensor (B,T',K) fp32 in HBM."""
+    def _dropout_layers(self):
+        """Indices of the layers with a Dropout in front of them (all but the last three, net.py:326-330)."""
+        return range(0, max(len(self.plans) - 3, 0))
+
+    def forward(self, input_batch=None, training=False):
+        """Runs the 11 conv layers + softmax.  Returns the probability tensor (B,T',K) fp32 in HBM.
+        training=True applies dropout (if self.dropout_rate) to the inputs of the first n-3 layers: the packed input
+        goes through sl_dropout into a second buffer, every other activation is dropped in place right after the
+        layer that produced it (so the stored activation is the post-dropout one the backward pass needs)."""
         buf = self.load_input(input_batch) if input_batch is not None else self.cur
         if self._packed_dirty:
             self.repack_weights()
         st = self._stream()
         n = len(self.plans)
+        rate = self.dropout_rate if training else None
+        buf.dropped = bool(rate)
         x = buf.x0
+        if rate:
+            if any(p.spec.activation == "elu" for p in self.plans[:-1]):
+                raise NotImplementedError("dropout with activation='elu': the backward pass recovers the keep mask from "
+                                          "the stored activation being > 0, which only holds for ReLU")
+            self._dropout_steps += 1
+            seed0 = (self.dropout_seed * 1000003 + self._dropout_steps) * 64
+            if buf.x0_dropped is None:
+                buf.x0_dropped = torch.zeros_like(buf.x0)
+            self._launch("dropout:input", "sl_dropout", buf.x0.data_ptr(), buf.x0_dropped.data_ptr(), buf.x0.numel(),
+                         self.dtype_code, rate, seed0, st)
+            x = buf.x0_dropped
         for p in self.plans:
             last = p.index == n - 1
             y = buf.logits if last else buf.y[p.index]
@@ -428,6 +455,9 @@ class Engine:
                           (_lib.EPI_BIAS_ELU if p.spec.activation == "elu" else _lib.EPI_BIAS_RELU),
                           self.dtype_code, 1 if last else 0,
                           self.nt_cfg.get(("fwd", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+            if rate and (p.index + 1) in self._dropout_layers():
+                self._launch("dropout:" + p.spec.name, "sl_dropout", y.data_ptr(), y.data_ptr(), y.numel(),
+                             self.dtype_code, rate, seed0 + p.index + 1, st)
             x = y
         self._launch("softmax", "sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
                       buf.t_out, self.grapheme_set_size, self.plans[-1].cout_pad, buf.tt_pad * self.plans[-1].cout_pad,
@@ -547,7 +577,7 @@ class Engine:
 
         for p in reversed(self.plans[first:]):
             i = p.index
-            x = buf.x0 if i == 0 else buf.y[i - 1]
+            x = (buf.x0_dropped if buf.dropped else buf.x0) if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
             ready = torch.cuda.Event()
             ready.record(main)  # g[i] (CTC gradient or the previous dgrad) is complete at this point of MAIN
@@ -589,6 +619,11 @@ class Engine:
                              _lib.EPI_ELU_MASK if self.specs[i - 1].activation == "elu" else _lib.EPI_RELU_MASK,
                              self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
                              buf.nt_ws.data_ptr(), buf.nt_ws.numel(), main.cuda_stream)
+                if buf.dropped and i in self._dropout_layers():
+                    # the dgrad epilogue's mask (stored activation > 0) already applied the keep mask: the stored
+                    # activation is post-dropout; what is left of d dropout / dx is the 1 / (1 - rate) factor
+                    self._launch("dropout_scale:" + p.spec.name, "sl_scale", buf.g[i - 1].data_ptr(), buf.g[i - 1].numel(),
+                                 self.dtype_code, 1.0 / (1.0 - self.dropout_rate), main.cuda_stream)
             if early_adam:
                 if i in grouped:
                     if i == grouped[i][0]:
@@ -650,7 +685,7 @@ class Engine:
 
     def train_step_resident(self, reducer=None):
         """Same, with input / labels / lengths already resident in HBM (bench.py's timed region)."""
-        self.forward()
+        self.forward(training=True)
         world = reducer.world_size if reducer is not None else 1
         loss = self.ctc(grad_scale=1.0 / (self.cur.batch * world))
         early = self.early_adam and not self.overlap_wgrad

@@ -244,8 +244,8 @@ class Wav2Letter:
             raise NotImplementedError("raw-wave input (wave_conv, net.py:310-312) is outside the MI355X hot path")
         if kenlm_directory is not None:
             raise NotImplementedError("KenLM beam-search decoding (net.py:444-451) is outside the MI355X hot path")
-        if dropout is not None:
-            raise NotImplementedError("dropout (net.py:301-303) is not implemented on the HIP path yet")
+        if dropout is not None and not 0.0 <= dropout < 1.0:
+            raise ValueError("dropout must be a rate in [0, 1)")
         self.kenlm_directory = kenlm_directory
         self.grapheme_encoding = CtcGraphemeEncoding(allowed_characters=allowed_characters)
         self.use_asg = use_asg
@@ -268,6 +268,8 @@ class Wav2Letter:
                              ctc_epsilon=ctc_epsilon, frozen_layer_count=frozen_layer_count, lr=self.optimizer.lr,
                              beta_1=self.optimizer.beta_1, beta_2=self.optimizer.beta_2,
                              adam_epsilon=self.optimizer.epsilon)
+        self.engine.dropout_rate = dropout if dropout else None  # applied by training steps only (learning phase 1)
+        self.engine.dropout_seed = seed
         self.engine.set_weights(self._glorot_uniform(specs, seed))
         self.predictive_net = PredictiveNet(self.engine)
         for layer in self.predictive_net.layers[:frozen_layer_count]:
