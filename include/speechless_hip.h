@@ -170,6 +170,18 @@ int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* label
 int sl_greedy_decode(const float* probs, const int32_t* input_len, int32_t* out, int32_t* out_len,
                      int32_t* frame_argmax, int batch, int t_out, int k, int blank, void* stream);
 
+/* The same fused update for SEVERAL layers in one launch (the small layers' launches are pure latency): layer i's
+ * block starts `offset` floats into param / grad / m / v (weights [k][cin_pad][cout_pad] followed by cout_pad biases). */
+#define SL_ADAM_MAX_LAYERS 16
+typedef struct {
+    int64_t offset;  /* first weight of the layer, in floats from the four base pointers (multiple of 4) */
+    void* w_fwd;     /* [cout_pad][k][cin_pad] dtype */
+    void* w_dgrad;   /* [cin_pad][k][cout_pad] dtype, taps flipped; NULL for a layer without input gradient */
+    int32_t k, cin_pad, cout_pad;
+} sl_adam_layer;
+int sl_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers, int n_layers,
+                        int dtype, int step, float lr, float beta1, float beta2, float eps, void* stream);
+
 /* ---- Dropout (net.py:301-303: a Keras Dropout(rate) layer in front of every conv except the last three; training
  * phase only, `dropout=None` in every reference configuration) ------------------------------------------------------
  * sl_dropout: dst[i] = keep_i ? src[i] / (1 - rate) : 0 over n elements (dst may be src), keep_i a pure function of

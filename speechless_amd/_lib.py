@@ -22,6 +22,12 @@ EPI_BIAS_ELU = 4
 EPI_ELU_MASK = 5
 
 
+class AdamLayer(ctypes.Structure):
+    """Mirror of sl_adam_layer (include/speechless_hip.h)."""
+    _fields_ = [("offset", c_int64), ("w_fwd", c_void_p), ("w_dgrad", c_void_p), ("k", c_int32), ("cin_pad", c_int32),
+                ("cout_pad", c_int32)]
+
+
 class ConvGeom(ctypes.Structure):
     """Mirror of sl_conv_geom (include/speechless_hip.h)."""
     _fields_ = [
@@ -70,6 +76,8 @@ SIGNATURES = {
                              c_float, c_void_p]),
     "sl_adam_pack_layer": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_float, c_float, c_float, c_float, c_void_p]),
+    "sl_adam_pack_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AdamLayer), c_int, c_int, c_int,
+                                    c_float, c_float, c_float, c_float, c_void_p]),
 }
 
 

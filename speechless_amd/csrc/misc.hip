@@ -128,13 +128,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // 4 fp32 reads + 3 fp32 writes + 2 narrow writes per parameter instead of Adam (4r+3w) followed by pack (1r+2w).
 // grid (cout/64, cin/32, k + 1): z == k is the bias block (only y == 0 works there).
 template <typename T>
-__global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                        float* __restrict__ m, float* __restrict__ v, T* __restrict__ wf,
-                                                        T* __restrict__ wd, int k, int cin, int cout, float lr_t, float b1,
-                                                        float b2, float eps) {
-    __shared__ float tile[32][65];
-    const int tap = blockIdx.z;
-    const int co0 = blockIdx.x * 64;
+__device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __restrict__ p, const float* __restrict__ g,
+                                                float* __restrict__ m, float* __restrict__ v, T* __restrict__ wf,
+                                                T* __restrict__ wd, int k, int cin, int cout, float lr_t, float b1,
+                                                float b2, float eps, int bx, int by, int bz) {
+    const int tap = bz;
+    const int co0 = bx * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     auto adam4 = [&](long idx) {
         const f32x4 gv = *(const f32x4*)(g + idx);
@@ -151,10 +150,10 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, c
         return pv;
     };
     if (tap == k) {  // bias block: cout floats right behind the weights
-        if (blockIdx.y == 0 && ty == 0) adam4((long)k * cin * cout + co0 + tx * 4);
+        if (by == 0 && ty == 0) adam4((long)k * cin * cout + co0 + tx * 4);
         return;
     }
-    const int ci0 = blockIdx.y * 32;
+    const int ci0 = by * 32;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int cil = ty + r * 16;
@@ -187,7 +186,78 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, c
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, T* __restrict__ wf,
+                                                        T* __restrict__ wd, int k, int cin, int cout, float lr_t, float b1,
+                                                        float b2, float eps) {
+    __shared__ float tile[32][65];
+    adam_pack_block<T>(tile, p, g, m, v, wf, wd, k, cin, cout, lr_t, b1, b2, eps, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// every trainable layer in ONE launch: the small layers' updates (0.46 M parameters each, 8 us per launch of pure
+// latency) ride along with the big ones.  blockIdx.x is a linear block id; the table maps it to (layer, x, y, z).
+struct AdamTable {
+    int n;
+    int block_begin[SL_ADAM_MAX_LAYERS + 1];
+    long offset[SL_ADAM_MAX_LAYERS];  // first weight of the layer in the flat fp32 buffers
+    void* wf[SL_ADAM_MAX_LAYERS];
+    void* wd[SL_ADAM_MAX_LAYERS];
+    int k[SL_ADAM_MAX_LAYERS], cin[SL_ADAM_MAX_LAYERS], cout[SL_ADAM_MAX_LAYERS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void adam_pack_multi_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ m, float* __restrict__ v, AdamTable t,
+                                                              float lr_t, float b1, float b2, float eps) {
+    __shared__ float tile[32][65];
+    int layer = 0;
+    while (layer + 1 < t.n && (int)blockIdx.x >= t.block_begin[layer + 1]) ++layer;
+    const int local = blockIdx.x - t.block_begin[layer];
+    const int k = t.k[layer], cin = t.cin[layer], cout = t.cout[layer];
+    const int nx = cout / 64, ny = cin / 32;
+    const int bx = local % nx, by = (local / nx) % ny, bz = local / (nx * ny);
+    const long off = t.offset[layer];
+    adam_pack_block<T>(tile, p + off, g + off, m + off, v + off, (T*)t.wf[layer], (T*)t.wd[layer], k, cin, cout, lr_t, b1,
+                       b2, eps, bx, by, bz);
+}
+
 }  // namespace
+
+extern "C" int sl_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers,
+                                   int n_layers, int dtype, int step, float lr, float beta1, float beta2, float eps,
+                                   void* stream) {
+    SL_CHECK_ARG(param && grad && m && v && layers, "sl_adam_pack_layers: null pointer");
+    SL_CHECK_ARG(n_layers >= 1 && n_layers <= SL_ADAM_MAX_LAYERS, "sl_adam_pack_layers: 1..%d layers per call",
+                 SL_ADAM_MAX_LAYERS);
+    SL_CHECK_ARG(step >= 1 && (dtype == SL_BF16 || dtype == SL_F32), "sl_adam_pack_layers: bad step or dtype");
+    AdamTable t;
+    t.n = n_layers;
+    int blocks = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const sl_adam_layer& L = layers[i];
+        SL_CHECK_ARG(L.w_fwd && L.k > 0 && L.cin_pad > 0 && L.cout_pad > 0 && L.cin_pad % 32 == 0 && L.cout_pad % 64 == 0 &&
+                         L.offset >= 0 && L.offset % 4 == 0,
+                     "sl_adam_pack_layers: layer %d: need w_fwd, cin_pad %% 32 == 0, cout_pad %% 64 == 0, offset %% 4 == 0", i);
+        t.block_begin[i] = blocks;
+        t.offset[i] = L.offset;
+        t.wf[i] = L.w_fwd;
+        t.wd[i] = L.w_dgrad;
+        t.k[i] = L.k;
+        t.cin[i] = L.cin_pad;
+        t.cout[i] = L.cout_pad;
+        blocks += (L.cout_pad / 64) * (L.cin_pad / 32) * (L.k + 1);
+    }
+    t.block_begin[n_layers] = blocks;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL((adam_pack_multi_kernel<unsigned short>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, param,
+                           grad, m, v, t, (float)lr_t, beta1, beta2, eps);
+    else
+        hipLaunchKernelGGL((adam_pack_multi_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m,
+                           v, t, (float)lr_t, beta1, beta2, eps);
+    return sl_check_launch("sl_adam_pack_layers");
+}
 
 extern "C" int sl_adam_pack_layer(float* param, const float* grad, float* m, float* v, void* w_fwd, void* w_dgrad, int k,
                                   int cin_pad, int cout_pad, int dtype, int step, float lr, float beta1, float beta2,

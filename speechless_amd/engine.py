@@ -665,15 +665,21 @@ class Engine:
 
     def _adam_layers(self, layers, st):
         """Fused Adam + bf16 operand repack of the given layers on stream st (self.adam_iterations already counts
-        this step)."""
-        for i in layers:
-            p = self.plans[i]
-            off = p.w_off * 4
-            wd = self.w_dgrad[p.index]
-            self._launch("adam:" + p.spec.name, "sl_adam_pack_layer", self.params.data_ptr() + off,
-                         self.grads.data_ptr() + off, self.adam_m.data_ptr() + off, self.adam_v.data_ptr() + off,
-                         self.w_fwd[p.index].data_ptr(), wd.data_ptr() if wd is not None else None,
-                         p.spec.kernel_size, p.cin_pad, p.cout_pad, self.dtype_code, self.adam_iterations, self.lr,
+        this step): ONE launch for all of them (sl_adam_pack_layers), 16 layers per call at most."""
+        layers = list(layers)
+        for lo in range(0, len(layers), 16):
+            chunk = layers[lo:lo + 16]
+            table = (_lib.AdamLayer * len(chunk))()
+            for entry, i in zip(table, chunk):
+                p = self.plans[i]
+                wd = self.w_dgrad[p.index]
+                entry.offset = p.w_off
+                entry.w_fwd = self.w_fwd[p.index].data_ptr()
+                entry.w_dgrad = wd.data_ptr() if wd is not None else None
+                entry.k, entry.cin_pad, entry.cout_pad = p.spec.kernel_size, p.cin_pad, p.cout_pad
+            self._launch("adam:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name),
+                         "sl_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                         self.adam_v.data_ptr(), table, len(chunk), self.dtype_code, self.adam_iterations, self.lr,
                          self.beta_1, self.beta_2, self.adam_epsilon, st)
 
     def train_step(self, input_batch, label_batch, label_lengths, prediction_lengths, reducer=None):
