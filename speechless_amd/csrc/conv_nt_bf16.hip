@@ -29,6 +29,8 @@
 //   * blockIdx -> tile mapping is XCD-aware: an XCD's work-groups share weight tiles in its private L2.
 #include "common.h"
 
+#include <type_traits>
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
@@ -470,6 +472,35 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     }
 }
 
+// Hand-interleaved half step for the slab kernel: 4*IT MFMAs of one k-half in groups of two, with ONE fragment read
+// of the other k-half issued after each of the first 4+IT groups.  Every group is fenced (sched_barrier), so the
+// LDS-read issue slots sit in the shadow of the matrix pipe instead of in a clump between two MFMA blocks; PMC on the
+// un-interleaved loop showed ~110 non-MFMA instructions per step and wave issued while the pipe drained (pipe busy 65 %).
+template <int IT, int Q, int NQ>
+struct SlabPhase {
+    template <typename Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4 * IT], const bf16x8 (&ca)[4], const bf16x8 (&cb)[IT],
+                                               bf16x8 (&na)[4], bf16x8 (&nb)[IT], unsigned a_addr, unsigned b_addr,
+                                               const Hook& hook) {
+        constexpr int M0 = 2 * Q, M1 = 2 * Q + 1;
+        acc[M0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[M0 / IT], cb[M0 % IT], acc[M0], 0, 0, 0);
+        acc[M1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[M1 / IT], cb[M1 % IT], acc[M1], 0, 0, 0);
+        if constexpr (Q < 4)
+            ds_read128<Q * 512>(na[Q], a_addr);
+        else if constexpr (Q < 4 + IT)
+            ds_read128<(Q - 4) * 2048>(nb[Q - 4], b_addr);
+        hook(std::integral_constant<int, Q>{});  // e.g. one LDS-DMA request of the next weight tile
+        __builtin_amdgcn_sched_barrier(0);
+        SlabPhase<IT, Q + 1, NQ>::template run<Hook>(acc, ca, cb, na, nb, a_addr, b_addr, hook);
+    }
+};
+template <int IT, int NQ>
+struct SlabPhase<IT, NQ, NQ> {
+    template <typename Hook>
+    static __device__ __forceinline__ void run(f32x4 (&)[4 * IT], const bf16x8 (&)[4], const bf16x8 (&)[IT], bf16x8 (&)[4],
+                                               bf16x8 (&)[IT], unsigned, unsigned, const Hook&) {}
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Slab variant (16x16x32 shape only).  Contraction order chunk OUTER, tap INNER: for one 64-channel chunk the BM + taps - 1
 // activation rows a tile needs for ALL taps are brought into LDS ONCE (the "slab", double buffered) and every tap reads its
@@ -482,10 +513,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
 //   vmcnt bookkeeping: the slab of chunk c+1 is issued in step (c, tap 0) BEFORE that step's weight tile, so it is older
 //   than every weight tile of chunk c+1 (needs taps >= STAGES) and only the steps with tap in [1, STAGES-2] see it among
 //   the instructions that may stay in flight.
-template <int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32>
+template <int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32, bool ILV>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_slab_bf16_kernel(NtArgs a) {
     constexpr int STAGES = STAGES_P & 7;
     constexpr bool PIPE = (STAGES_P & 8) != 0;
+    static_assert(!ILV || PIPE, "the interleaved schedule is a variant of the register-pipelined loop");
     static_assert(STAGES >= 2, "ring too shallow");
     constexpr int NW = WM * WN;
     constexpr int WROWS = 16 * IT;
@@ -597,7 +629,69 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     };
     int tap_c = 0, par_c = 0, chunk_c = 0;  // chunk_c counts chunks of this split
 
-    if constexpr (PIPE) {
+    if constexpr (ILV) {
+        // ---- interleaved schedule.  Per step and wave:
+        //   A: [a0,b0 ready] 4*IT MFMAs of k-half 0, one read of k-half 1 after every second MFMA
+        //   lgkmcnt(0), vmcnt, barrier
+        //   B: 4*IT MFMAs of k-half 1, one read of the NEXT tile's k-half 0 after every second MFMA, then the request
+        //      of the weight tile that re-uses this slot (branch-free: past the end the last tile is requested again
+        //      into a slot nobody reads) somewhere among the remaining MFMAs
+        int issued = 0;
+        const __bf16* ws_next = nullptr;  // source of the weight tile being requested piecewise
+        char* wl_next = nullptr;
+        auto begin_w = [&](int slot) {  // address of the next tile; advances the (clamped) request counters
+            ws_next = wbase + (long)tap_i * a.cin + cc_i * BK;
+            wl_next = smem + RING0 + slot * W_BYTES + (wave * WPW) * 1024;
+            const bool more = issued + 1 < n;
+            issued += more ? 1 : 0;
+            const bool wrap = tap_i + 1 == taps;
+            const int t1 = wrap ? 0 : tap_i + 1;
+            cc_i = (more && wrap) ? cc_i + 1 : cc_i;
+            tap_i = more ? t1 : tap_i;
+        };
+        auto no_hook = [](auto) {};
+        auto dma_hook = [&](auto q_c) {  // groups 0..WPW-1 of phase B each carry one request of the tile
+            constexpr int Q = decltype(q_c)::value;
+            if constexpr (Q < WPW) glds16(ws_next + woff[Q], wl_next + Q * 1024);
+        };
+        issue_slab(c0, 0);
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i) {
+            begin_w(i);
+#pragma unroll
+            for (int q = 0; q < WPW; ++q) glds16(ws_next + woff[q], wl_next + q * 1024);
+        }
+        wait_vmcnt<WPW*(STAGES - 1)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 a0[4], b0[IT], a1[4], b1[IT];
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        DsReadRun<0, 4, 512>::go(a0, lds0 + aoff);
+        DsReadRun<0, IT, 2048>::go(b0, lds0 + b_offset(0, 0));
+        int cur = 0;
+        for (int i = 0; i < n; ++i) {
+            const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
+            wait_frags<0>(a0, b0);
+            SlabPhase<IT, 0, 2 * IT>::run(acc, a0, b0, a1, b1, lds0 + ((aoff + cur * W_BYTES) ^ 64),
+                                          lds0 + (b_offset(par_c, tap_c) ^ 64), no_hook);
+            wait_frags<0>(a1, b1);  // my reads of weight slot cur (and, on a chunk's last tap, of its slab) are complete
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // the only branch of the loop body: once per chunk, in front of the straight-line phase
+            if (tap_c == 0 && chunk_c + 1 < nchunks) issue_slab(c0 + chunk_c + 1, par_c ^ 1);
+            const bool wrap = tap_c + 1 == taps;
+            chunk_c += wrap ? 1 : 0;
+            par_c = wrap ? par_c ^ 1 : par_c;
+            tap_c = wrap ? 0 : tap_c + 1;
+            begin_w(cur);
+            SlabPhase<IT, 0, 2 * IT>::run(acc, a1, b1, a0, b0, lds0 + aoff + nxt * W_BYTES, lds0 + b_offset(par_c, tap_c),
+                                          dma_hook);
+            cur = nxt;
+        }
+        wait_vmcnt<0>();       // the surplus requests still target this work-group's LDS
+        wait_frags<0>(a0, b0);  // ... and the surplus fragment reads these registers
+    } else if constexpr (PIPE) {
         issue_slab(c0, 0);
 #pragma unroll
         for (int i = 0; i < STAGES; ++i)
@@ -798,17 +892,18 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
 template <bool M32, int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
 int launch_main(const NtArgs& a, hipStream_t s) {
     const int grid = xcd_grid(a.batch * a.t_tiles * a.n_tiles * a.ksplit);
-    if constexpr (!M32 && IT >= 100) {  // slab variant: IT - 100 is the real IT
-        constexpr int RIT = IT - 100;
+    if constexpr (!M32 && IT >= 100) {  // slab variant: IT - 100 is the real IT (IT - 200: interleaved schedule)
+        constexpr bool ILV = IT >= 200;
+        constexpr int RIT = ILV ? IT - 200 : IT - 100;
         constexpr int LDS_BYTES = 2 * (16 * RIT * WM / 8 + 4) * 1024 + (STAGES & 7) * 64 * WN * 128;
         static_assert(LDS_BYTES <= 160 * 1024, "slabs + weight ring exceed the 160 KiB of a CU");
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_nt_slab_bf16_kernel<RIT, WM, WN, STAGES, MODE, OUT_F32>,
+            (void)hipFuncSetAttribute((const void*)conv_nt_slab_bf16_kernel<RIT, WM, WN, STAGES, MODE, OUT_F32, ILV>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_nt_slab_bf16_kernel<RIT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid),
+        hipLaunchKernelGGL((conv_nt_slab_bf16_kernel<RIT, WM, WN, STAGES, MODE, OUT_F32, ILV>), dim3(grid),
                            dim3(64 * WM * WN), LDS_BYTES, s, a);
         return sl_check_launch("sl_conv1d_nt(bf16, slab)");
     } else {
@@ -836,7 +931,7 @@ int launch_tail(const NtArgs& a, int rows_per_batch, hipStream_t s) {
 
 template <bool M32, int IT, int WM, int WN, int STAGES>
 int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
-    constexpr int BM = (M32 ? 64 : 16 * (IT >= 100 ? IT - 100 : IT)) * WM;
+    constexpr int BM = (M32 ? 64 : 16 * (IT >= 200 ? IT - 200 : IT >= 100 ? IT - 100 : IT)) * WM;
     a.t_tiles = (a.t_out + BM - 1) / BM;
     a.n_tiles = a.cout / (64 * WN);
     if (a.ksplit > 1) {
@@ -877,16 +972,18 @@ struct Cfg {
     int wm, wn, stages, ksplit, it, m32;
     int gm = 0;  // m-tiles per raster block (0 = automatic)
     int slab = 0;  // chunk-major contraction with the activation slab kept in LDS (conv_nt_slab_bf16_kernel)
+    int ilv = 0;   // slab kernel with the hand-interleaved MFMA / LDS-read / DMA-request schedule
     int bm() const { return (m32 ? 64 : 16 * it) * wm; }
 };
 
 // cfg word: wm | wn << 4 | stages << 8 | ksplit << 12 | it << 20 (it = 0 means 4) | m32 << 24 | (1 + log2 gm) << 25 (0 = auto)
-// | slab << 29;  0 = choose everything automatically
+// | slab << 29 | interleaved << 30;  0 = choose everything automatically
 Cfg decode_cfg(int cfg) {
     Cfg c{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 15, (cfg >> 12) & 255, (cfg >> 20) & 15, (cfg >> 24) & 1};
     const int gml = (cfg >> 25) & 15;
     c.gm = gml ? 1 << (gml - 1) : 0;
     c.slab = (cfg >> 29) & 1;
+    c.ilv = (cfg >> 30) & 1;
     if (c.it == 0) c.it = 4;
     if (c.m32) c.it = 4;
     return c;
@@ -898,15 +995,16 @@ Cfg auto_cfg(const sl_conv_geom* g) {
     if (g->cout % 256 == 0) {
         const long tiles256 = (long)g->batch * ((g->t_out + 255) / 256) * (g->cout / 256);
         const bool slab_ok = g->taps >= 2 && g->taps <= 33;
-        // 256x256 tile, one work-group per CU.  With taps the slab variant (8 waves of 128x64, register-pipelined):
-        // big_conv_1 forward 0.348 ms = 1.47 PFLOP/s against 0.372 for the 16-wave tap-major kernel; 1x1 layers keep
-        // the 16-wave kernel (1.19 PFLOP/s on big_conv_2)
-        if (tiles256 >= 192) return slab_ok ? Cfg{2, 4, 10, 1, 8, 0, 0, 1} : Cfg{4, 4, 2, 1, 4, 0};
+        // 256x256 tile, one work-group per CU.  With taps the slab variant (8 waves of 128x64, register-pipelined,
+        // hand-interleaved MFMA / LDS-read / DMA-request stream): big_conv_1 forward 0.334 ms = 1.53 PFLOP/s (0.345
+        // un-interleaved, 0.372 for the 16-wave tap-major kernel); 1x1 layers keep the 16-wave kernel (1.19 PFLOP/s
+        // on big_conv_2)
+        if (tiles256 >= 192) return slab_ok ? Cfg{2, 4, 10, 1, 8, 0, 0, 1, 1} : Cfg{4, 4, 2, 1, 4, 0};
         if (nsteps >= 256) {  // long contraction but few tiles (dgrad of big_conv_1: 64 tiles, K = 65536): split K
             long ks = (256 + tiles256 - 1) / tiles256;
             if (ks > 8) ks = 8;
             const long chunks = g->cin / BK;
-            if (slab_ok && chunks % ks == 0) return Cfg{2, 4, 10, (int)ks, 8, 0, 0, 1};
+            if (slab_ok && chunks % ks == 0) return Cfg{2, 4, 10, (int)ks, 8, 0, 0, 1, 1};
             return Cfg{4, 4, 2, (int)ks, 4, 0};
         }
     }
@@ -940,6 +1038,7 @@ bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
     if (!shape || c.ksplit < 1) return false;
     if (g->cout % (64 * c.wn)) return false;
     const long nsteps = (long)g->taps * (g->cin / BK);
+    if (c.ilv && !(c.slab && !c.m32 && c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10)) return false;
     if (c.slab) {
         // instantiated slab shapes; the slab holds BM + 32 rows and its DMA must be older than the next chunk's tiles
         const bool inst = !c.m32 && ((c.it == 4 && c.wm == 4 && c.wn == 4 && full.stages == 2) ||
@@ -1012,6 +1111,7 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
 #define SL_NT_SLAB_CASE(IT_, WM_, WN_, ST_)                                      \
     if (c.slab && c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
         return launch_cfg<false, 100 + IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);
+    if (c.slab && c.ilv) return launch_cfg<false, 208, 2, 4, 10>(a, epilogue, out_f32, s);
     SL_NT_SLAB_CASE(4, 4, 4, 2)
     SL_NT_SLAB_CASE(8, 2, 4, 10)
     SL_NT_SLAB_CASE(2, 4, 2, 11)

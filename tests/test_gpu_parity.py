@@ -619,8 +619,9 @@ def test_power_spectrogram_shape_with_ragged_lengths(dtype):
 
 # ------------------------------------------------------------------------------------------ every NT tile configuration
 def _nt_cfg(wm, wn, stages, ksplit=1, it=4, m32=0, gm_log2p1=0, slab=0):
-    """cfg word of sl_conv1d_nt (see conv_nt_bf16.hip:decode_cfg)."""
-    return wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20) | (m32 << 24) | (gm_log2p1 << 25) | (slab << 29)
+    """cfg word of sl_conv1d_nt (see conv_nt_bf16.hip:decode_cfg); slab = 3 selects the interleaved slab schedule."""
+    return (wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20) | (m32 << 24) | (gm_log2p1 << 25) |
+            ((slab & 1) << 29) | ((slab >> 1) << 30))
 
 
 NT_CONFIGS = (
@@ -636,7 +637,8 @@ NT_CONFIGS = (
     # slab (chunk-major) variants, with and without split-K, and an explicit 2-D raster
     [(4, 4, 2, 1, 4, 0, 0, 1), (2, 4, 10, 1, 8, 0, 0, 1), (4, 2, 11, 1, 2, 0, 0, 1), (4, 2, 3, 1, 2, 0, 0, 1),
      (2, 2, 11, 1, 4, 0, 0, 1), (2, 2, 12, 1, 4, 0, 0, 1), (2, 4, 10, 2, 8, 0, 0, 1), (4, 2, 11, 4, 2, 0, 0, 1),
-     (2, 4, 10, 1, 8, 0, 2, 1), (4, 4, 2, 1, 4, 0, 1, 0), (4, 2, 11, 1, 2, 0, 3, 0)] +
+     (2, 4, 10, 1, 8, 0, 2, 1), (4, 4, 2, 1, 4, 0, 1, 0), (4, 2, 11, 1, 2, 0, 3, 0),
+     (2, 4, 10, 1, 8, 0, 0, 3), (2, 4, 10, 2, 8, 0, 0, 3), (2, 4, 10, 4, 8, 0, 1, 3)] +
     # split-K of the tap-major kernels
     [(4, 4, 2, 3, 4, 0, 0, 0), (4, 2, 11, 2, 2, 0, 0, 0)])
 

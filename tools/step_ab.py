@@ -38,19 +38,20 @@ def only_conv(tag, name, *args):
     if name in ("sl_bias_grad", "sl_ctc_loss_grad", "sl_softmax_logq"): return
     real_launch(tag, name, *args)
 variants = {
-    "A adam after backward (main)": dict(early=False, adam=True, launch=real_launch),
-    "B early adam (side)": dict(early=True, adam=True, launch=real_launch),
-    "C no adam": dict(early=True, adam=False, launch=real_launch),
-    "D early adam, no bias grads": dict(early=True, adam=True, launch=no_bias),
-    "E no adam, no bias grads": dict(early=True, adam=False, launch=no_bias),
-    "F convs only": dict(early=True, adam=False, launch=only_conv),
+    "A default (Adam after backward, bias grads on side stream)": dict(early=False, adam=True, launch=real_launch, ow=False),
+    "B early adam (side stream)": dict(early=True, adam=True, launch=real_launch, ow=False),
+    "C no adam": dict(early=False, adam=False, launch=real_launch, ow=False),
+    "D no bias grads": dict(early=False, adam=True, launch=no_bias, ow=False),
+    "E wgrads on the side stream (overlap_wgrad)": dict(early=False, adam=True, launch=real_launch, ow=True),
+    "F convs only": dict(early=False, adam=False, launch=only_conv, ow=False),
 }
 res = {k: [] for k in variants}
 for rep in range(4):
     for k, v in variants.items():
         eng.early_adam = v["early"]
+        eng.overlap_wgrad = v["ow"]
         eng._adam_layers = real_adam if v["adam"] else (lambda layers, st: None)
         eng._launch = v["launch"]
         res[k].append(timed())
 for k, v in res.items():
-    print("%-34s median %.4f  min %.4f  all %s" % (k, statistics.median(v), min(v), [round(x, 3) for x in v]))
+    print("%-62s median %.4f  min %.4f  all %s" % (k, statistics.median(v), min(v), [round(x, 3) for x in v]))

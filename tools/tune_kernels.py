@@ -17,8 +17,9 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def cfg_word(wm, wn, stages, ksplit, it=4, m32=0, gml=0, slab=0):
-    return wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20) | (m32 << 24) | (gml << 25) | (slab << 29)
+def cfg_word(wm, wn, stages, ksplit, it=4, m32=0, gml=0, slab=0, ilv=0):
+    return (wm | (wn << 4) | (stages << 8) | (ksplit << 12) | (it << 20) | (m32 << 24) | (gml << 25) | (slab << 29) |
+            (ilv << 30))
 
 
 def main():
@@ -67,7 +68,7 @@ def main():
               (2, 2, 2, 32), (2, 2, 3, 32), (2, 2, 4, 32), (4, 2, 2, 32), (4, 2, 3, 32), (2, 4, 2, 32), (2, 4, 3, 32),
               (4, 4, 2, 32)]
     # slab variant (chunk-major, activation slab kept in LDS): it + 100
-    shapes += [(4, 4, 2, 104), (2, 4, 10, 108), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
+    shapes += [(4, 4, 2, 104), (2, 4, 10, 108), (2, 4, 10, 208), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
     results = {}
     n = len(eng.plans)
 
@@ -108,6 +109,7 @@ def main():
                 if slab and ks > geom.cin // 64:
                     continue
                 cfg = (cfg_word(wm, wn, stg, ks, 4, 1) if it == 32 else
+                       cfg_word(wm, wn, stg, ks, it - 200, slab=1, ilv=1) if it >= 200 else
                        cfg_word(wm, wn, stg, ks, it - 100, slab=1) if slab else cfg_word(wm, wn, stg, ks, it))
                 try:
                     out = run(kind, p, cfg)
