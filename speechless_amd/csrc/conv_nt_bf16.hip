@@ -180,13 +180,48 @@ __device__ __forceinline__ void load_bias16(const float* bias, int co, float (&b
     }
 }
 
+// Hand-interleaved half step: the 4*IT MFMAs of one k-half in groups of G, with ONE fragment read of the other k-half
+// issued after each of the first 4+IT groups and the hook (e.g. one LDS-DMA request) after every group.  Every group is
+// fenced (sched_barrier), so the LDS-read / DMA issue slots sit in the shadow of the matrix pipe instead of in a clump
+// between two MFMA blocks; PMC on the un-interleaved loops showed ~110 non-MFMA instructions per step and wave issued
+// while the pipe drained (pipe busy 65 % on the 256x256 tile).
+template <int IT, int G, int Q, int NQ>
+struct IlvPhase {
+    template <typename Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4 * IT], const bf16x8 (&ca)[4], const bf16x8 (&cb)[IT],
+                                               bf16x8 (&na)[4], bf16x8 (&nb)[IT], unsigned a_addr, unsigned b_addr,
+                                               const Hook& hook) {
+        static_assert(NQ * G == 4 * IT && NQ >= 4 + IT, "groups must cover the MFMAs and offer a slot per fragment read");
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int m = G * Q + j;
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[m / IT], cb[m % IT], acc[m], 0, 0, 0);
+        }
+        if constexpr (Q < 4)
+            ds_read128<Q * 512>(na[Q], a_addr);
+        else if constexpr (Q < 4 + IT)
+            ds_read128<(Q - 4) * 2048>(nb[Q - 4], b_addr);
+        hook(std::integral_constant<int, Q>{});
+        __builtin_amdgcn_sched_barrier(0);
+        IlvPhase<IT, G, Q + 1, NQ>::template run<Hook>(acc, ca, cb, na, nb, a_addr, b_addr, hook);
+    }
+};
+template <int IT, int G, int NQ>
+struct IlvPhase<IT, G, NQ, NQ> {
+    template <typename Hook>
+    static __device__ __forceinline__ void run(f32x4 (&)[4 * IT], const bf16x8 (&)[4], const bf16x8 (&)[IT], bf16x8 (&)[4],
+                                               bf16x8 (&)[IT], unsigned, unsigned, const Hook&) {}
+};
+
 // STAGES_P: low 3 bits = ring slots, bit 3 = register-pipelined main loop (fragments of the next tile's first half are
 // read from LDS while the MFMAs of the current tile's second half run, see the loop)
 template <bool M32, int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_bf16_kernel(NtArgs a) {
     constexpr int STAGES = STAGES_P & 7;
     constexpr bool PIPE = (STAGES_P & 8) != 0;
+    constexpr bool ILV = (STAGES_P & 16) != 0;  // hand-interleaved variant of the pipelined loop
     static_assert(STAGES >= 2, "ring too shallow");
+    static_assert(!ILV || (PIPE && !M32), "the interleaved schedule is a variant of the register-pipelined 16x16 loop");
     constexpr int NW = WM * WN;
     constexpr int WROWS = M32 ? 64 : 16 * IT;  // time rows per wave
     constexpr int BM = WROWS * WM;
@@ -352,7 +387,71 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     asm volatile("" : "+s"(e.y), "+s"(e.mask), "+s"(e.bias), "+s"(e.partial), "+s"(e.y_bs));
     asm volatile("" : "+s"(e.y_row0), "+s"(e.y_rs), "+s"(e.t_out), "+s"(e.cout), "+s"(e.batch), "+s"(e.t_tiles));
 
-    if constexpr (PIPE && !M32) {
+    if constexpr (ILV) {
+        // ---- interleaved schedule (see IlvPhase).  Per step and wave:
+        //   A: [a0,b0 ready] MFMAs of k-half 0, one fragment read of k-half 1 per group
+        //   lgkmcnt(0), counted vmcnt, barrier
+        //   B: MFMAs of k-half 1, per group one fragment read of the NEXT tile's k-half 0 and one LDS-DMA request of the
+        //      tile that re-uses this slot.  The request stream is branch-free: past the end of the split the last tile
+        //      is requested again into a slot nobody reads, so the vmcnt bookkeeping stays exact to the last step.
+        constexpr int G = (IT >= 4) ? 2 : 1;  // MFMAs per group: 4*IT / G groups must offer 4+IT read slots
+        constexpr int NQ = 4 * IT / G;
+        static_assert(NI <= NQ, "one DMA request per group");
+        const __bf16* xs_n = nullptr;
+        const __bf16* ws_n = nullptr;
+        char* xl_n = nullptr;
+        char* wl_n = nullptr;
+        auto begin_stage = [&](int local_step, int slot) {
+            const int st = s_begin + (local_step < n ? local_step : n - 1);
+            const int chunks = a.cin / BK;
+            const int tap = st / chunks;
+            const int cc = st - tap * chunks;
+            xs_n = xbase + (long)tap * a.x_rs + cc * BK;
+            ws_n = wbase + (long)st * BK;
+            xl_n = smem + slot * STAGE_BYTES + (wave * XPW) * 1024;
+            wl_n = smem + slot * STAGE_BYTES + X_BYTES + (wave * WPW) * 1024;
+        };
+        auto dma_piece = [&](auto q_c) {
+            constexpr int Q = decltype(q_c)::value;
+            if constexpr (Q < XPW)
+                glds16(xs_n + xoff[Q], xl_n + Q * 1024);
+            else if constexpr (Q < NI)
+                glds16(ws_n + woff[Q - XPW], wl_n + (Q - XPW) * 1024);
+        };
+        auto no_hook = [](auto) {};
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i) {
+            begin_stage(i, i);
+#pragma unroll
+            for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], xl_n + q * 1024);
+#pragma unroll
+            for (int q = 0; q < WPW; ++q) glds16(ws_n + woff[q], wl_n + q * 1024);
+        }
+        wait_vmcnt<NI*(STAGES - 1)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 a0[NA], b0[NB], a1[NA], b1[NB];
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        DsReadRun<0, NA, 512>::go(a0, lds0 + aoff);
+        DsReadRun<0, NB, 2048>::go(b0, lds0 + boff);
+        int cur = 0;
+        for (int i = 0; i < n; ++i) {
+            const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
+            wait_frags<0>(a0, b0);
+            IlvPhase<IT, G, 0, NQ>::run(acc, a0, b0, a1, b1, lds0 + cur * STAGE_BYTES + (aoff ^ 64),
+                                        lds0 + cur * STAGE_BYTES + (boff ^ 64), no_hook);
+            wait_frags<0>(a1, b1);  // my reads of slot cur are complete
+            wait_vmcnt<NI*(STAGES - 2)>();  // tile i+1 has landed; the younger ones stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            begin_stage(i + STAGES, cur);
+            IlvPhase<IT, G, 0, NQ>::run(acc, a1, b1, a0, b0, lds0 + nxt * STAGE_BYTES + aoff,
+                                        lds0 + nxt * STAGE_BYTES + boff, dma_piece);
+            cur = nxt;
+        }
+        wait_vmcnt<0>();        // the surplus requests still target this work-group's LDS
+        wait_frags<0>(a0, b0);  // ... and the surplus fragment reads these registers
+    } else if constexpr (PIPE && !M32) {
         // Register-pipelined ring.  All STAGES slots are filled up front; tile i's slot is refilled with tile
         // i+STAGES at the barrier in the MIDDLE of iteration i, by which time every wave has its whole tile i in
         // registers.  That same barrier publishes tile i+1, whose first-half fragments are then read from LDS while
@@ -471,35 +570,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         }
     }
 }
-
-// Hand-interleaved half step for the slab kernel: 4*IT MFMAs of one k-half in groups of two, with ONE fragment read
-// of the other k-half issued after each of the first 4+IT groups.  Every group is fenced (sched_barrier), so the
-// LDS-read issue slots sit in the shadow of the matrix pipe instead of in a clump between two MFMA blocks; PMC on the
-// un-interleaved loop showed ~110 non-MFMA instructions per step and wave issued while the pipe drained (pipe busy 65 %).
-template <int IT, int Q, int NQ>
-struct SlabPhase {
-    template <typename Hook>
-    static __device__ __forceinline__ void run(f32x4 (&acc)[4 * IT], const bf16x8 (&ca)[4], const bf16x8 (&cb)[IT],
-                                               bf16x8 (&na)[4], bf16x8 (&nb)[IT], unsigned a_addr, unsigned b_addr,
-                                               const Hook& hook) {
-        constexpr int M0 = 2 * Q, M1 = 2 * Q + 1;
-        acc[M0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[M0 / IT], cb[M0 % IT], acc[M0], 0, 0, 0);
-        acc[M1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[M1 / IT], cb[M1 % IT], acc[M1], 0, 0, 0);
-        if constexpr (Q < 4)
-            ds_read128<Q * 512>(na[Q], a_addr);
-        else if constexpr (Q < 4 + IT)
-            ds_read128<(Q - 4) * 2048>(nb[Q - 4], b_addr);
-        hook(std::integral_constant<int, Q>{});  // e.g. one LDS-DMA request of the next weight tile
-        __builtin_amdgcn_sched_barrier(0);
-        SlabPhase<IT, Q + 1, NQ>::template run<Hook>(acc, ca, cb, na, nb, a_addr, b_addr, hook);
-    }
-};
-template <int IT, int NQ>
-struct SlabPhase<IT, NQ, NQ> {
-    template <typename Hook>
-    static __device__ __forceinline__ void run(f32x4 (&)[4 * IT], const bf16x8 (&)[4], const bf16x8 (&)[IT], bf16x8 (&)[4],
-                                               bf16x8 (&)[IT], unsigned, unsigned, const Hook&) {}
-};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Slab variant (16x16x32 shape only).  Contraction order chunk OUTER, tap INNER: for one 64-channel chunk the BM + taps - 1
@@ -672,7 +742,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         for (int i = 0; i < n; ++i) {
             const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
             wait_frags<0>(a0, b0);
-            SlabPhase<IT, 0, 2 * IT>::run(acc, a0, b0, a1, b1, lds0 + ((aoff + cur * W_BYTES) ^ 64),
+            IlvPhase<IT, 2, 0, 2 * IT>::run(acc, a0, b0, a1, b1, lds0 + ((aoff + cur * W_BYTES) ^ 64),
                                           lds0 + (b_offset(par_c, tap_c) ^ 64), no_hook);
             wait_frags<0>(a1, b1);  // my reads of weight slot cur (and, on a chunk's last tap, of its slab) are complete
             wait_vmcnt<0>();
@@ -685,7 +755,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
             par_c = wrap ? par_c ^ 1 : par_c;
             tap_c = wrap ? 0 : tap_c + 1;
             begin_w(cur);
-            SlabPhase<IT, 0, 2 * IT>::run(acc, a1, b1, a0, b0, lds0 + aoff + nxt * W_BYTES, lds0 + b_offset(par_c, tap_c),
+            IlvPhase<IT, 2, 0, 2 * IT>::run(acc, a1, b1, a0, b0, lds0 + aoff + nxt * W_BYTES, lds0 + b_offset(par_c, tap_c),
                                           dma_hook);
             cur = nxt;
         }
@@ -997,9 +1067,9 @@ Cfg auto_cfg(const sl_conv_geom* g) {
         const bool slab_ok = g->taps >= 2 && g->taps <= 33;
         // 256x256 tile, one work-group per CU.  With taps the slab variant (8 waves of 128x64, register-pipelined,
         // hand-interleaved MFMA / LDS-read / DMA-request stream): big_conv_1 forward 0.334 ms = 1.53 PFLOP/s (0.345
-        // un-interleaved, 0.372 for the 16-wave tap-major kernel); 1x1 layers keep the 16-wave kernel (1.19 PFLOP/s
-        // on big_conv_2)
-        if (tiles256 >= 192) return slab_ok ? Cfg{2, 4, 10, 1, 8, 0, 0, 1, 1} : Cfg{4, 4, 2, 1, 4, 0};
+        // un-interleaved, 0.372 for the 16-wave tap-major kernel); 1x1 layers: the same 8-wave tile, tap-major,
+        // interleaved (big_conv_2 forward 0.104 ms = 1.24 PFLOP/s, 0.107 for the 16-wave kernel)
+        if (tiles256 >= 192) return slab_ok ? Cfg{2, 4, 10, 1, 8, 0, 0, 1, 1} : Cfg{2, 4, 10, 1, 8, 0, 0, 0, 1};
         if (nsteps >= 256) {  // long contraction but few tiles (dgrad of big_conv_1: 64 tiles, K = 65536): split K
             long ks = (256 + tiles256 - 1) / tiles256;
             if (ks > 8) ks = 8;
@@ -1008,9 +1078,10 @@ Cfg auto_cfg(const sl_conv_geom* g) {
             return Cfg{4, 4, 2, (int)ks, 4, 0};
         }
     }
-    // short layers (one 128x128 tile per CU at most): 8 waves of 32x64 per tile (two waves per SIMD), 3-slot ring,
-    // register-pipelined loop with hand-counted LDS waits: 18.8 us per 250-channel layer against 20.7 for the plain loop
-    return Cfg{4, 2, 11, 1, 2, 0};
+    // short layers (one 128x128 tile per CU at most): 4 waves of 64x64, 3-slot ring, register-pipelined and
+    // hand-interleaved: 17.7 us per 250-channel layer (8 waves of 32x64 un-interleaved 18.8, plain loop 20.7);
+    // striding_conv 48.5 us (54.0)
+    return Cfg{2, 2, 11, 1, 4, 0, 0, 0, 1};
 }
 
 bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
@@ -1038,7 +1109,13 @@ bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
     if (!shape || c.ksplit < 1) return false;
     if (g->cout % (64 * c.wn)) return false;
     const long nsteps = (long)g->taps * (g->cin / BK);
-    if (c.ilv && !(c.slab && !c.m32 && c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10)) return false;
+    if (c.ilv) {  // instantiated interleaved shapes: the slab 256x256 kernel and three tap-major pipelined tiles
+        const bool slab_ilv = c.slab && !c.m32 && c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10;
+        const bool tap_ilv = !c.slab && !c.m32 && (full.stages & 8) &&
+                             ((c.it == 2 && c.wm == 4 && c.wn == 2) || (c.it == 4 && c.wm == 2 && c.wn == 2) ||
+                              (c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10));
+        if (!slab_ilv && !tap_ilv) return false;
+    }
     if (c.slab) {
         // instantiated slab shapes; the slab holds BM + 32 rows and its DMA must be older than the next chunk's tiles
         const bool inst = !c.m32 && ((c.it == 4 && c.wm == 4 && c.wn == 4 && full.stages == 2) ||
@@ -1123,6 +1200,17 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
         sl_set_error("sl_conv1d_nt(bf16): slab configuration not instantiated");
         return SL_ERR_UNSUPPORTED;
     }
+#define SL_NT_ILV_CASE(IT_, WM_, WN_, ST_)                                          \
+    if (!c.slab && c.ilv && c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
+        return launch_cfg<false, IT_, WM_, WN_, (ST_ | 16)>(a, epilogue, out_f32, s);
+    SL_NT_ILV_CASE(2, 4, 2, 10)
+    SL_NT_ILV_CASE(2, 4, 2, 11)
+    SL_NT_ILV_CASE(2, 4, 2, 12)
+    SL_NT_ILV_CASE(4, 2, 2, 10)
+    SL_NT_ILV_CASE(4, 2, 2, 11)
+    SL_NT_ILV_CASE(4, 2, 2, 12)
+    SL_NT_ILV_CASE(8, 2, 4, 10)
+#undef SL_NT_ILV_CASE
 #define SL_NT_CASE(M32_, IT_, WM_, WN_, ST_)                                                \
     if (c.m32 == M32_ && c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
         return launch_cfg<(M32_ != 0), IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);

@@ -638,7 +638,10 @@ NT_CONFIGS = (
     [(4, 4, 2, 1, 4, 0, 0, 1), (2, 4, 10, 1, 8, 0, 0, 1), (4, 2, 11, 1, 2, 0, 0, 1), (4, 2, 3, 1, 2, 0, 0, 1),
      (2, 2, 11, 1, 4, 0, 0, 1), (2, 2, 12, 1, 4, 0, 0, 1), (2, 4, 10, 2, 8, 0, 0, 1), (4, 2, 11, 4, 2, 0, 0, 1),
      (2, 4, 10, 1, 8, 0, 2, 1), (4, 4, 2, 1, 4, 0, 1, 0), (4, 2, 11, 1, 2, 0, 3, 0),
-     (2, 4, 10, 1, 8, 0, 0, 3), (2, 4, 10, 2, 8, 0, 0, 3), (2, 4, 10, 4, 8, 0, 1, 3)] +
+     (2, 4, 10, 1, 8, 0, 0, 3), (2, 4, 10, 2, 8, 0, 0, 3), (2, 4, 10, 4, 8, 0, 1, 3),
+     # interleaved tap-major (slab = 2: only the interleave bit)
+     (4, 2, 10, 1, 2, 0, 0, 2), (4, 2, 11, 1, 2, 0, 0, 2), (4, 2, 12, 2, 2, 0, 0, 2), (2, 2, 10, 1, 4, 0, 0, 2),
+     (2, 2, 11, 1, 4, 0, 0, 2), (2, 2, 12, 1, 4, 0, 0, 2), (2, 4, 10, 1, 8, 0, 0, 2)] +
     # split-K of the tap-major kernels
     [(4, 4, 2, 3, 4, 0, 0, 0), (4, 2, 11, 2, 2, 0, 0, 0)])
 

@@ -68,7 +68,9 @@ def main():
               (2, 2, 2, 32), (2, 2, 3, 32), (2, 2, 4, 32), (4, 2, 2, 32), (4, 2, 3, 32), (2, 4, 2, 32), (2, 4, 3, 32),
               (4, 4, 2, 32)]
     # slab variant (chunk-major, activation slab kept in LDS): it + 100
-    shapes += [(4, 4, 2, 104), (2, 4, 10, 108), (2, 4, 10, 208), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
+    shapes += [(4, 2, 10, 302), (4, 2, 11, 302), (4, 2, 12, 302), (2, 2, 10, 304), (2, 2, 11, 304), (2, 2, 12, 304),
+               (2, 4, 10, 308),  # it + 300: interleaved tap-major
+               (4, 4, 2, 104), (2, 4, 10, 108), (2, 4, 10, 208), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
     results = {}
     n = len(eng.plans)
 
@@ -100,7 +102,7 @@ def main():
         for (wm, wn, stg, it) in shapes:
             if geom.cout % (64 * wn):
                 continue
-            slab = it >= 100
+            slab = 100 <= it < 300
             if slab and (geom.taps < (stg & 7) or geom.taps > 33):
                 continue
             for ks in (1, 2, 4, 8):
@@ -109,6 +111,7 @@ def main():
                 if slab and ks > geom.cin // 64:
                     continue
                 cfg = (cfg_word(wm, wn, stg, ks, 4, 1) if it == 32 else
+                       cfg_word(wm, wn, stg, ks, it - 300, ilv=1) if it >= 300 else
                        cfg_word(wm, wn, stg, ks, it - 200, slab=1, ilv=1) if it >= 200 else
                        cfg_word(wm, wn, stg, ks, it - 100, slab=1) if slab else cfg_word(wm, wn, stg, ks, it))
                 try:
