@@ -258,7 +258,7 @@ def main():
         "kernels": groups,
     }
     if args.config == 3:
-        # Dominant kernel (largest share of GPU time in profiles/r01g_kernel_stats.csv): wgrad_tn_bf16_kernel<4,4,2>,
+        # Dominant kernel (largest share of GPU time in profiles/r01h_kernel_stats.csv): wgrad_tn_bf16_kernel<4,4,2>,
         # the 256x256-tile weight-gradient kernel.  THREE launches per step use this instantiation (the library's
         # measured table picks it for big_conv_1, big_conv_2 and for the grouped launch that covers the seven
         # inner_conv_i); algorithmic FLOPs per launch = (sum of those nine layers' wgrad FLOPs) / 3.
@@ -269,7 +269,7 @@ def main():
         dom_ms = sum(live_ms[t] for t in dom_tags) / len(dom_tags)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         traffic = None
-        pmc = ROOT / "profiles" / "r01g_pmc_traffic_wgrad442.json"
+        pmc = ROOT / "profiles" / "r01h_pmc_traffic_wgrad442.json"
         if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 correction)
             traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
         result["roofline"] = {
@@ -279,16 +279,16 @@ def main():
             "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
             "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits included), "
-                            "average of its three launches per step, profiles/r01g_pmc_traffic_wgrad442.json "
+                            "average of its three launches per step, profiles/r01h_pmc_traffic_wgrad442.json "
                             "(tools/pmc_traffic.sh)",
             "duration_note": "HIP events around the sl_conv1d_wgrad call on its stream: the kernel plus, for "
                              "batch-split launches, the deterministic wgrad_reduce_grouped_kernel tail (rocprofv3: "
-                             "196.6 us kernel + 17 us reduce per launch in profiles/r01g_kernel_stats.csv)",
+                             "199.9 us kernel + 17 us reduce per launch in profiles/r01h_kernel_stats.csv)",
             "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms}
     if args.config in (2, 3):
         nt_flops = fl[names.index("big_conv_1")] * BATCH_PER_GPU
         nt_ms = live_ms["fwd:big_conv_1"]
-        nt = {"bound": "mfma", "kernel": "conv_nt_slab_bf16_kernel<IT=8,WM=2,WN=4,STAGES=2|pipelined,BIAS_RELU,bf16> "
+        nt = {"bound": "mfma", "kernel": "conv_nt_slab_bf16_kernel<IT=8,WM=2,WN=4,STAGES=2|pipelined,BIAS_RELU,bf16,interleaved> "
                                          "(forward of big_conv_1)",
               "achieved": nt_flops / (nt_ms * 1e-3) / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
               "frac": nt_flops / (nt_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
