@@ -249,6 +249,199 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Interleaved 256x256 variant: 8 waves, each a 128 (input channels) x 64 (output channels) patch = 32 accumulator tiles,
+// two waves per SIMD with 256 registers each.  A 64-row step is two k-halves; the fragments of the other half (12
+// transpose-read pairs) are requested one pair per two MFMAs, and after the barrier one LDS-DMA request of the next
+// tile rides behind each of the first eight MFMA pairs -- the issue slots of the LDS / DMA instructions sit in the
+// shadow of the matrix pipe (same scheme as IlvPhase in conv_nt_bf16.hip).  Fewer LDS bytes per MFMA than the 16-wave
+// kernel (24 fragment reads per 64 MFMAs instead of 16 per 32).
+struct TrFrags {
+    s16x4 gl[4], gh[4];  // gradient fragments (MFMA A operand): 4 x 16 output channels
+    s16x4 xl[8], xh[8];  // activation fragments (MFMA B operand): 8 x 16 input channels
+};
+__device__ __forceinline__ void wait_trfrags(TrFrags& f) {  // lgkmcnt(0) tied to all 24 half-fragments
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.gl[0]), "+v"(f.gh[0]), "+v"(f.gl[1]), "+v"(f.gh[1]), "+v"(f.gl[2]), "+v"(f.gh[2]), "+v"(f.gl[3]),
+                   "+v"(f.gh[3]), "+v"(f.xl[0]), "+v"(f.xh[0]), "+v"(f.xl[1]), "+v"(f.xh[1]), "+v"(f.xl[2]), "+v"(f.xh[2]),
+                   "+v"(f.xl[3]), "+v"(f.xh[3]), "+v"(f.xl[4]), "+v"(f.xh[4]), "+v"(f.xl[5]), "+v"(f.xh[5]), "+v"(f.xl[6]),
+                   "+v"(f.xh[6]), "+v"(f.xl[7]), "+v"(f.xh[7]));
+}
+
+template <int KK, int Q, int NQ>
+struct TrPhase {
+    // KK = k-half the READS address (the MFMAs consume `cur`); group Q = MFMAs 2Q, 2Q+1 (jn = m / 8, it = m % 8)
+    template <typename Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4][8], TrFrags& cur, TrFrags& nxt, const unsigned (&gaddr)[4],
+                                               const unsigned (&xaddr)[8], const Hook& hook) {
+        constexpr int GRB = 512, XRB = 512;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = 2 * Q + j;
+            const int jn = m / 8, it = m % 8;
+            acc[jn][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(cur.gl[jn], cur.gh[jn]), frag8(cur.xl[it], cur.xh[it]),
+                                                                  acc[jn][it], 0, 0, 0);
+        }
+        if constexpr (Q < 4)
+            tr_read8<KK * 32 * GRB, GRB>(nxt.gl[Q], nxt.gh[Q], gaddr[Q]);
+        else if constexpr (Q < 12)
+            tr_read8<KK * 32 * XRB, XRB>(nxt.xl[Q - 4], nxt.xh[Q - 4], xaddr[Q - 4]);
+        hook(std::integral_constant<int, Q>{});
+        __builtin_amdgcn_sched_barrier(0);
+        TrPhase<KK, Q + 1, NQ>::template run<Hook>(acc, cur, nxt, gaddr, xaddr, hook);
+    }
+};
+template <int KK, int NQ>
+struct TrPhase<KK, NQ, NQ> {
+    template <typename Hook>
+    static __device__ __forceinline__ void run(f32x4 (&)[4][8], TrFrags&, TrFrags&, const unsigned (&)[4],
+                                               const unsigned (&)[8], const Hook&) {}
+};
+
+__global__ __launch_bounds__(512, 2) void wgrad_tn_ilv_kernel(TnArgs a) {
+    constexpr int NW = 8, STAGES = 2;
+    constexpr int TCI = 256, TCO = 256;
+    constexpr int XRB = 512, GRB = 512;
+    constexpr int X_BYTES = TK * XRB;
+    constexpr int STAGE_BYTES = TK * (XRB + GRB);
+    constexpr int XPW = 32 / NW, GPW = 32 / NW;  // 1-KiB DMA instructions per wave per stage and operand
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;  // 128-channel block of ci
+    const int wn = wave & 3;   // 64-channel block of co
+    const int g = lane >> 4;
+
+    int wg = xcd_remap(blockIdx.x, a.tiles * a.splits * a.groups);
+    if (wg >= a.tiles * a.splits * a.groups) return;  // grid padding (xcd_grid)
+    const int group = wg / (a.tiles * a.splits);
+    wg -= group * (a.tiles * a.splits);
+    const int tap = wg % a.taps;
+    wg /= a.taps;
+    const int ci_tile = wg % a.ci_tiles;
+    wg /= a.ci_tiles;
+    const int co_tile = wg % a.co_tiles;
+    const int split = wg / a.co_tiles;
+    const int b_begin = split * a.b_per_split;
+    int b_end = b_begin + a.b_per_split;
+    if (b_end > a.batch) b_end = a.batch;
+    const int n = (b_end - b_begin) * a.t_chunks;
+
+    int xoff[XPW], goff_src[GPW];
+#pragma unroll
+    for (int q = 0; q < XPW; ++q) xoff[q] = dma_src_offset<4>(wave * XPW + q, lane, a.x_rs);
+#pragma unroll
+    for (int q = 0; q < GPW; ++q) goff_src[q] = dma_src_offset<4>(wave * GPW + q, lane, a.g_rs);
+    const __bf16* xbase = a.x + group * a.x_gs + (long)(a.x_row0 + tap) * a.x_rs + ci_tile * TCI;
+    const __bf16* gbase = a.g + group * a.g_gs + (long)a.g_row0 * a.g_rs + co_tile * TCO;
+
+    const __bf16* xs_n = nullptr;
+    const __bf16* gs_n = nullptr;
+    char* xl_n = nullptr;
+    char* gl_n = nullptr;
+    auto begin_stage = [&](int step, int buf) {  // past the end the last tile is requested again (dead slot)
+        const int st = step < n ? step : n - 1;
+        const int bb = st / a.t_chunks;
+        const int tc = st - bb * a.t_chunks;
+        const int b = b_begin + bb;
+        xs_n = xbase + (long)b * a.x_bs + (long)(tc * TK) * a.x_rs;
+        gs_n = gbase + (long)b * a.g_bs + (long)(tc * TK) * a.g_rs;
+        xl_n = smem + buf * STAGE_BYTES + (wave * XPW) * 1024;
+        gl_n = smem + buf * STAGE_BYTES + X_BYTES + (wave * GPW) * 1024;
+    };
+    auto dma_piece = [&](auto q_c) {
+        constexpr int Q = decltype(q_c)::value;
+        if constexpr (Q < XPW)
+            glds16(xs_n + xoff[Q], xl_n + Q * 1024);
+        else if constexpr (Q < XPW + GPW)
+            glds16(gs_n + goff_src[Q - XPW], gl_n + (Q - XPW) * 1024);
+    };
+    auto no_hook = [](auto) {};
+
+    const int i16 = lane & 15;
+    const int rkey = (i16 >> 2) | ((g & 1) << 2);
+    const int rrow = g * 8 + (i16 >> 2);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    unsigned xrel[8], grel[4];  // read offsets inside a stage (k-half 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xrel[j] = rrow * XRB + (((wm * 8 + j) ^ rkey) * 32) + (i16 & 3) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) grel[j] = X_BYTES + rrow * GRB + (((wn * 4 + j) ^ rkey) * 32) + (i16 & 3) * 8;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (n > 0) {
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i) {
+            begin_stage(i, i);
+#pragma unroll
+            for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], xl_n + q * 1024);
+#pragma unroll
+            for (int q = 0; q < GPW; ++q) glds16(gs_n + goff_src[q], gl_n + q * 1024);
+        }
+        wait_vmcnt<(XPW + GPW) * (STAGES - 1)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TrFrags f0, f1;
+        unsigned ga[4], xa[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_read8<0, GRB>(f0.gl[j], f0.gh[j], lds0 + grel[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tr_read8<0, XRB>(f0.xl[j], f0.xh[j], lds0 + xrel[j]);
+        int cur = 0;
+        for (int i = 0; i < n; ++i) {
+            const int nxt = cur ^ 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ga[j] = lds0 + cur * STAGE_BYTES + grel[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[j] = lds0 + cur * STAGE_BYTES + xrel[j];
+            wait_trfrags(f0);
+            TrPhase<1, 0, 16>::run(acc, f0, f1, ga, xa, no_hook);  // k-half 0 multiplies, k-half 1 is read
+            wait_trfrags(f1);  // my reads of slot cur are complete
+            wait_vmcnt<0>();   // tile i+1 has landed (2-slot ring)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            begin_stage(i + STAGES, cur);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ga[j] = lds0 + nxt * STAGE_BYTES + grel[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[j] = lds0 + nxt * STAGE_BYTES + xrel[j];
+            TrPhase<0, 0, 16>::run(acc, f1, f0, ga, xa, dma_piece);  // k-half 1 multiplies, next tile's k-half 0 is read
+            cur = nxt;
+        }
+        wait_vmcnt<0>();   // the surplus requests still target this work-group's LDS
+        wait_trfrags(f0);  // ... and the surplus fragment reads these registers
+    }
+
+    // ---- store: lane holds co = co_base + jn*16 + g*4 + {0..3} for ci = ci_base + it*16 + (lane & 15)
+    float* out = a.splits > 1 ? a.out + ((long)group * a.splits + split) * a.split_stride : a.out + group * a.dw_gs;
+    const int ci_base = ci_tile * TCI + wm * 128 + (lane & 15);
+    const int co_base = co_tile * TCO + wn * 64 + g * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const long row = ((long)tap * a.cin + ci_base + it * 16) * a.cout;
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) *(f32x4*)(out + row + co_base + jn * 16) = acc[jn][it];
+    }
+}
+
+int launch_ilv(const TnArgs& a, hipStream_t s) {
+    constexpr int LDS_BYTES = 2 * TK * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_ilv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_tn_ilv_kernel, dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(512), LDS_BYTES, s, a);
+    return sl_check_launch("sl_conv1d_wgrad(bf16, interleaved)");
+}
+
 template <int WM, int WN, int STAGES>
 int launch(const TnArgs& a, hipStream_t s) {
     constexpr int LDS_BYTES = STAGES * TK * 128 * (WM + WN);
@@ -289,9 +482,10 @@ WCfg auto_wcfg(const sl_conv_geom* g, int groups) {
     // measured on MI355X with tools/tune_kernels.py (profiles/r01_tune_kernels.json), see DESIGN.md section 3
     if (g->cin % 256 == 0 && g->cout % 256 == 0) {
         const long tiles256 = (long)g->taps * (g->cin / 256) * (g->cout / 256) * groups;
-        // 256x256 tile, 16 waves: big_conv_1 1376 TFLOP/s (128x128: 1140), big_conv_2 1105 (128x128: 1121);
-        // striding_conv (24 such tiles) is better off with 128x128 tiles and 4 batch splits: 0.061 vs 0.065 ms
-        if (tiles256 >= 48) return WCfg{4, 4, 2, choose_splits(g, 256, 256, 256, groups)};
+        // 256x256 tile, 8 waves, interleaved stream: big_conv_1 0.351 ms = 1.46 PFLOP/s (16-wave kernel 0.363, 128x128
+        // tiles 0.45); the grouped inner-layer launch 0.1175 ms (16-wave 0.123).  big_conv_2 (64 such tiles) and
+        // striding_conv (24) are better off with 128x128 tiles and a batch split: 0.107 vs 0.110 ms, 0.062 vs 0.066 ms
+        if (tiles256 >= 128 || (groups > 1 && tiles256 >= 48)) return WCfg{4, 4, 10, choose_splits(g, 256, 256, 256, groups)};
     }
     // short layers: 128x128 tiles, batch split so that ~2 work-groups land on every CU (deeper rings measured no gain)
     return WCfg{2, 2, 2, choose_splits(g, 128, 128, 512, groups)};
@@ -301,7 +495,7 @@ bool valid_wcfg(const WCfg& c, const sl_conv_geom* g) {
     const bool shape = (c.wm == 2 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) ||
                        (c.wm == 4 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
                        (c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
-                       (c.wm == 4 && c.wn == 4 && c.stages == 2);
+                       (c.wm == 4 && c.wn == 4 && (c.stages == 2 || c.stages == 10));  // 10: 8-wave interleaved kernel
     return shape && g->cin % (64 * c.wm) == 0 && g->cout % (64 * c.wn) == 0 && c.splits >= 1 && c.splits <= g->batch;
 }
 
@@ -405,6 +599,7 @@ int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* 
     SL_TN_CASE(2, 4, 3)
     SL_TN_CASE(4, 4, 2)
 #undef SL_TN_CASE
+    if (c.wm == 4 && c.wn == 4 && c.stages == 10) rc = launch_ilv(a, s);
     if (rc != SL_OK) return rc;
     if (a.splits > 1) {
         const long n4 = a.split_stride / 4;

@@ -700,7 +700,8 @@ def test_every_nt_tile_configuration_against_float64(hip_lib, taps, t_out, batch
     assert ran >= len(NT_CONFIGS) - 8
 
 
-WGRAD_CONFIGS = [(2, 2, 2), (2, 2, 3), (2, 2, 4), (4, 2, 2), (4, 2, 3), (2, 4, 2), (2, 4, 3), (4, 4, 2)]
+WGRAD_CONFIGS = [(2, 2, 2), (2, 2, 3), (2, 2, 4), (4, 2, 2), (4, 2, 3), (2, 4, 2), (2, 4, 3), (4, 4, 2),
+                 (4, 4, 10)]  # stages 10: the 8-wave interleaved 256x256 kernel
 
 
 @pytest.mark.parametrize("taps,t_out,batch,groups", [(7, 200, 6, 1), (3, 130, 5, 3), (1, 64, 4, 1)])

@@ -157,7 +157,8 @@ def main():
         run_w(cfg_word(2, 2, 2, 0, 0))
         ref = dw.clone()
         rows = []
-        for (wm, wn, stg) in [(2, 2, 2), (2, 2, 3), (2, 2, 4), (4, 2, 2), (4, 2, 3), (2, 4, 2), (2, 4, 3), (4, 4, 2)]:
+        for (wm, wn, stg) in [(2, 2, 2), (2, 2, 3), (2, 2, 4), (4, 2, 2), (4, 2, 3), (2, 4, 2), (2, 4, 3), (4, 4, 2),
+                              (4, 4, 10)]:
             if geom.cin % (64 * wm) or geom.cout % (64 * wn):
                 continue
             for sp in (0, 1, 2, 4, 8, 16, 32):
