@@ -112,3 +112,28 @@ def test_batchnorm_folds_into_the_fused_conv_bias_relu_epilogue():
     assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
     with pytest.raises(ValueError):
         fold_batchnorm_into_conv(w, b, gamma[:3], beta, mean, var)
+
+
+def test_keras_h5_checkpoints_convert_to_the_npz_the_net_loads(tmp_path):
+    """tools/h5_to_npz.py (numpy + h5py only; run under an interpreter that has h5py) turns a Keras-layout weight file
+    into the .npz layout of PredictiveNet.load_weights, and back."""
+    import shutil
+    import subprocess
+    py = shutil.which("python3.9", path="/opt/conda/bin") or shutil.which("python3.9")
+    if py is None or subprocess.run([py, "-c", "import h5py"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with h5py in this image")
+    tool = str(Path(__file__).resolve().parent.parent / "tools" / "h5_to_npz.py")
+    rng = np.random.RandomState(0)
+    layers = {"striding_conv": (48, 128, 250), "inner_conv_1": (7, 250, 250), "output_conv": (1, 2000, 29)}
+    npz = tmp_path / "weights-epoch3.npz"
+    np.savez(npz, **{n + "/kernel": rng.randn(*sh).astype(np.float32) for n, sh in layers.items()},
+             **{n + "/bias": rng.randn(sh[2]).astype(np.float32) for n, sh in layers.items()})
+    h5 = tmp_path / "weights-epoch3.h5"
+    assert subprocess.run([py, tool, "--reverse", str(npz), str(h5)], capture_output=True).returncode == 0
+    back = tmp_path / "back.npz"
+    res = subprocess.run([py, tool, str(h5), str(back)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    a, b = np.load(npz), np.load(back)
+    assert sorted(a.files) == sorted(b.files)
+    for key in a.files:
+        assert np.array_equal(a[key], b[key])
