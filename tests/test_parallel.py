@@ -91,3 +91,67 @@ def test_single_process_reducer_is_a_no_op():
     reducer.reduce_bucket(1)
     reducer.wait_all()
     assert torch.equal(flat, torch.arange(10, dtype=torch.float32))
+
+
+# ------------------------------------------------------------------------------------------ the real engine, two ranks
+def _engine_case():
+    from oracle import w2l_oracle as o
+    from speechless_amd.engine import wav2letter_layer_specs
+    specs = wav2letter_layer_specs(128, 29)
+    weights = o.glorot_uniform_weights(o.layer_specs(128, 29), seed=2, dtype=np.float32)
+    rng = np.random.RandomState(7)
+    x = rng.randn(4, 120, 128).astype(np.float32)
+    lab_len = np.array([9, 4, 12, 7], dtype=np.int32)
+    labels = -np.ones((4, 12), dtype=np.int32)
+    for i, n in enumerate(lab_len):
+        labels[i, :n] = rng.randint(0, 28, size=n)
+    pred_len = np.array([60, 57, 60, 55], dtype=np.int32)
+    return specs, weights, x, labels, lab_len, pred_len
+
+
+def _engine_worker(rank, world, port, out_dir):
+    from speechless_amd.engine import Engine
+    from speechless_amd.parallel import GradBucketReducer, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share cuda:0: gloo moves the bytes
+    specs, weights, x, labels, lab_len, pred_len = _engine_case()
+    eng = Engine(specs, 29, dtype="f32", device="cuda:0", lr=1e-3)
+    eng.set_weights(weights)
+    ranges, _ = eng.bucket_ranges()
+    reducer = GradBucketReducer(eng.grads, ranges)
+    lo, hi = shard_range(x.shape[0], rank, world)
+    for _ in range(2):
+        eng.train_step(x[lo:hi], labels[lo:hi], lab_len[lo:hi], pred_len[lo:hi], reducer)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), *[w for w, _ in eng.get_weights()])
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_engine_ranks_equal_one_rank_on_the_global_batch(tmp_path):
+    """Two processes, each running the real HIP engine on its utterance shard with the bucketed, overlapped gradient
+    all-reduce (gloo transport, both on the one GPU of the test box), must end up with the weights of a single process
+    that trained on the global batch: same gradient scale (1 / (B_local * world)), same bucket ranges, same Adam."""
+    from speechless_amd.engine import Engine
+    world = 2
+    mp.spawn(_engine_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    specs, weights, x, labels, lab_len, pred_len = _engine_case()
+    eng = Engine(specs, 29, dtype="f32", device="cuda:0", lr=1e-3)
+    eng.set_weights(weights)
+    for _ in range(2):
+        eng.train_step(x, labels, lab_len, pred_len)
+    torch.cuda.synchronize()
+    ref = [w for w, _ in eng.get_weights()]
+    moved = 0.0
+    for rank in range(world):
+        got = np.load(str(tmp_path / "rank{}.npz".format(rank)))
+        for i, r in enumerate(ref):
+            g = got["arr_{}".format(i)]
+            # identical up to the fp32 summation order of the gradient (two partial sums added by the all-reduce); Adam's
+            # m / sqrt(v) amplifies that for the few elements whose gradient is ~0, hence a bound relative to the step
+            step_size = np.abs(r - weights[i][0]).max()
+            diff = np.abs(g - r)
+            assert diff.max() <= 2e-2 * step_size and np.mean(diff > 1e-3 * step_size) < 1e-3, (rank, i, diff.max())
+            moved = max(moved, float(np.abs(r - weights[i][0]).max()))
+    assert moved > 1e-4  # the steps did change the weights
