@@ -722,7 +722,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         auto no_hook = [](auto) {};
         auto dma_hook = [&](auto q_c) {  // groups 0..WPW-1 of phase B each carry one request of the tile
             constexpr int Q = decltype(q_c)::value;
+#if defined(SL_PROBE_NO_DMA)  // timing probes only (wrong results): how much of the step is waiting for the weight stream
+            (void)q_c;
+#elif defined(SL_PROBE_HALF_DMA)
+            if constexpr (Q < WPW / 2) glds16(ws_next + woff[Q], wl_next + Q * 1024);
+#else
             if constexpr (Q < WPW) glds16(ws_next + woff[Q], wl_next + Q * 1024);
+#endif
         };
         issue_slab(c0, 0);
 #pragma unroll
