@@ -26,7 +26,13 @@
 //   * split-K (over taps x chunks) when the tile count cannot fill the chip (dgrad of big_conv_1: K = 65536, 64 tiles):
 //     fp32 partial tiles go to a workspace and nt_splitk_epilogue_kernel reduces them in a fixed order and applies the
 //     epilogue (deterministic).
-//   * blockIdx -> tile mapping is XCD-aware: an XCD's work-groups share weight tiles in its private L2.
+//   * blockIdx -> tile mapping is XCD-aware (xcd_remap + a 2-D raster): an XCD's work-groups share weight panels and
+//     activation rows in its private L2; grids are padded to a multiple of 8 so that this holds for any tile count.
+//   * three loop flavours per tile shape (stages field of the cfg word): plain ring (compiler-scheduled LDS reads);
+//     register-pipelined (+8: fragments read through inline asm with hand-counted lgkmcnt, barrier in the middle of a
+//     step); interleaved (cfg bit 30: IlvPhase, one LDS read / DMA request behind every one or two MFMAs).
+//   * conv_nt_slab_bf16_kernel (cfg bit 29) is the chunk-major variant that keeps the activation rows of all taps in LDS.
+//   The library's measured table (auto_cfg) picks shape, flavour and kernel per launch; tools/tune_kernels.py sweeps them.
 #include "common.h"
 
 #include <type_traits>
@@ -845,7 +851,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
             if (tap_c == 0 && has_next_chunk) issue_slab(c0 + chunk_c + 1, par_c ^ 1);
             if (i + STAGES - 1 < n) issue_next_w(nxt);
             const char* wl = smem + cur * W_BYTES;
-            const char* xl = smem + b_offset(par_c, tap_c);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8 af[4], bfr[IT];
@@ -856,7 +861,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
                     bfr[it] = *(const bf16x8*)(smem + ((b_offset(par_c, tap_c) + it * 2048) ^ (kk << 6)));
                 mma_half(af, bfr);
             }
-            (void)xl;
             if (++tap_c == taps) {
                 tap_c = 0;
                 par_c ^= 1;
