@@ -8,6 +8,9 @@ from pathlib import Path
 PACKAGE_DIR = Path(__file__).resolve().parent
 CSRC = PACKAGE_DIR / "csrc"
 LIB_PATH = PACKAGE_DIR / "libspeechless_hip.so"
+HOST_LIB_PATH = PACKAGE_DIR / "libspeechless_host.so"  # plain C++ helpers of the host input pipeline (no HIP)
+HOST_SOURCES = [PACKAGE_DIR / "csrc_host" / "pack_batch.cpp"]
+CXX = os.environ.get("CXX", "g++")
 SOURCES = ["capi.hip", "conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_f32.hip", "ctc.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
@@ -56,7 +59,20 @@ def _compile(src):
     return obj, err
 
 
+def build_host(force=False):
+    newest = max(f.stat().st_mtime for f in HOST_SOURCES)
+    if not force and HOST_LIB_PATH.exists() and HOST_LIB_PATH.stat().st_mtime >= newest:
+        return HOST_LIB_PATH
+    cmd = [CXX, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-o", str(HOST_LIB_PATH)] + \
+        [str(f) for f in HOST_SOURCES]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("host library build failed:\n{}\n{}".format(res.stdout, res.stderr))
+    return HOST_LIB_PATH
+
+
 def build(force=False, verbose=False):
+    build_host(force)
     if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= _newest_source_mtime():
         return LIB_PATH
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:

@@ -1,0 +1,61 @@
+// pack_batch.cpp -- host-side batch packer of the input pipeline (speechless_amd/pipeline.py).
+//
+// Replaces, for the staged pipeline, the numpy loop of the reference's _input_batch_and_prediction_lengths
+// (speechless/net.py:578-587): B spectrograms (T_i, F) in float64 or float32 are converted to float32 and zero-padded
+// into one (B, Tmax, F) staging buffer.  Plain C++ with a few std::threads; called through ctypes, which releases the
+// GIL for the duration of the call -- the Python version of this loop fought the training thread for the GIL and capped
+// the end-to-end rate at ~11 k utt/s with a 13 k utt/s GPU step.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+template <typename T>
+void pack_rows(const void* const* src, const int32_t* lengths, int b0, int b1, int f, int t_max, float* dst) {
+    for (int b = b0; b < b1; ++b) {
+        const T* s = static_cast<const T*>(src[b]);
+        float* d = dst + (size_t)b * t_max * f;
+        const size_t n = (size_t)lengths[b] * f;
+        for (size_t i = 0; i < n; ++i) d[i] = static_cast<float>(s[i]);
+        std::memset(d + n, 0, ((size_t)t_max * f - n) * sizeof(float));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// src[b]: C-contiguous (lengths[b], f) array of float64 (is_f64 != 0) or float32; dst: (batch, t_max, f) float32.
+// Returns 0, or -1 on bad arguments.
+int sl_host_pack_batch(const void* const* src, const int32_t* lengths, int batch, int f, int t_max, int is_f64, float* dst,
+                       int n_threads) {
+    if (!src || !lengths || !dst || batch <= 0 || f <= 0 || t_max <= 0) return -1;
+    for (int b = 0; b < batch; ++b)
+        if (!src[b] || lengths[b] < 0 || lengths[b] > t_max) return -1;
+    n_threads = std::max(1, std::min(n_threads, batch));
+    auto work = [&](int b0, int b1) {
+        if (is_f64)
+            pack_rows<double>(src, lengths, b0, b1, f, t_max, dst);
+        else
+            pack_rows<float>(src, lengths, b0, b1, f, t_max, dst);
+    };
+    if (n_threads == 1) {
+        work(0, batch);
+        return 0;
+    }
+    std::vector<std::thread> pool;
+    const int per = (batch + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        const int b0 = t * per, b1 = std::min(batch, b0 + per);
+        if (b0 < b1) pool.emplace_back(work, b0, b1);
+    }
+    for (auto& th : pool) th.join();
+    return 0;
+}
+
+int sl_host_version(void) { return 1; }
+
+}  // extern "C"

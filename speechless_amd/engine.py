@@ -506,6 +506,19 @@ class Engine:
         buf.label_len.copy_(torch.from_numpy(lab_len), non_blocking=True)
         self.set_input_lengths(prediction_lengths)
 
+    def set_labels_resident(self, labels_dev, label_len_dev, input_len_dev):
+        """set_labels for int32 tensors that already live in HBM (the staged input pipeline copies them on its copy
+        stream): labels (B, Lmax >= 1) with every entry of row b below label_len[b] in [0, K-1), lengths (B,).  The
+        tensors are used in place -- the caller keeps them alive and unchanged until the step's kernels have run."""
+        buf = self.cur
+        buf.ensure_backward(self)
+        if labels_dev.dim() != 2 or labels_dev.shape[0] != buf.batch or labels_dev.shape[1] < 1:
+            raise ValueError("label batch must be (B, Lmax >= 1)")
+        buf.ensure_ctc(self, int(labels_dev.shape[1]))
+        buf.labels = labels_dev
+        buf.label_len = label_len_dev
+        buf.input_len = input_len_dev
+
     def ctc(self, grad_scale=None, with_grad=True):
         """Per-utterance CTC loss of the current probabilities (tensor (B,) in HBM) and, into g[last], the gradient
         w.r.t. the output_conv logits of grad_scale * sum_b loss_b (default 1/B: Keras' mean, net.py:389)."""

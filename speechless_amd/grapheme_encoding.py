@@ -21,6 +21,10 @@ class CtcGraphemeEncoding:
         self.grapheme_set_size = self.allowed_character_count + 1
         self.ctc_blank = self.grapheme_set_size - 1  # blank is the LAST index (tf.nn.ctc_loss convention)
         self.graphemes_by_character = {c: i for i, c in enumerate(self.allowed_characters)}
+        # code point -> index table for the vectorised batch encoder (-1 = not allowed)
+        self._table = np.full(max(ord(c) for c in self.allowed_characters) + 1, -1, dtype=np.int32)
+        for c, i in self.graphemes_by_character.items():
+            self._table[ord(c)] = i
 
     def encode_character(self, label_char):
         index = self.graphemes_by_character.get(label_char)
@@ -36,7 +40,15 @@ class CtcGraphemeEncoding:
         width = max(len(label) for label in labels)
         batch = np.full((len(labels), width), -1, dtype=np.int32)
         for row, label in zip(batch, labels):
-            row[:len(label)] = self.encode(label)
+            if not label:
+                continue
+            codes = np.frombuffer(label.encode("utf-32-le"), dtype=np.uint32)  # one table lookup per label, not per char
+            known = codes < self._table.size
+            indices = self._table[np.where(known, codes, 0)]
+            if not known.all() or (indices < 0).any():
+                bad = int(np.argmax(~known | (indices < 0)))
+                raise ValueError("Unexpected char: '{}'".format(label[bad]))
+            row[:len(label)] = indices
         return batch
 
     def decode_grapheme(self, grapheme, previous_grapheme=None):

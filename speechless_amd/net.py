@@ -457,12 +457,13 @@ class Wav2Letter:
     def train_on_staged_batch(self, staged, stager, reducer=None):
         """train_on_batch for a pipeline.StagedBatch (input already in HBM, arrival ordered by an event)."""
         self.engine.load_input(staged.x_dev)
-        stager.release(staged)
-        self.engine.set_labels(staged.labels, staged.label_lengths, staged.prediction_lengths)
-        return self.engine.train_step_resident(reducer).mean()
+        self.engine.set_labels_resident(staged.labels_dev, staged.label_len_dev, staged.pred_len_dev)
+        mean = self.engine.train_step_resident(reducer).mean()
+        stager.release(staged)  # everything that reads the staged tensors is enqueued now
+        return mean
 
     def train(self, labeled_spectrogram_batches, preview_labeled_spectrogram_batch, tensor_board_log_directory,
-              net_directory, batches_per_epoch, max_epochs=100000000, reducer=None, prefetch_depth=2):
+              net_directory, batches_per_epoch, max_epochs=100000000, reducer=None, prefetch_depth=3):
         """Epoch loop of reference net.py:541-576: preview, then epochs of `batches_per_epoch` steps starting at
         `load_epoch or 0`; after every epoch the preview is logged and (epoch > 0) the weights are saved as
         weights-epoch{N}.  Ends when the batch iterable is exhausted or after max_epochs (Keras: 1e8).
@@ -476,7 +477,7 @@ class Wav2Letter:
         if prefetch_depth > 0:
             from .pipeline import BatchStager
             stager = BatchStager(labeled_spectrogram_batches, self._pack_for_staging, self.engine.device,
-                                 depth=prefetch_depth)
+                                 blank=self.grapheme_encoding.grapheme_set_size - 1, depth=prefetch_depth)
             batches = iter(stager)
         else:
             batches = iter(labeled_spectrogram_batches)

@@ -17,21 +17,59 @@ The staging buffer is deliberately PAGEABLE: on this platform CPU stores into hi
 drop to ~3 GB/s while the GPU is busy (5.5 ms to fill 16 MB, against 0.4 ms idle and 0.7 ms for pageable memory), and
 the pageable H2D costs the worker 0.7 ms instead of 0.3 -- measured with tools/e2e_train_throughput.py.
 """
+import ctypes
 import threading
+from pathlib import Path
 
 import numpy as np
 import torch
+
+_HOST_LIB = None
+
+
+def host_lib():
+    """libspeechless_host.so (speechless_amd/csrc_host/pack_batch.cpp, built by speechless_amd.build): the C++ batch
+    packer.  ctypes releases the GIL while it runs, so packing no longer competes with the training thread."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        path = Path(__file__).resolve().parent / "libspeechless_host.so"
+        if not path.exists():
+            raise RuntimeError("{} is missing: run `python -m speechless_amd.build`".format(path))
+        lib = ctypes.CDLL(str(path))
+        lib.sl_host_pack_batch.restype = ctypes.c_int
+        lib.sl_host_pack_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32), ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        if lib.sl_host_version() != 1:
+            raise RuntimeError("libspeechless_host.so version mismatch")
+        _HOST_LIB = lib
+    return _HOST_LIB
+
+
+def pack_spectrograms(spectrograms, dst, n_threads=4):
+    """Converts + zero-pads a list of (T_i, F) float64/float32 arrays into dst, a C-contiguous (B, Tmax, F) float32
+    numpy array (reference net.py:583-586), in native code."""
+    b, t_max, f = dst.shape
+    dtype = spectrograms[0].dtype
+    if dtype not in (np.float64, np.float32) or any(s.dtype != dtype for s in spectrograms):
+        dtype = np.float64
+    arrays = [np.ascontiguousarray(s, dtype=dtype) for s in spectrograms]  # no copy when already in that form
+    ptrs = (ctypes.c_void_p * b)(*[a.ctypes.data for a in arrays])
+    lengths = (ctypes.c_int32 * b)(*[a.shape[0] for a in arrays])
+    rc = host_lib().sl_host_pack_batch(ptrs, lengths, b, f, t_max, 1 if dtype == np.float64 else 0,
+                                       dst.ctypes.data, n_threads)
+    if rc != 0:
+        raise ValueError("sl_host_pack_batch rejected the batch (lengths / shapes)")
 
 
 class StagedBatch:
     """One batch resident (or arriving) in HBM.  `ready` is recorded on the copy stream behind the H2D copy."""
 
-    def __init__(self, slot, x_dev, labels, label_lengths, prediction_lengths, ready):
+    def __init__(self, slot, x_dev, labels_dev, label_len_dev, pred_len_dev, ready):
         self.slot = slot
         self.x_dev = x_dev
-        self.labels = labels
-        self.label_lengths = label_lengths
-        self.prediction_lengths = prediction_lengths
+        self.labels_dev = labels_dev        # int32 (B, Lmax >= 1), validated on the host
+        self.label_len_dev = label_len_dev  # int32 (B,)
+        self.pred_len_dev = pred_len_dev    # int32 (B,)
         self.ready = ready
 
 
@@ -48,13 +86,14 @@ class BatchStager:
 
     pack(batch) -> (spectrogram list, label_batch int32 (B, Lmax), label_lengths, prediction_lengths) is the net's own
     packer, so the staged tensors are exactly what train_on_batch would have built.  `depth` batches are in flight on
-    `workers` threads (numpy's conversion loops release the GIL); the batch iterable itself is only ever advanced by
+    `workers` threads (the native packer runs without the GIL); the batch iterable itself is only ever advanced by
     the consuming thread, and batches are delivered in order."""
 
-    def __init__(self, batches, pack, device, depth=2, workers=2):
+    def __init__(self, batches, pack, device, blank, depth=3, workers=3):
         from concurrent.futures import ThreadPoolExecutor
         self.device = torch.device(device)
         self.pack = pack
+        self.blank = blank  # labels must lie in [0, blank)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.depth = max(1, depth)
         self.slots = [_Slot() for _ in range(self.depth + 1)]
@@ -81,18 +120,31 @@ class BatchStager:
             slot.pinned = torch.empty((n,), dtype=torch.float32)
             slot.device = torch.empty((n,), dtype=torch.float32, device=self.device)
         host = slot.pinned[:n].view(b, t_max, f)
-        host_np = host.numpy()
-        for row, s in zip(host_np, spectrograms):  # convert + zero-pad in one pass (net.py:583-586)
-            row[:s.shape[0]] = s
-            row[s.shape[0]:] = 0
+        pack_spectrograms(spectrograms, host.numpy())  # convert + zero-pad in one native pass (net.py:583-586)
         x_dev = slot.device[:n].view(b, t_max, f)
+        # labels and lengths travel on the copy stream too: a pageable H2D copy on the COMPUTE stream blocks the host
+        # until everything queued before it has run, which exposes the step's launch overhead (2.9 instead of 2.4 ms)
+        labels = np.asarray(labels, dtype=np.int32)
+        lab_len = np.asarray(label_lengths, dtype=np.int32).reshape(-1)
+        pred_len = np.asarray(prediction_lengths, dtype=np.int32).reshape(-1)
+        if labels.ndim != 2 or labels.shape[0] != b:
+            raise ValueError("label batch must be (B, Lmax)")
+        for i in range(b):
+            row = labels[i, :lab_len[i]]
+            if row.size and (row.min() < 0 or row.max() >= self.blank):
+                raise ValueError("label {} holds an index outside [0, {}) (blank is {})".format(i, self.blank, self.blank))
+        if labels.shape[1] == 0:
+            labels = np.zeros((b, 1), dtype=np.int32)
         with self.copy_lock, torch.cuda.stream(self.copy_stream):
             x_dev.copy_(host, non_blocking=True)
+            labels_dev = torch.from_numpy(np.ascontiguousarray(labels)).to(self.device)
+            lab_len_dev = torch.from_numpy(lab_len).to(self.device)
+            pred_len_dev = torch.from_numpy(pred_len).to(self.device)
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
         slot.copied = ready
         slot.consumed = None
-        return StagedBatch(slot, x_dev, labels, label_lengths, prediction_lengths, ready)
+        return StagedBatch(slot, x_dev, labels_dev, lab_len_dev, pred_len_dev, ready)
 
     def _fill(self):
         while not self.exhausted and len(self.pending) < self.depth:
@@ -114,11 +166,16 @@ class BatchStager:
             raise StopIteration
         item = self.pending.pop(0).result()  # re-raises a worker's exception
         self._fill()
-        torch.cuda.current_stream(self.device).wait_event(item.ready)
+        stream = torch.cuda.current_stream(self.device)
+        stream.wait_event(item.ready)
+        # the label tensors were allocated on the copy stream: tell the caching allocator that the compute stream uses
+        # them, so that their memory is not handed out again before the step that reads them has run
+        for tensor in (item.labels_dev, item.label_len_dev, item.pred_len_dev):
+            tensor.record_stream(stream)
         return item
 
     def release(self, staged):
-        """Call once the kernels reading staged.x_dev have been enqueued on the current stream."""
+        """Call once every kernel reading the staged tensors (input AND labels) has been enqueued on the current stream."""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         staged.slot.consumed = ev

@@ -137,3 +137,19 @@ def test_keras_h5_checkpoints_convert_to_the_npz_the_net_loads(tmp_path):
     assert sorted(a.files) == sorted(b.files)
     for key in a.files:
         assert np.array_equal(a[key], b[key])
+
+
+def test_native_batch_packer_matches_the_numpy_packing():
+    """libspeechless_host.so:sl_host_pack_batch == the reference's zero-padding loop (net.py:583-586), f64 and f32."""
+    from speechless_amd.pipeline import pack_spectrograms
+    rng = np.random.RandomState(5)
+    for dtype in (np.float64, np.float32):
+        specs = [rng.randn(int(t), 37).astype(dtype) for t in (50, 1, 33, 50, 17)]
+        want = np.zeros((5, 50, 37), dtype=np.float32)
+        for row, s in zip(want, specs):
+            row[:s.shape[0]] = s
+        got = np.full((5, 50, 37), 9.0, dtype=np.float32)
+        pack_spectrograms(specs, got, n_threads=3)
+        assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        pack_spectrograms([rng.randn(60, 37)], np.zeros((1, 50, 37), dtype=np.float32))

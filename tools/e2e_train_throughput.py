@@ -40,7 +40,8 @@ def main():
         loss = net.train_on_batch(b, lazy=True)
     float(loss.item())
     serial = time.perf_counter() - t0
-    stager = BatchStager(batches[4:4 + args.steps], net._pack_for_staging, net.engine.device, depth=3)
+    stager = BatchStager(batches[4:4 + args.steps], net._pack_for_staging, net.engine.device,
+                         blank=net.grapheme_encoding.grapheme_set_size - 1, depth=3, workers=3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for staged in stager:
@@ -48,6 +49,15 @@ def main():
     float(loss.item())
     piped = time.perf_counter() - t0
     stager.close()
+    eng = net.engine
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step_resident()
+    torch.cuda.synchronize()
+    resident = time.perf_counter() - t0
+    print("resident input (the bench.py regime): {:8.1f} utt/s ({:.2f} ms per batch)".format(
+        32 * args.steps / resident, resident / args.steps * 1e3))
     print("serial loop   : {:8.1f} utt/s ({:.2f} ms per batch of 32, host packing + pageable H2D on the critical path)".format(
         32 * args.steps / serial, serial / args.steps * 1e3))
     print("staged (worker thread, copy stream): {:8.1f} utt/s ({:.2f} ms per batch)".format(
