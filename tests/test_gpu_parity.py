@@ -938,3 +938,30 @@ def test_training_overfits_a_small_batch_to_exact_transcripts(dtype):
     assert first > 100 and result.average_loss < 0.05
     assert [r.predicted for r in result.results] == [r.expected for r in result.results]
     assert result.average_letter_error_rate == 0.0
+
+
+@pytest.mark.parametrize("b,t,f,k,sizes", [
+    (1, 31, 128, 29, None),                                                       # a batch of ONE, odd length
+    (2, 2, 128, 29, None),                                                        # two input frames -> one output frame
+    (3, 70, 128, 33, None),                                                       # German alphabet: 32 graphemes + blank
+    (2, 90, 40, 29, dict(main_filter_count=100, out_filter_count=300)),           # channel counts far from the padding grid
+    (2, 66, 257, 29, dict(striding_kernel=12, inner_kernel=3, big_kernel=5, inner_count=2)),  # other kernel sizes / depth
+])
+def test_loss_and_gradients_f32_unusual_shapes(b, t, f, k, sizes):
+    """The fp32 path against the oracle on shapes off the beaten track: batch 1, a single output frame, K = 33, channel
+    counts that need heavy padding, other kernel sizes and a shallower stack (the kernels are generic in all of them)."""
+    case = make_case(b=b, t=t, f=f, k=k, seed=23, sizes=sizes)
+    eng = make_engine(case, "f32")
+    losses, grads = run_loss_and_grads(eng, case)
+    ref = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), case["labels"],
+                               case["prediction_lengths"], case["label_lengths"])
+    finite = np.isfinite(ref["losses"])
+    np.testing.assert_allclose(losses[finite], ref["losses"][finite], rtol=2e-5)
+    assert np.array_equal(np.isfinite(losses), finite)
+    if finite.all():
+        for i, ((dw, db), (rw, rb)) in enumerate(zip(grads, ref["grads"])):
+            assert rel_l2(dw, rw) < 2e-4 and rel_l2(db, rb) < 2e-4, (i, rel_l2(dw, rw), rel_l2(db, rb))
+    # the bf16 path runs the same shapes (tile tables, padding, grid rounding) and must stay close to the fp32 one
+    eng16 = make_engine(case, "bf16")
+    losses16, _ = run_loss_and_grads(eng16, case)
+    np.testing.assert_allclose(losses16[finite], ref["losses"][finite], rtol=2e-2)
