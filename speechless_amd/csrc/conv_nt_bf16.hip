@@ -1081,11 +1081,23 @@ Cfg auto_cfg(const sl_conv_geom* g) {
         // interleaved (big_conv_2 forward 0.104 ms = 1.24 PFLOP/s, 0.107 for the 16-wave kernel)
         if (tiles256 >= 192) return slab_ok ? Cfg{2, 4, 10, 1, 8, 0, 0, 1, 1} : Cfg{2, 4, 10, 1, 8, 0, 0, 0, 1};
         if (nsteps >= 256) {  // long contraction but few tiles (dgrad of big_conv_1: 64 tiles, K = 65536): split K
-            long ks = (256 + tiles256 - 1) / tiles256;
-            if (ks > 8) ks = 8;
+            // among the split counts that divide the chunks (whole chunks per split, the slab kernel's requirement) take
+            // the one with the least (rounds of 256 work-groups) x (steps per split); ties go to the smaller split
+            // (less partial-tile traffic).  B = 48: 96 tiles -> 2 splits (192 work-groups), not 3 (288 = two rounds).
             const long chunks = g->cin / BK;
-            if (slab_ok && chunks % ks == 0) return Cfg{2, 4, 10, (int)ks, 8, 0, 0, 1, 1};
-            return Cfg{4, 4, 2, (int)ks, 4, 0};
+            int best = 1;
+            double best_cost = 1e30;
+            for (int ks = 1; ks <= 8; ++ks) {
+                if (chunks % ks) continue;
+                const double rounds = (double)((tiles256 * ks + 255) / 256);
+                const double cost = rounds / ks;
+                if (cost < best_cost - 1e-9) {
+                    best_cost = cost;
+                    best = ks;
+                }
+            }
+            if (slab_ok) return Cfg{2, 4, 10, best, 8, 0, 0, 1, 1};
+            return Cfg{4, 4, 2, best, 4, 0};
         }
     }
     // short layers (one 128x128 tile per CU at most): 4 waves of 64x64, 3-slot ring, register-pipelined and

@@ -468,14 +468,22 @@ int choose_splits(const sl_conv_geom* g, int tci, int tco, int target_wgs, int g
     long want = (target_wgs + tiles - 1) / tiles;
     if (want < 1) want = 1;
     if (want > g->batch) want = g->batch;
-    // prefer a split count that divides the batch (equal work per work-group; measured: 4 x 8 utterances 0.144 ms vs
-    // 6 uneven splits 0.179 ms on the grouped inner-layer launch): the divisor closest to `want`, smaller one on ties
+    // Split counts that divide the batch give equal work per work-group (measured: 4 x 8 utterances 0.144 ms vs 6 uneven
+    // splits 0.179 ms on the grouped inner-layer launch).  Among the divisors up to 2 * want take the one with the least
+    // (rounds of `target_wgs` resident work-groups) x (utterances per split); ties go to the smaller split count (less
+    // partial-sum traffic).  B = 48, 49 tiles: 4 splits (196 work-groups, one round), not 6 (294 = two rounds).
     int best = 1;
-    for (int d = 1; d <= g->batch; ++d)
-        if (g->batch % d == 0 && labs(d - want) < labs(best - want)) best = d;
-    if (best * 2 >= want) return best;
-    const int bps = (int)((g->batch + want - 1) / want);
-    return (g->batch + bps - 1) / bps;
+    double best_cost = 1e30;
+    for (int d = 1; d <= g->batch && d <= 2 * want; ++d) {
+        if (g->batch % d) continue;
+        const double rounds = (double)((tiles * d + target_wgs - 1) / target_wgs);
+        const double cost = rounds * (g->batch / d);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = d;
+        }
+    }
+    return best;
 }
 
 WCfg auto_wcfg(const sl_conv_geom* g, int groups) {
