@@ -52,6 +52,9 @@ def _compile(src):
     err = res.stderr
     if src in NO_SCRATCH:
         bad = _scratch_users(err)
+        if bad and os.environ.get("SL_ALLOW_SCRATCH"):  # experiments only: results of the listed kernels are not to be trusted
+            print("WARNING: scratch in asm-read kernels: " + "; ".join(b.split("(")[0][-60:] for b in bad[:4]), file=sys.stderr)
+            bad = []
         if bad:
             raise RuntimeError("{}: kernels with asm-tracked LDS reads must not spill, but these use scratch: {}".format(
                 src, "; ".join(bad)))
