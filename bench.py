@@ -116,11 +116,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node {} for --gpus {}".format(
                 args.gpus, args.gpus))
+    # Test hook (single-GPU boxes only): SL_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and moves the bytes with gloo, so
+    # that the multi-rank control flow of this script can be exercised where only one GPU exists.  Never set in a
+    # measurement: the ranks then share one device.
+    share_gpu = os.environ.get("SL_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = "cuda:{}".format(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
 
     bins = LONG_BINS if args.config == 5 else MEL
     specs = wav2letter_layer_specs(bins, K_CLASSES)
