@@ -713,6 +713,20 @@ class Engine:
         else:
             early = early and reducer.overlap
             self.backward(on_bucket_ready=reducer.reduce_bucket, early_adam=early, reducer=reducer)
+            if not early and (reducer.world_size > 1 or reducer.force):
+                # bucket 0 (the three output layers, 81 % of the bytes) finished reducing under the rest of backward:
+                # update those layers while the small last bucket is still on the wire, then the rest
+                _, split = self.bucket_ranges()
+                first = self.frozen_layer_count
+                if self._packed_dirty:
+                    self.repack_weights()
+                self.adam_iterations += 1
+                reducer.wait_next()
+                self._adam_layers(range(split, len(self.plans)), self._stream())
+                reducer.wait_all()
+                if split > first:
+                    self._adam_layers(range(first, split), self._stream())
+                return loss
             reducer.wait_all()
         if not early:
             self.adam_step()

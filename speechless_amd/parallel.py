@@ -64,6 +64,16 @@ class GradBucketReducer:
             done.record(self.comm_stream)
         self._pending.append(done)
 
+    def wait_next(self):
+        """Makes the current stream (or the host, on CPU) wait for the OLDEST outstanding bucket only."""
+        if not self._pending:
+            return
+        p = self._pending.pop(0)
+        if self.overlap:
+            torch.cuda.current_stream(self.flat.device).wait_event(p)
+        else:
+            p.wait()
+
     def wait_all(self):
         """Makes the current stream (or the host, on CPU) wait for every outstanding bucket."""
         for p in self._pending:
