@@ -1,4 +1,4 @@
-import sys, time
+import sys
 from pathlib import Path
 import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
