@@ -1070,7 +1070,7 @@ Cfg decode_cfg(int cfg) {
 }
 
 Cfg auto_cfg(const sl_conv_geom* g) {
-    // Table measured on MI355X with tools/tune_kernels.py (profiles/r01_tune_kernels.json), see DESIGN.md section 3.1.
+    // Table measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01i_tune_kernels.json), see DESIGN.md section 3.1.
     const long nsteps = (long)g->taps * (g->cin / BK);
     if (g->cout % 256 == 0) {
         const long tiles256 = (long)g->batch * ((g->t_out + 255) / 256) * (g->cout / 256);

@@ -487,7 +487,7 @@ int choose_splits(const sl_conv_geom* g, int tci, int tco, int target_wgs, int g
 }
 
 WCfg auto_wcfg(const sl_conv_geom* g, int groups) {
-    // measured on MI355X with tools/tune_kernels.py (profiles/r01_tune_kernels.json), see DESIGN.md section 3
+    // measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01i_tune_kernels.json), see DESIGN.md section 3
     if (g->cin % 256 == 0 && g->cout % 256 == 0) {
         const long tiles256 = (long)g->taps * (g->cin / 256) * (g->cout / 256) * groups;
         // 256x256 tile, 8 waves, interleaved stream: big_conv_1 0.351 ms = 1.46 PFLOP/s (16-wave kernel 0.363, 128x128
