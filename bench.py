@@ -221,7 +221,9 @@ def main():
         if other in live_ms:
             groups[other] = {"ms_per_step": live_ms[other]}
     groups["adam_and_repack"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("adam"))}
-    groups["bias_grad"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("bgrad:"))}
+    groups["bias_grad"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("bgrad:")),
+                           "note": "side stream, concurrent with the wgrad/dgrad kernels of the same layer: these "
+                                   "durations are stretched by the overlap and are NOT additive with the other groups"}
     groups["per_launch_ms"] = {t: round(v, 4) for t, v in sorted(live_ms.items())}
     conv_ms = sum(groups[g]["ms_per_step"] for g in ("fwd", "dgrad", "wgrad") if g in groups)
 

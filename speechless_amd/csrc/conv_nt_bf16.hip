@@ -400,38 +400,80 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         //   B: MFMAs of k-half 1, per group one fragment read of the NEXT tile's k-half 0 and one LDS-DMA request of the
         //      tile that re-uses this slot.  The request stream is branch-free: past the end of the split the last tile
         //      is requested again into a slot nobody reads, so the vmcnt bookkeeping stays exact to the last step.
-        constexpr int G = (IT >= 4) ? 2 : 1;  // MFMAs per group: 4*IT / G groups must offer 4+IT read slots
+        constexpr int G = (IT >= 4) ? 2 : 1;  // MFMAs per group: 4*IT / G groups must offer 4+IT read slots (G = 1 for IT = 4: measured slower)
         constexpr int NQ = 4 * IT / G;
         static_assert(NI <= NQ, "one DMA request per group");
         const __bf16* xs_n = nullptr;
         const __bf16* ws_n = nullptr;
-        char* xl_n = nullptr;
-        char* wl_n = nullptr;
-        auto begin_stage = [&](int local_step, int slot) {
-            const int st = s_begin + (local_step < n ? local_step : n - 1);
-            const int chunks = a.cin / BK;
-            const int tap = st / chunks;
-            const int cc = st - tap * chunks;
-            xs_n = xbase + (long)tap * a.x_rs + cc * BK;
-            ws_n = wbase + (long)st * BK;
-            xl_n = smem + slot * STAGE_BYTES + (wave * XPW) * 1024;
-            wl_n = smem + slot * STAGE_BYTES + X_BYTES + (wave * WPW) * 1024;
+        unsigned xl_n = 0, wl_n = 0;  // LDS byte offsets of this wave's part of the slot being refilled
+        // Request stream state: sources of the NEXT activation / weight tile to request, advanced by pointer increments
+        // (tap-major order: the weight tiles are consecutive, the activation tile moves one chunk right or wraps to the
+        // next tap's row).  The former per-step "step -> (tap, chunk)" division was a ~45-instruction scalar clump
+        // between the two MFMA phases; with one wave per SIMD (the 4-wave tiles) nobody covers it.
+        const int chunks = a.cin / BK;
+        const int tap_first = s_begin / chunks;
+        int cc_r = s_begin - tap_first * chunks;
+        int rx_left = n, rw_left = n;
+        const __bf16* xs_r = xbase + (long)tap_first * a.x_rs + cc_r * BK;
+        const __bf16* ws_r = wbase + (long)s_begin * BK;
+        const int x_wrap = a.x_rs - (chunks - 1) * BK;
+        const unsigned wave_x = (wave * XPW) * 1024, wave_w = X_BYTES + (wave * WPW) * 1024;
+        auto next_x = [&](int slot) {  // past the end the last tile is requested again
+            xs_n = xs_r;
+            xl_n = slot * STAGE_BYTES + wave_x;
+            const bool more = rx_left > 1;
+            const bool wrap = cc_r + 1 == chunks;
+            int dx = wrap ? x_wrap : BK;
+            dx = more ? dx : 0;
+            xs_r += dx;
+            const int cn = wrap ? 0 : cc_r + 1;
+            cc_r = more ? cn : cc_r;
+            rx_left -= more ? 1 : 0;
         };
-        auto dma_piece = [&](auto q_c) {
+        auto next_w = [&](int slot) {
+            ws_n = ws_r;
+            wl_n = slot * STAGE_BYTES + wave_w;
+            const bool more = rw_left > 1;
+            ws_r += more ? BK : 0;
+            rw_left -= more ? 1 : 0;
+        };
+        int cur = 0;
+        // the address arithmetic rides in phase A, in the shadow of MFMA groups; the asm pins it there (otherwise it sinks
+        // below the barrier)
+        auto pin_w = [&]() {
+            next_w(cur);
+            asm volatile("" : "+s"(ws_n), "+s"(wl_n), "+s"(ws_r), "+s"(rw_left));
+        };
+        auto pin_x = [&]() {
+            next_x(cur);
+            asm volatile("" : "+s"(xs_n), "+s"(xl_n), "+s"(xs_r), "+s"(cc_r), "+s"(rx_left));
+        };
+        auto hook_a = [&](auto q_c) {
             constexpr int Q = decltype(q_c)::value;
-            if constexpr (Q < XPW)
-                glds16(xs_n + xoff[Q], xl_n + Q * 1024);
-            else if constexpr (Q < NI)
-                glds16(ws_n + woff[Q - XPW], wl_n + (Q - XPW) * 1024);
+            if constexpr (Q == 1) pin_w();
+            if constexpr (Q == 3) pin_x();
         };
-        auto no_hook = [](auto) {};
+        // (issuing the weight half of a tile's requests in phase A and the activation half in phase B -- half the
+        // texture-path load per phase -- was measured: no gain, 0.46 vs 0.45 us per step on the 128x128 tile)
+        auto hook_b = [&](auto q_c) {
+            constexpr int Q = decltype(q_c)::value;
+#if defined(SL_PROBE_NO_DMA)  // timing probe only (wrong results)
+            (void)q_c;
+#else
+            if constexpr (Q < XPW)
+                glds16(xs_n + xoff[Q], smem + xl_n + Q * 1024);
+            else if constexpr (Q < NI)
+                glds16(ws_n + woff[Q - XPW], smem + wl_n + (Q - XPW) * 1024);
+#endif
+        };
 #pragma unroll
         for (int i = 0; i < STAGES; ++i) {
-            begin_stage(i, i);
+            next_x(i);
+            next_w(i);
 #pragma unroll
-            for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], xl_n + q * 1024);
+            for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], smem + xl_n + q * 1024);
 #pragma unroll
-            for (int q = 0; q < WPW; ++q) glds16(ws_n + woff[q], wl_n + q * 1024);
+            for (int q = 0; q < WPW; ++q) glds16(ws_n + woff[q], smem + wl_n + q * 1024);
         }
         wait_vmcnt<NI*(STAGES - 1)>();
         __builtin_amdgcn_s_barrier();
@@ -440,19 +482,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         const unsigned lds0 = (unsigned)(size_t)smem;
         DsReadRun<0, NA, 512>::go(a0, lds0 + aoff);
         DsReadRun<0, NB, 2048>::go(b0, lds0 + boff);
-        int cur = 0;
         for (int i = 0; i < n; ++i) {
             const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
             wait_frags<0>(a0, b0);
             IlvPhase<IT, G, 0, NQ>::run(acc, a0, b0, a1, b1, lds0 + cur * STAGE_BYTES + (aoff ^ 64),
-                                        lds0 + cur * STAGE_BYTES + (boff ^ 64), no_hook);
+                                        lds0 + cur * STAGE_BYTES + (boff ^ 64), hook_a);
             wait_frags<0>(a1, b1);  // my reads of slot cur are complete
             wait_vmcnt<NI*(STAGES - 2)>();  // tile i+1 has landed; the younger ones stay in flight
+#if !defined(SL_PROBE_NO_BARRIER)  // timing probe only (wrong results)
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
-            begin_stage(i + STAGES, cur);
             IlvPhase<IT, G, 0, NQ>::run(acc, a1, b1, a0, b0, lds0 + nxt * STAGE_BYTES + aoff,
-                                        lds0 + nxt * STAGE_BYTES + boff, dma_piece);
+                                        lds0 + nxt * STAGE_BYTES + boff, hook_b);
             cur = nxt;
         }
         wait_vmcnt<0>();        // the surplus requests still target this work-group's LDS
@@ -736,6 +778,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
             if constexpr (Q < WPW) glds16(ws_next + woff[Q], wl_next + Q * 1024);
 #endif
         };
+        constexpr int GS = 2;  // MFMAs per interleave group, see conv_nt_bf16_kernel
         issue_slab(c0, 0);
 #pragma unroll
         for (int i = 0; i < STAGES; ++i) {
@@ -754,20 +797,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         for (int i = 0; i < n; ++i) {
             const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
             wait_frags<0>(a0, b0);
-            IlvPhase<IT, 2, 0, 2 * IT>::run(acc, a0, b0, a1, b1, lds0 + ((aoff + cur * W_BYTES) ^ 64),
+            IlvPhase<IT, GS, 0, 4 * IT / GS>::run(acc, a0, b0, a1, b1, lds0 + ((aoff + cur * W_BYTES) ^ 64),
                                           lds0 + (b_offset(par_c, tap_c) ^ 64), no_hook);
             wait_frags<0>(a1, b1);  // my reads of weight slot cur (and, on a chunk's last tap, of its slab) are complete
-            wait_vmcnt<0>();
+            if constexpr (STAGES == 2) {
+                wait_vmcnt<0>();
+            } else {  // weight tile i+1 has landed; the STAGES-2 younger ones (and a slab requested among them) fly on
+                if (tap_c >= 1 && tap_c <= STAGES - 2 && chunk_c + 1 < nchunks)
+                    wait_vmcnt<WPW*(STAGES - 2) + XPW>();
+                else
+                    wait_vmcnt<WPW*(STAGES - 2)>();
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            // the only branch of the loop body: once per chunk, in front of the straight-line phase
+            // once per chunk, in front of the straight-line phase
             if (tap_c == 0 && chunk_c + 1 < nchunks) issue_slab(c0 + chunk_c + 1, par_c ^ 1);
             const bool wrap = tap_c + 1 == taps;
             chunk_c += wrap ? 1 : 0;
             par_c = wrap ? par_c ^ 1 : par_c;
             tap_c = wrap ? 0 : tap_c + 1;
             begin_w(cur);
-            IlvPhase<IT, 2, 0, 2 * IT>::run(acc, a1, b1, a0, b0, lds0 + aoff + nxt * W_BYTES, lds0 + b_offset(par_c, tap_c),
+            IlvPhase<IT, GS, 0, 4 * IT / GS>::run(acc, a1, b1, a0, b0, lds0 + aoff + nxt * W_BYTES, lds0 + b_offset(par_c, tap_c),
                                           dma_hook);
             cur = nxt;
         }
@@ -1132,7 +1182,8 @@ bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
     if (g->cout % (64 * c.wn)) return false;
     const long nsteps = (long)g->taps * (g->cin / BK);
     if (c.ilv) {  // instantiated interleaved shapes: the slab 256x256 kernel and three tap-major pipelined tiles
-        const bool slab_ilv = c.slab && !c.m32 && c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10;
+        const bool slab_ilv = c.slab && !c.m32 && ((c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10) ||
+                                                   (c.it == 4 && c.wm == 2 && c.wn == 2 && full.stages >= 10 && full.stages <= 12));
         const bool tap_ilv = !c.slab && !c.m32 && (full.stages & 8) &&
                              ((c.it == 2 && c.wm == 4 && c.wn == 2) || (c.it == 4 && c.wm == 2 && c.wn == 2) ||
                               (c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10));
@@ -1143,7 +1194,8 @@ bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
         const bool inst = !c.m32 && ((c.it == 4 && c.wm == 4 && c.wn == 4 && full.stages == 2) ||
                                      (c.it == 8 && c.wm == 2 && c.wn == 4 && full.stages == 10) ||
                                      (c.it == 2 && c.wm == 4 && c.wn == 2 && (full.stages == 11 || full.stages == 3)) ||
-                                     (c.it == 4 && c.wm == 2 && c.wn == 2 && (full.stages == 11 || full.stages == 12)));
+                                     (c.it == 4 && c.wm == 2 && c.wn == 2 && (full.stages == 11 || full.stages == 12)) ||
+                                     (c.ilv && c.it == 4 && c.wm == 2 && c.wn == 2 && full.stages == 10));
         if (!inst || g->taps > 33 || g->taps < c.stages) return false;
         return c.ksplit <= g->cin / BK;  // whole chunks per split
     }
@@ -1210,7 +1262,10 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
 #define SL_NT_SLAB_CASE(IT_, WM_, WN_, ST_)                                      \
     if (c.slab && c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
         return launch_cfg<false, 100 + IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);
-    if (c.slab && c.ilv) return launch_cfg<false, 208, 2, 4, 10>(a, epilogue, out_f32, s);
+    if (c.slab && c.ilv && c.it == 8) return launch_cfg<false, 208, 2, 4, 10>(a, epilogue, out_f32, s);
+    if (c.slab && c.ilv && c.stages == 10) return launch_cfg<false, 204, 2, 2, 10>(a, epilogue, out_f32, s);
+    if (c.slab && c.ilv && c.stages == 11) return launch_cfg<false, 204, 2, 2, 11>(a, epilogue, out_f32, s);
+    if (c.slab && c.ilv && c.stages == 12) return launch_cfg<false, 204, 2, 2, 12>(a, epilogue, out_f32, s);
     SL_NT_SLAB_CASE(4, 4, 4, 2)
     SL_NT_SLAB_CASE(8, 2, 4, 10)
     SL_NT_SLAB_CASE(2, 4, 2, 11)

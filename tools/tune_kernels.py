@@ -70,7 +70,7 @@ def main():
     # slab variant (chunk-major, activation slab kept in LDS): it + 100
     shapes += [(4, 2, 10, 302), (4, 2, 11, 302), (4, 2, 12, 302), (2, 2, 10, 304), (2, 2, 11, 304), (2, 2, 12, 304),
                (2, 4, 10, 308),  # it + 300: interleaved tap-major
-               (4, 4, 2, 104), (2, 4, 10, 108), (2, 4, 10, 208), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
+               (4, 4, 2, 104), (2, 4, 10, 108), (2, 4, 10, 208), (2, 2, 10, 204), (2, 2, 11, 204), (2, 2, 12, 204), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
     results = {}
     n = len(eng.plans)
 
