@@ -10,7 +10,13 @@ PARITY PINNING STATUS
   (speechless/test/test_ctc_decoders.py:19-41, test_grapheme_encoding.py:9-31)
   and by fixtures generated from the importable reference module
   ``speechless.grapheme_enconding`` (tests/golden/make_golden.py).
-* Conv1D stack, CTC loss / gradient, Adam: **parity unpinned**.  The arithmetic
+* CTC core (loss, gradient w.r.t. the logits, greedy decoder): PINNED against the
+  known-answer vectors of TensorFlow's own unit tests for tf.nn.ctc_loss /
+  tf.nn.ctc_greedy_decoder (ctc_loss_op_test.py testBasic, ctc_decoder_ops_test.py),
+  the third-party ops net.py:402-406 / 452-454 bottom out in:
+  tests/golden/tf_ctc_known_answers.json (provenance and self-check in the file).
+* Conv1D stack, the Keras wrapper around the CTC op (log(p+1e-8) re-softmax, label /
+  length plumbing) and Adam: **parity unpinned**.  The arithmetic
   of the reference lives in Keras 2.0.x / TensorFlow 1.x (un-vendored, un-pinned,
   not importable in the build container) and the
   reference holds no golden vectors for it.  This file restates the published

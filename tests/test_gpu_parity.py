@@ -278,6 +278,38 @@ def test_ctc_kernel_long_labels(hip_lib):
     assert rel_l2(dl, o.softmax_backward(ref_p, ref_dp)) < 1e-3  # fp32 log-space lattice (|alpha| ~ 1e3, ulp 1e-4) vs float64 oracle
 
 
+def test_ctc_and_decode_kernels_against_tensorflow_known_answers(hip_lib):
+    """The HIP softmax + CTC lattice / gradient kernels and the greedy decoder on TensorFlow's own known-answer vectors
+    for tf.nn.ctc_loss / tf.nn.ctc_greedy_decoder (tests/golden/tf_ctc_known_answers.json): not via the oracle."""
+    import torch
+    kat = json.loads((ROOT / "tests" / "golden" / "tf_ctc_known_answers.json").read_text())
+    cases = kat["ctc_loss"]
+    t, k = 5, 6
+    logits = np.stack([np.log(np.array(c["probs"], dtype=np.float64)) for c in cases]).astype(np.float32)
+    labels = -np.ones((len(cases), 5), dtype=np.int32)
+    for i, c in enumerate(cases):
+        labels[i, :len(c["labels"])] = c["labels"]
+    lab_len = [len(c["labels"]) for c in cases]
+    for eps, tol in ((0.0, 3e-6), (1e-8, 5e-6)):  # eps = 0: the op's own arithmetic; 1e-8: what Keras feeds it
+        probs, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, [t, t], eps=eps)
+        for i, c in enumerate(cases):
+            assert np.abs(probs[i] - np.array(c["probs"])).max() < 2e-6
+            assert abs(loss[i] - c["loss"]) < 1e-5, (eps, i, loss[i])
+            # d loss / d (network logits) == TF's gradient w.r.t. its logits (the softmax chain contributes
+            # -p * sum_k(du_k) = 0 because softmax - occupancy sums to zero per frame)
+            assert np.abs(dl[i] - np.array(c["grad_logits"])).max() < tol, (eps, i)
+    dec = kat["ctc_greedy_decoder"]
+    p = torch.tensor(np.array(dec["probs"]), dtype=torch.float32, device="cuda:0")
+    il = torch.tensor(dec["sequence_length"], dtype=torch.int32, device="cuda:0")
+    out = torch.zeros((2, 6), dtype=torch.int32, device="cuda:0")
+    out_len = torch.zeros((2,), dtype=torch.int32, device="cuda:0")
+    hip_lib.call("sl_greedy_decode", p.data_ptr(), il.data_ptr(), out.data_ptr(), out_len.data_ptr(), None, 2, 6, 4, 3,
+                 torch.cuda.current_stream().cuda_stream)
+    got = [out[i, :int(out_len[i])].tolist() for i in range(2)]
+    assert got == dec["decoded"]
+    assert out[0].tolist() == [0, 1, -1, -1, -1, -1]
+
+
 # ------------------------------------------------------------------------------------------ decode, Adam
 def test_greedy_decode_known_answers(hip_lib):
     import torch

@@ -139,6 +139,32 @@ def test_bf16_rounding_is_round_to_nearest_even():
     np.testing.assert_array_equal(r, torch.tensor(x).to(torch.bfloat16).to(torch.float32).numpy())
 
 
+def test_ctc_core_against_tensorflow_known_answers():
+    """tf.nn.ctc_loss / tf.nn.ctc_greedy_decoder known-answer vectors from TensorFlow's own unit tests (the third-party ops
+    net.py:402-406 and net.py:452-454 bottom out in; provenance in the fixture): loss, gradient w.r.t. the logits and the
+    decoded sequences.  This pins the CTC core of the oracle; the Keras wrapper around it (log(p + 1e-8), padding and
+    length plumbing) has no published vectors and stays covered by the independent checks below."""
+    import json
+    kat = json.loads((GOLDEN / "tf_ctc_known_answers.json").read_text())
+    for case in kat["ctc_loss"]:
+        p = np.array(case["probs"], dtype=np.float64)
+        assert np.abs(p.sum(axis=1) - 1).max() < 2e-6  # the fixture's self-check: rows are softmax outputs
+        k = p.shape[1]
+        loss, du = o.ctc_single(np.log(p / p.sum(axis=1, keepdims=True)), case["labels"], k - 1)
+        assert abs(loss - case["loss"]) < 1e-5
+        assert np.abs(du - np.array(case["grad_logits"])).max() < 2e-6
+        # the same through the Keras entry point (eps = 0 turns the re-softmax into the identity)
+        losses, dp = o.ctc_batch_cost(p[None], np.array([case["labels"]]), [p.shape[0]], [len(case["labels"])], eps=0.0)
+        assert abs(losses[0] - case["loss"]) < 1e-5
+        assert np.abs(dp[0] * p - np.array(case["grad_logits"])).max() < 2e-6
+        # ... and with the eps Keras adds the answer moves by ~1e-7 only
+        losses, _ = o.ctc_batch_cost(p[None], np.array([case["labels"]]), [p.shape[0]], [len(case["labels"])])
+        assert abs(losses[0] - case["loss"]) < 1e-5
+    dec = kat["ctc_greedy_decoder"]
+    got = o.greedy_decode_indices(np.array(dec["probs"]), dec["sequence_length"])
+    assert [list(d) for d in got] == dec["decoded"]
+
+
 def test_greedy_decode_known_answers():
     import json
     kat = json.loads((GOLDEN / "codec_golden.json").read_text(encoding="utf8"))["tf_greedy_kat"]
