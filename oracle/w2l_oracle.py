@@ -15,8 +15,9 @@ PARITY PINNING STATUS
   tf.nn.ctc_greedy_decoder (ctc_loss_op_test.py testBasic, ctc_decoder_ops_test.py),
   the third-party ops net.py:402-406 / 452-454 bottom out in:
   tests/golden/tf_ctc_known_answers.json (provenance and self-check in the file).
-* Conv1D stack, the Keras wrapper around the CTC op (log(p+1e-8) re-softmax, label /
-  length plumbing) and Adam: **parity unpinned**.  The arithmetic
+  keras.backend.ctc_batch_cost on a padded batch: Keras' own backend test
+  (backend_test.py::test_ctc, same data, atol 1e-5) is in the same fixture.
+* Conv1D stack and Adam: **parity unpinned**.  The arithmetic
   of the reference lives in Keras 2.0.x / TensorFlow 1.x (un-vendored, un-pinned,
   not importable in the build container) and the
   reference holds no golden vectors for it.  This file restates the published

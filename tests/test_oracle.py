@@ -142,8 +142,7 @@ def test_bf16_rounding_is_round_to_nearest_even():
 def test_ctc_core_against_tensorflow_known_answers():
     """tf.nn.ctc_loss / tf.nn.ctc_greedy_decoder known-answer vectors from TensorFlow's own unit tests (the third-party ops
     net.py:402-406 and net.py:452-454 bottom out in; provenance in the fixture): loss, gradient w.r.t. the logits and the
-    decoded sequences.  This pins the CTC core of the oracle; the Keras wrapper around it (log(p + 1e-8), padding and
-    length plumbing) has no published vectors and stays covered by the independent checks below."""
+    decoded sequences, plus Keras' own backend test of K.ctc_batch_cost on the same data (padded batch, log(p + 1e-8))."""
     import json
     kat = json.loads((GOLDEN / "tf_ctc_known_answers.json").read_text())
     for case in kat["ctc_loss"]:
@@ -160,6 +159,11 @@ def test_ctc_core_against_tensorflow_known_answers():
         # ... and with the eps Keras adds the answer moves by ~1e-7 only
         losses, _ = o.ctc_batch_cost(p[None], np.array([case["labels"]]), [p.shape[0]], [len(case["labels"])])
         assert abs(losses[0] - case["loss"]) < 1e-5
+    # Keras' own test of the wrapper (backend_test.py::test_ctc): both sequences as one padded batch
+    kb = kat["keras_ctc_batch_cost"]
+    probs = np.stack([np.array(c["probs"]) for c in kat["ctc_loss"]])
+    losses, _ = o.ctc_batch_cost(probs, np.array(kb["labels"]), kb["input_lengths"], kb["label_lengths"])
+    np.testing.assert_allclose(losses, kb["loss_log_probs_tf"], atol=kb["atol"])
     dec = kat["ctc_greedy_decoder"]
     got = o.greedy_decode_indices(np.array(dec["probs"]), dec["sequence_length"])
     assert [list(d) for d in got] == dec["decoded"]
