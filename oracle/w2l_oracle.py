@@ -14,10 +14,13 @@ PARITY PINNING STATUS
   known-answer vectors of TensorFlow's own unit tests for tf.nn.ctc_loss /
   tf.nn.ctc_greedy_decoder (ctc_loss_op_test.py testBasic, ctc_decoder_ops_test.py),
   the third-party ops net.py:402-406 / 452-454 bottom out in:
-  tests/golden/tf_ctc_known_answers.json (provenance and self-check in the file).
+  tests/golden/tf_known_answers.json (provenance and self-check in the file).
   keras.backend.ctc_batch_cost on a padded batch: Keras' own backend test
   (backend_test.py::test_ctc, same data, atol 1e-5) is in the same fixture.
-* Conv1D stack and Adam: **parity unpinned**.  The arithmetic
+* Convolution (TF "SAME" padding incl. the asymmetric stride-2 case, forward, input and
+  filter gradients): PINNED on TensorFlow's conv_ops_test.py known answers restated as
+  1-D problems (same fixture, section "conv").
+* Full-size Conv1D stack beyond those small cases, and Adam: **parity unpinned**.  The arithmetic
   of the reference lives in Keras 2.0.x / TensorFlow 1.x (un-vendored, un-pinned,
   not importable in the build container) and the
   reference holds no golden vectors for it.  This file restates the published

@@ -94,6 +94,72 @@ def test_forward_f32_layer_by_layer(t):
     np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_kernels_against_tensorflow_known_answers(dtype):
+    """The HIP convolution (both dtypes; fp32 accumulate) on TensorFlow's own conv_ops_test.py known answers
+    (tests/golden/tf_known_answers.json): kernel 2 / stride 1 and kernel 2 / stride 2 with SAME's asymmetric right pad.
+    Integer data: the fp32 path must be exact, the bf16 path exact up to the bf16 rounding of the stored activation."""
+    from speechless_amd.engine import Engine, LayerSpec
+    from test_oracle import _tf_conv_cases
+    convs, _ = _tf_conv_cases()
+    for name, x, w, stride, want in convs:
+        cin, cout = w.shape[1], w.shape[2]
+        specs = [LayerSpec("striding_conv", w.shape[0], stride, cin, cout, "relu"),
+                 LayerSpec("output_conv", 1, 1, cout, 4, "softmax")]
+        eng = Engine(specs, 4, dtype=dtype)
+        eng.set_weights([(w.astype(np.float32), np.zeros(cout, dtype=np.float32)),
+                         (np.zeros((1, cout, 4), dtype=np.float32), np.zeros(4, dtype=np.float32))])
+        eng.forward(x.astype(np.float32))
+        got, _ = layer_activation(eng, eng.cur, 0)   # relu(z); every expected value is positive
+        got = got[:, :want.shape[1]]
+        if dtype == "f32":
+            assert np.array_equal(got, want), (name, got)
+        else:
+            assert np.array_equal(got, o.round_to_bf16(want.astype(np.float32))), (name, got)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_gradient_kernels_against_tensorflow_known_answers(dtype):
+    """sl_conv1d_wgrad / sl_bias_grad / the dgrad launch of sl_conv1d_nt on conv_ops_test.py's backprop known answers
+    (tests/golden/tf_known_answers.json -> conv.backprop): small integers, exact in both dtypes."""
+    import ctypes
+    import torch
+    from speechless_amd import _lib
+    from speechless_amd.engine import Engine, LayerSpec, HALO
+    c = json.loads((ROOT / "tests" / "golden" / "tf_known_answers.json").read_text())["conv"]["backprop"]
+    x, w, dz = np.array(c["x"], dtype=np.float32), np.array(c["w"], dtype=np.float32), np.array(c["dz"], dtype=np.float32)
+    specs = [LayerSpec("striding_conv", 2, 2, 4, 2, "relu"), LayerSpec("inner_conv_1", 2, 1, 2, 1, "relu"),
+             LayerSpec("output_conv", 1, 1, 1, 4, "softmax")]
+    eng = Engine(specs, 4, dtype=dtype)
+    eng.set_weights([(np.zeros((2, 4, 2), dtype=np.float32), np.zeros(2, dtype=np.float32)), (w, np.zeros(1, dtype=np.float32)),
+                     (np.zeros((1, 1, 4), dtype=np.float32), np.zeros(4, dtype=np.float32))])
+    buf = eng.load_input(np.zeros((1, 6, 4), dtype=np.float32))   # 6 input frames -> 3 frames after the stride
+    buf.ensure_backward(eng)
+    eng.repack_weights()
+    assert buf.t_out == 3
+    td = eng.torch_dtype
+    y0 = torch.zeros_like(buf.y[0])
+    y0[0, HALO:HALO + 3, :2] = torch.tensor(x).to(td)
+    buf.y[0].copy_(y0)
+    g1 = torch.zeros_like(buf.g[1])
+    g1[0, HALO:HALO + 3, :1] = torch.tensor(dz).to(td)
+    buf.g[1].copy_(g1)
+    st = torch.cuda.current_stream().cuda_stream
+    p = eng.plans[1]
+    dw_v, db_v = eng.layer_param_views(eng.grads, p)
+    eng.lib.call("sl_conv1d_wgrad", buf.y[0].data_ptr(), buf.g[1].data_ptr(), dw_v.data_ptr(),
+                 ctypes.byref(buf.wgrad_geom[1]), eng.dtype_code, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+    eng.lib.call("sl_bias_grad", buf.g[1].data_ptr(), db_v.data_ptr(), ctypes.byref(buf.wgrad_geom[1]), eng.dtype_code,
+                 buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
+    eng.lib.call("sl_conv1d_nt", buf.g[1].data_ptr(), eng.w_dgrad[1].data_ptr(), None, buf.y[0].data_ptr(),
+                 buf.g[0].data_ptr(), ctypes.byref(buf.dgrad_geom[1]), _lib.EPI_RELU_MASK, eng.dtype_code, 0, 0,
+                 buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(dw_v[:, :2, :1].cpu().numpy(), np.array(c["dw"]))
+    assert db_v[:1].cpu().numpy().tolist() == [3.0]
+    assert np.array_equal(buf.g[0][0, HALO:HALO + 3, :2].float().cpu().numpy(), np.array(c["dx"]))
+
+
 def test_forward_bf16_matches_mirrored_oracle():
     import torch
     case = make_case(b=3, t=64)
@@ -280,9 +346,9 @@ def test_ctc_kernel_long_labels(hip_lib):
 
 def test_ctc_and_decode_kernels_against_tensorflow_known_answers(hip_lib):
     """The HIP softmax + CTC lattice / gradient kernels and the greedy decoder on TensorFlow's own known-answer vectors
-    for tf.nn.ctc_loss / tf.nn.ctc_greedy_decoder (tests/golden/tf_ctc_known_answers.json): not via the oracle."""
+    for tf.nn.ctc_loss / tf.nn.ctc_greedy_decoder (tests/golden/tf_known_answers.json): not via the oracle."""
     import torch
-    kat = json.loads((ROOT / "tests" / "golden" / "tf_ctc_known_answers.json").read_text())
+    kat = json.loads((ROOT / "tests" / "golden" / "tf_known_answers.json").read_text())
     cases = kat["ctc_loss"]
     t, k = 5, 6
     logits = np.stack([np.log(np.array(c["probs"], dtype=np.float64)) for c in cases]).astype(np.float32)

@@ -144,7 +144,7 @@ def test_ctc_core_against_tensorflow_known_answers():
     net.py:402-406 and net.py:452-454 bottom out in; provenance in the fixture): loss, gradient w.r.t. the logits and the
     decoded sequences, plus Keras' own backend test of K.ctc_batch_cost on the same data (padded batch, log(p + 1e-8))."""
     import json
-    kat = json.loads((GOLDEN / "tf_ctc_known_answers.json").read_text())
+    kat = json.loads((GOLDEN / "tf_known_answers.json").read_text())
     for case in kat["ctc_loss"]:
         p = np.array(case["probs"], dtype=np.float64)
         assert np.abs(p.sum(axis=1) - 1).max() < 2e-6  # the fixture's self-check: rows are softmax outputs
@@ -167,6 +167,51 @@ def test_ctc_core_against_tensorflow_known_answers():
     dec = kat["ctc_greedy_decoder"]
     got = o.greedy_decode_indices(np.array(dec["probs"]), dec["sequence_length"])
     assert [list(d) for d in got] == dec["decoded"]
+
+
+def _tf_conv_cases():
+    """(name, x (B,T,Cin), w (k,Cin,Cout), stride, expected (B,frames,Cout)) from the TensorFlow conv known answers"""
+    import json
+    cases = {c["name"]: c for c in json.loads((GOLDEN / "tf_known_answers.json").read_text())["conv"]["cases"]}
+    out = []
+    c = cases["testConv2D1x2Filter"]
+    x = np.arange(1, 19, dtype=np.float64).reshape(c["x_shape"])
+    w = np.arange(1, 19, dtype=np.float64).reshape(c["w_shape"])
+    out.append((c["name"], x, w, 1, np.array(c["expected"]).reshape(2, 2, 3)))
+    c = cases["testConv2D2x2FilterStride2Same"]
+    x2 = np.arange(1, 19, dtype=np.float64).reshape(c["x_shape_2d"])
+    w2 = np.arange(1, 37, dtype=np.float64).reshape(c["w_shape_2d"])
+    x1 = np.concatenate([x2[0], x2[1]], axis=1)[None]   # (1, 3 frames, 6 = (kh, ci))
+    w1 = np.concatenate([w2[0], w2[1]], axis=1)         # (kw, 6, co)
+    out.append((c["name"], x1, w1, 2, np.array(c["expected"]).reshape(1, 2, 3)))
+    return out, cases
+
+
+def test_conv_against_tensorflow_known_answers():
+    """TF "SAME" padding + convolution arithmetic of the oracle against TensorFlow's own conv_ops_test.py cases (fixture
+    tests/golden/tf_known_answers.json): kernel 2 at stride 1, kernel 2 at stride 2 with the asymmetric right pad, and
+    kernel 1 at stride 2."""
+    convs, cases = _tf_conv_cases()
+    for name, x, w, stride, want in convs:
+        z = o.conv1d_preactivation(x, w, np.zeros(w.shape[2]), stride)
+        assert np.array_equal(z[:, :want.shape[1]], want), name
+    c = cases["testConv2DKernelSmallerThanStrideSame"]
+    for n, want in zip(c["n"], c["expected"]):
+        img = np.arange(1, n * n + 1, dtype=np.float64).reshape(n, n, 1)
+        z = o.conv1d_preactivation(img, np.ones((1, 1, 1)), np.zeros(1), 2)
+        assert z[::2].reshape(-1).tolist() == want
+
+
+def test_conv_gradients_against_tensorflow_known_answers():
+    """Input and filter gradients of the oracle's convolution against conv_ops_test.py's backprop known answers."""
+    import json
+    c = json.loads((GOLDEN / "tf_known_answers.json").read_text())["conv"]["backprop"]
+    x, w, dz = np.array(c["x"])[None], np.array(c["w"]), np.array(c["dz"])[None]
+    # the fixture's 1-D restatement is the published 2-D answer, transposed: dx[w][kh], dw[kw][kh]
+    assert np.array(c["dx"]).T.reshape(-1).tolist() == c["expected_input_gradient_2d"]
+    assert np.array(c["dw"])[:, :, 0].T.reshape(-1).tolist() == c["expected_filter_gradient_2d"]
+    dx, dw, db = o.conv1d_backward(x, w, 1, dz)
+    assert np.array_equal(dx[0], np.array(c["dx"])) and np.array_equal(dw, np.array(c["dw"])) and db.tolist() == [3.0]
 
 
 def test_greedy_decode_known_answers():
