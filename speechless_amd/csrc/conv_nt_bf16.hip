@@ -754,28 +754,37 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         //   B: 4*IT MFMAs of k-half 1, one read of the NEXT tile's k-half 0 after every second MFMA, then the request
         //      of the weight tile that re-uses this slot (branch-free: past the end the last tile is requested again
         //      into a slot nobody reads) somewhere among the remaining MFMAs
-        int issued = 0;
-        const __bf16* ws_next = nullptr;  // source of the weight tile being requested piecewise
-        char* wl_next = nullptr;
-        auto begin_w = [&](int slot) {  // address of the next tile; advances the (clamped) request counters
-            ws_next = wbase + (long)tap_i * a.cin + cc_i * BK;
-            wl_next = smem + RING0 + slot * W_BYTES + (wave * WPW) * 1024;
-            const bool more = issued + 1 < n;
-            issued += more ? 1 : 0;
-            const bool wrap = tap_i + 1 == taps;
-            const int t1 = wrap ? 0 : tap_i + 1;
-            cc_i = (more && wrap) ? cc_i + 1 : cc_i;
-            tap_i = more ? t1 : tap_i;
+        // All per-step scalar / address work (next weight tile's source and slot, the compute-side counters, the LDS
+        // address of the next step's activation fragments) rides in phase A in the shadow of MFMA groups, pinned there by
+        // asm: left between the barrier and phase B it is a ~40-instruction clump that every wave of the work-group
+        // executes at the same moment with the matrix pipe empty (the waves are in lockstep, so the second wave of a
+        // SIMD does not cover it).
+        int left = n;                     // requests that still advance the stream (past the end: the last tile again)
+        const __bf16* ws_r = wbase + (long)c0 * BK;  // source of the next weight tile to request (tap 0 of chunk c0)
+        int tap_r = 0;
+        const int w_wrap = BK - (taps - 1) * a.cin;  // element step from the last tap of a chunk to tap 0 of the next
+        const __bf16* ws_next = nullptr;  // source / LDS offset of the weight tile phase B requests piecewise
+        unsigned wl_next = 0;
+        const unsigned wave_w = RING0 + (wave * WPW) * 1024;
+        auto begin_w = [&](int slot) {
+            ws_next = ws_r;
+            wl_next = slot * W_BYTES + wave_w;
+            const bool more = left > 1;
+            const bool wrap = tap_r + 1 == taps;
+            int dw = wrap ? w_wrap : a.cin;
+            dw = more ? dw : 0;
+            ws_r += dw;
+            tap_r = wrap ? 0 : tap_r + 1;  // (keeps cycling past the end: dw is zero there)
+            left = more ? left - 1 : left;
         };
-        auto no_hook = [](auto) {};
         auto dma_hook = [&](auto q_c) {  // groups 0..WPW-1 of phase B each carry one request of the tile
             constexpr int Q = decltype(q_c)::value;
 #if defined(SL_PROBE_NO_DMA)  // timing probes only (wrong results): how much of the step is waiting for the weight stream
             (void)q_c;
 #elif defined(SL_PROBE_HALF_DMA)
-            if constexpr (Q < WPW / 2) glds16(ws_next + woff[Q], wl_next + Q * 1024);
+            if constexpr (Q < WPW / 2) glds16(ws_next + woff[Q], smem + wl_next + Q * 1024);
 #else
-            if constexpr (Q < WPW) glds16(ws_next + woff[Q], wl_next + Q * 1024);
+            if constexpr (Q < WPW) glds16(ws_next + woff[Q], smem + wl_next + Q * 1024);
 #endif
         };
         constexpr int GS = 2;  // MFMAs per interleave group, see conv_nt_bf16_kernel
@@ -784,7 +793,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         for (int i = 0; i < STAGES; ++i) {
             begin_w(i);
 #pragma unroll
-            for (int q = 0; q < WPW; ++q) glds16(ws_next + woff[q], wl_next + q * 1024);
+            for (int q = 0; q < WPW; ++q) glds16(ws_next + woff[q], smem + wl_next + q * 1024);
         }
         wait_vmcnt<WPW*(STAGES - 1)>();
         __builtin_amdgcn_s_barrier();
@@ -794,31 +803,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         DsReadRun<0, 4, 512>::go(a0, lds0 + aoff);
         DsReadRun<0, IT, 2048>::go(b0, lds0 + b_offset(0, 0));
         int cur = 0;
+        // what phase A's hooks prepare for the barrier and phase B of the same step
+        int slab_chunk = -1, slab_par = 0;  // slab to request right after the barrier (-1: none)
+        int wait_slab = 0;                  // STAGES > 2: tap of the step if a slab request may be among the loads in flight
+        unsigned b_next = 0;                // LDS address of the next step's first-half activation fragments
+        auto pin_w = [&]() {
+            begin_w(cur);
+            asm volatile("" : "+s"(ws_next), "+s"(wl_next), "+s"(ws_r));
+        };
+        auto pin_counters = [&]() {
+            const bool has_next = chunk_c + 1 < nchunks;
+            slab_chunk = (tap_c == 0 && has_next) ? c0 + chunk_c + 1 : -1;
+            slab_par = par_c ^ 1;
+            wait_slab = has_next ? tap_c : 0;  // in [1, STAGES-2]: the slab request may stay in flight at the wait
+            const bool wrap = tap_c + 1 == taps;
+            chunk_c = wrap ? chunk_c + 1 : chunk_c;
+            par_c = chunk_c & 1;
+            tap_c = wrap ? 0 : tap_c + 1;
+            asm volatile("" : "+s"(slab_chunk), "+s"(slab_par), "+s"(chunk_c), "+s"(tap_c));
+        };
+        auto pin_b_next = [&]() {
+            b_next = lds0 + b_offset(par_c, tap_c);
+            asm volatile("" : "+v"(b_next));
+        };
+        auto hook_a = [&](auto q_c) {
+            constexpr int Q = decltype(q_c)::value;
+            if constexpr (Q == 1) pin_w();
+            if constexpr (Q == 3) pin_counters();
+            if constexpr (Q == 5) pin_b_next();
+        };
+        static_assert(4 * IT / GS > 5, "phase A needs six groups for its hooks");
         for (int i = 0; i < n; ++i) {
             const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
             wait_frags<0>(a0, b0);
             IlvPhase<IT, GS, 0, 4 * IT / GS>::run(acc, a0, b0, a1, b1, lds0 + ((aoff + cur * W_BYTES) ^ 64),
-                                          lds0 + (b_offset(par_c, tap_c) ^ 64), no_hook);
+                                          lds0 + (b_offset(par_c, tap_c) ^ 64), hook_a);
             wait_frags<0>(a1, b1);  // my reads of weight slot cur (and, on a chunk's last tap, of its slab) are complete
             if constexpr (STAGES == 2) {
                 wait_vmcnt<0>();
             } else {  // weight tile i+1 has landed; the STAGES-2 younger ones (and a slab requested among them) fly on
-                if (tap_c >= 1 && tap_c <= STAGES - 2 && chunk_c + 1 < nchunks)
+                if (wait_slab >= 1 && wait_slab <= STAGES - 2)
                     wait_vmcnt<WPW*(STAGES - 2) + XPW>();
                 else
                     wait_vmcnt<WPW*(STAGES - 2)>();
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            // once per chunk, in front of the straight-line phase
-            if (tap_c == 0 && chunk_c + 1 < nchunks) issue_slab(c0 + chunk_c + 1, par_c ^ 1);
-            const bool wrap = tap_c + 1 == taps;
-            chunk_c += wrap ? 1 : 0;
-            par_c = wrap ? par_c ^ 1 : par_c;
-            tap_c = wrap ? 0 : tap_c + 1;
-            begin_w(cur);
-            IlvPhase<IT, GS, 0, 4 * IT / GS>::run(acc, a1, b1, a0, b0, lds0 + aoff + nxt * W_BYTES, lds0 + b_offset(par_c, tap_c),
-                                          dma_hook);
+            if (slab_chunk >= 0) issue_slab(slab_chunk, slab_par);  // once per chunk, in front of the straight-line phase
+            IlvPhase<IT, GS, 0, 4 * IT / GS>::run(acc, a1, b1, a0, b0, lds0 + aoff + nxt * W_BYTES, b_next, dma_hook);
             cur = nxt;
         }
         wait_vmcnt<0>();       // the surplus requests still target this work-group's LDS
