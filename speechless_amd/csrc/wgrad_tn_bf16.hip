@@ -337,29 +337,43 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_ilv_kernel(TnArgs a) {
     const __bf16* xbase = a.x + group * a.x_gs + (long)(a.x_row0 + tap) * a.x_rs + ci_tile * TCI;
     const __bf16* gbase = a.g + group * a.g_gs + (long)a.g_row0 * a.g_rs + co_tile * TCO;
 
+    // Request stream: sources of the NEXT tile, advanced by pointer increments (one 64-row chunk down, or on to the
+    // next utterance); past the end the last tile is requested again into a dead slot.  The former per-step
+    // "step -> (utterance, chunk)" division plus 64-bit multiplies was a ~55-instruction scalar clump between phase A
+    // and the barrier, executed by all eight waves at the same moment with the matrix pipe empty.
     const __bf16* xs_n = nullptr;
     const __bf16* gs_n = nullptr;
-    char* xl_n = nullptr;
-    char* gl_n = nullptr;
-    auto begin_stage = [&](int step, int buf) {  // past the end the last tile is requested again (dead slot)
-        const int st = step < n ? step : n - 1;
-        const int bb = st / a.t_chunks;
-        const int tc = st - bb * a.t_chunks;
-        const int b = b_begin + bb;
-        xs_n = xbase + (long)b * a.x_bs + (long)(tc * TK) * a.x_rs;
-        gs_n = gbase + (long)b * a.g_bs + (long)(tc * TK) * a.g_rs;
-        xl_n = smem + buf * STAGE_BYTES + (wave * XPW) * 1024;
-        gl_n = smem + buf * STAGE_BYTES + X_BYTES + (wave * GPW) * 1024;
+    unsigned xl_n = 0, gl_n = 0;  // LDS byte offsets of this wave's part of the slot being refilled
+    const long x_step = (long)TK * a.x_rs, g_step = (long)TK * a.g_rs;
+    const long x_wrap = (long)a.x_bs - (long)(a.t_chunks - 1) * x_step;
+    const long g_wrap = (long)a.g_bs - (long)(a.t_chunks - 1) * g_step;
+    const __bf16* xs_r = xbase + (long)b_begin * a.x_bs;
+    const __bf16* gs_r = gbase + (long)b_begin * a.g_bs;
+    int tc_r = 0, left = n;
+    const unsigned wave_x = (wave * XPW) * 1024, wave_g = X_BYTES + (wave * GPW) * 1024;
+    auto begin_stage = [&](int buf) {
+        xs_n = xs_r;
+        gs_n = gs_r;
+        xl_n = buf * STAGE_BYTES + wave_x;
+        gl_n = buf * STAGE_BYTES + wave_g;
+        const bool more = left > 1;
+        const bool wrap = tc_r + 1 == a.t_chunks;
+        long dx = wrap ? x_wrap : x_step;
+        long dg = wrap ? g_wrap : g_step;
+        dx = more ? dx : 0L;
+        dg = more ? dg : 0L;
+        xs_r += dx;
+        gs_r += dg;
+        tc_r = wrap ? 0 : tc_r + 1;
+        left = more ? left - 1 : left;
     };
     auto dma_piece = [&](auto q_c) {
         constexpr int Q = decltype(q_c)::value;
         if constexpr (Q < XPW)
-            glds16(xs_n + xoff[Q], xl_n + Q * 1024);
+            glds16(xs_n + xoff[Q], smem + xl_n + Q * 1024);
         else if constexpr (Q < XPW + GPW)
-            glds16(gs_n + goff_src[Q - XPW], gl_n + (Q - XPW) * 1024);
+            glds16(gs_n + goff_src[Q - XPW], smem + gl_n + (Q - XPW) * 1024);
     };
-    auto no_hook = [](auto) {};
-
     const int i16 = lane & 15;
     const int rkey = (i16 >> 2) | ((g & 1) << 2);
     const int rrow = g * 8 + (i16 >> 2);
@@ -379,39 +393,59 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_ilv_kernel(TnArgs a) {
     if (n > 0) {
 #pragma unroll
         for (int i = 0; i < STAGES; ++i) {
-            begin_stage(i, i);
+            begin_stage(i);
 #pragma unroll
-            for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], xl_n + q * 1024);
+            for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], smem + xl_n + q * 1024);
 #pragma unroll
-            for (int q = 0; q < GPW; ++q) glds16(gs_n + goff_src[q], gl_n + q * 1024);
+            for (int q = 0; q < GPW; ++q) glds16(gs_n + goff_src[q], smem + gl_n + q * 1024);
         }
         wait_vmcnt<(XPW + GPW) * (STAGES - 1)>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         TrFrags f0, f1;
-        unsigned ga[4], xa[8];
+        unsigned ga[4], xa[8];  // fragment read addresses in the slot being read (k-half 0)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tr_read8<0, GRB>(f0.gl[j], f0.gh[j], lds0 + grel[j]);
+        for (int j = 0; j < 4; ++j) ga[j] = lds0 + grel[j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tr_read8<0, XRB>(f0.xl[j], f0.xh[j], lds0 + xrel[j]);
+        for (int j = 0; j < 8; ++j) xa[j] = lds0 + xrel[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_read8<0, GRB>(f0.gl[j], f0.gh[j], ga[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tr_read8<0, XRB>(f0.xl[j], f0.xh[j], xa[j]);
         int cur = 0;
+        int slot_delta = 0;  // byte distance from the slot phase A reads to the slot phase B (and the next phase A) reads
+        // Phase A carries, in the shadow of its MFMA groups: the request-stream arithmetic (group 1) and, once its own
+        // twelve fragment reads are out (groups 12-14), the move of the read addresses to the other slot.
+        auto pin_stage = [&]() {
+            begin_stage(cur);
+            asm volatile("" : "+s"(xs_n), "+s"(gs_n), "+s"(xl_n), "+s"(gl_n), "+s"(xs_r), "+s"(gs_r));
+        };
+        auto move_g = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ga[j] += slot_delta;
+            asm volatile("" : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]));
+        };
+        auto move_x = [&](int j0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xa[j0 + j] += slot_delta;
+            asm volatile("" : "+v"(xa[j0]), "+v"(xa[j0 + 1]), "+v"(xa[j0 + 2]), "+v"(xa[j0 + 3]));
+        };
+        auto hook_a = [&](auto q_c) {
+            constexpr int Q = decltype(q_c)::value;
+            if constexpr (Q == 1) pin_stage();
+            if constexpr (Q == 12) move_g();
+            if constexpr (Q == 13) move_x(0);
+            if constexpr (Q == 14) move_x(4);
+        };
         for (int i = 0; i < n; ++i) {
             const int nxt = cur ^ 1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ga[j] = lds0 + cur * STAGE_BYTES + grel[j];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xa[j] = lds0 + cur * STAGE_BYTES + xrel[j];
+            slot_delta = (nxt - cur) * STAGE_BYTES;
             wait_trfrags(f0);
-            TrPhase<1, 0, 16>::run(acc, f0, f1, ga, xa, no_hook);  // k-half 0 multiplies, k-half 1 is read
+            TrPhase<1, 0, 16>::run(acc, f0, f1, ga, xa, hook_a);  // k-half 0 multiplies, k-half 1 is read
             wait_trfrags(f1);  // my reads of slot cur are complete
             wait_vmcnt<0>();   // tile i+1 has landed (2-slot ring)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            begin_stage(i + STAGES, cur);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ga[j] = lds0 + nxt * STAGE_BYTES + grel[j];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xa[j] = lds0 + nxt * STAGE_BYTES + xrel[j];
             TrPhase<0, 0, 16>::run(acc, f1, f0, ga, xa, dma_piece);  // k-half 1 multiplies, next tile's k-half 0 is read
             cur = nxt;
         }
