@@ -269,32 +269,32 @@ def main():
         "kernels": groups,
     }
     if args.config == 3:
-        # Dominant kernel (largest share of main-stream GPU time, profiles/r01i_kernel_stats.csv): wgrad_tn_ilv_kernel,
-        # the 8-wave interleaved 256x256-tile weight-gradient kernel.  TWO launches per step use it (the library's
-        # measured table picks it for big_conv_1 and for the grouped launch that covers the seven inner_conv_i);
-        # algorithmic FLOPs per launch = (sum of those eight layers' wgrad FLOPs) / 2.
-        dom_layers = ("big_conv_1",) + tuple("inner_conv_{}".format(i) for i in range(1, 8))
+        # Dominant kernel (largest share of main-stream GPU time, profiles/r01j_kernel_stats.csv): wgrad_tn_ilv_kernel,
+        # the 8-wave interleaved 256x256-tile weight-gradient kernel.  THREE launches per step use it (the library's
+        # measured table picks it for big_conv_1, big_conv_2 and the grouped launch that covers the seven inner_conv_i);
+        # algorithmic FLOPs per launch = (sum of those nine layers' wgrad FLOPs) / 3.
+        dom_layers = ("big_conv_1", "big_conv_2") + tuple("inner_conv_{}".format(i) for i in range(1, 8))
         dom_tags = [t for t in live_ms if t.startswith("wgrad:") and
-                    t not in ("wgrad:output_conv", "wgrad:striding_conv", "wgrad:big_conv_2")]
+                    t not in ("wgrad:output_conv", "wgrad:striding_conv")]
         dom_flops = sum(fl[i] for i, n in enumerate(names) if n in dom_layers) * BATCH_PER_GPU / len(dom_tags)
         dom_ms = sum(live_ms[t] for t in dom_tags) / len(dom_tags)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         traffic = None
-        pmc = ROOT / "profiles" / "r01i_pmc_traffic_wgrad_ilv.json"
+        pmc = ROOT / "profiles" / "r01j_pmc_traffic_wgrad_ilv.json"
         if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 correction)
             traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
         result["roofline"] = {
-            "bound": "mfma", "kernel": "wgrad_tn_ilv_kernel (weight gradient of big_conv_1 and the grouped "
+            "bound": "mfma", "kernel": "wgrad_tn_ilv_kernel (weight gradient of big_conv_1, big_conv_2 and the grouped "
                                        "inner_conv_1..7 launch; average over its {} launches per "
                                        "step)".format(len(dom_tags)),
             "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
             "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits included), "
-                            "average of its two launches per step, profiles/r01i_pmc_traffic_wgrad_ilv.json "
+                            "average of its launches per step, profiles/r01j_pmc_traffic_wgrad_ilv.json "
                             "(tools/pmc_traffic.sh)",
             "duration_note": "HIP events around the sl_conv1d_wgrad call on its stream: the kernel plus, for the "
-                             "batch-split grouped launch, the deterministic wgrad_reduce_grouped_kernel tail; compare "
-                             "with the kernel-only average in profiles/r01i_kernel_stats.csv",
+                             "batch-split launches, the deterministic reduction kernel tail; compare "
+                             "with the kernel-only average in profiles/r01j_kernel_stats.csv",
             "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms}
     if args.config in (2, 3):
         nt_flops = fl[names.index("big_conv_1")] * BATCH_PER_GPU

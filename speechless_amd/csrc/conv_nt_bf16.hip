@@ -1152,13 +1152,13 @@ Cfg decode_cfg(int cfg) {
 }
 
 Cfg auto_cfg(const sl_conv_geom* g) {
-    // Table measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01i_tune_kernels.json), see DESIGN.md section 3.1.
+    // Table measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01j_tune_kernels.json), see DESIGN.md section 3.1.
     const long nsteps = (long)g->taps * (g->cin / BK);
     if (g->cout % 256 == 0) {
         const long tiles256 = (long)g->batch * ((g->t_out + 255) / 256) * (g->cout / 256);
         const bool slab_ok = g->taps >= 2 && g->taps <= 33;
         // 256x256 tile, one work-group per CU.  With taps the slab variant (8 waves of 128x64, register-pipelined,
-        // hand-interleaved MFMA / LDS-read / DMA-request stream): big_conv_1 forward 0.334 ms = 1.53 PFLOP/s (0.345
+        // hand-interleaved MFMA / LDS-read / DMA-request stream): big_conv_1 forward 0.327 ms = 1.57 PFLOP/s (0.345
         // un-interleaved, 0.372 for the 16-wave tap-major kernel); 1x1 layers: the same 8-wave tile, tap-major,
         // interleaved (big_conv_2 forward 0.104 ms = 1.24 PFLOP/s, 0.107 for the 16-wave kernel)
         if (tiles256 >= 192) return slab_ok ? Cfg{2, 4, 10, 1, 8, 0, 0, 1, 1} : Cfg{2, 4, 10, 1, 8, 0, 0, 0, 1};

@@ -521,13 +521,13 @@ int choose_splits(const sl_conv_geom* g, int tci, int tco, int target_wgs, int g
 }
 
 WCfg auto_wcfg(const sl_conv_geom* g, int groups) {
-    // measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01i_tune_kernels.json), see DESIGN.md section 3
+    // measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01j_tune_kernels.json), see DESIGN.md section 3
     if (g->cin % 256 == 0 && g->cout % 256 == 0) {
         const long tiles256 = (long)g->taps * (g->cin / 256) * (g->cout / 256) * groups;
-        // 256x256 tile, 8 waves, interleaved stream: big_conv_1 0.351 ms = 1.46 PFLOP/s (16-wave kernel 0.363, 128x128
-        // tiles 0.45); the grouped inner-layer launch 0.1175 ms (16-wave 0.123).  big_conv_2 (64 such tiles) and
-        // striding_conv (24) are better off with 128x128 tiles and a batch split: 0.107 vs 0.110 ms, 0.062 vs 0.066 ms
-        if (tiles256 >= 128 || (groups > 1 && tiles256 >= 48)) return WCfg{4, 4, 10, choose_splits(g, 256, 256, 256, groups)};
+        // 256x256 tile, 8 waves, interleaved stream: big_conv_1 0.329 ms = 1.55 PFLOP/s (16-wave kernel 0.374, 128x128
+        // tiles 0.45); the grouped inner-layer launch 0.105 ms (16-wave 0.123); big_conv_2 (64 such tiles, batch split
+        // 4) 0.106 ms against 0.108 for 128x128 tiles.  striding_conv (128 input channels) keeps the 128x128 tiles.
+        if (tiles256 >= 64 || (groups > 1 && tiles256 >= 48)) return WCfg{4, 4, 10, choose_splits(g, 256, 256, 256, groups)};
     }
     // short layers: 128x128 tiles, batch split so that ~2 work-groups land on every CU (deeper rings measured no gain)
     return WCfg{2, 2, 2, choose_splits(g, 128, 128, 512, groups)};
