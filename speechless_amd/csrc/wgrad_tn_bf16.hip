@@ -140,18 +140,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
     const __bf16* xbase = a.x + group * a.x_gs + (long)(a.x_row0 + tap) * a.x_rs + ci_tile * TCI;
     const __bf16* gbase = a.g + group * a.g_gs + (long)a.g_row0 * a.g_rs + co_tile * TCO;
 
-    auto stage = [&](int step, int buf) {
-        const int bb = step / a.t_chunks;
-        const int tc = step - bb * a.t_chunks;
-        const int b = b_begin + bb;
-        const __bf16* xs = xbase + (long)b * a.x_bs + (long)(tc * TK) * a.x_rs;
-        const __bf16* gs = gbase + (long)b * a.g_bs + (long)(tc * TK) * a.g_rs;
+    // the tiles are requested in step order: the sources advance by pointer increments (one 64-row chunk down, or on to
+    // the next utterance) instead of a per-step "step -> (utterance, chunk)" division and 64-bit multiplies -- with one
+    // wave per SIMD (the 4-wave tile) that scalar clump sat between the barrier and the MFMAs with the matrix pipe empty
+    const long x_step = (long)TK * a.x_rs, g_step = (long)TK * a.g_rs;
+    const long x_wrap = (long)a.x_bs - (long)(a.t_chunks - 1) * x_step;
+    const long g_wrap = (long)a.g_bs - (long)(a.t_chunks - 1) * g_step;
+    const __bf16* xs_r = xbase + (long)b_begin * a.x_bs;
+    const __bf16* gs_r = gbase + (long)b_begin * a.g_bs;
+    int tc_r = 0;
+    auto stage = [&](int buf) {
         char* xl = smem + buf * STAGE_BYTES + (wave * XPW) * 1024;
         char* gl = smem + buf * STAGE_BYTES + X_BYTES + (wave * GPW) * 1024;
 #pragma unroll
-        for (int q = 0; q < XPW; ++q) glds16(xs + xoff[q], xl + q * 1024);
+        for (int q = 0; q < XPW; ++q) glds16(xs_r + xoff[q], xl + q * 1024);
 #pragma unroll
-        for (int q = 0; q < GPW; ++q) glds16(gs + goff_src[q], gl + q * 1024);
+        for (int q = 0; q < GPW; ++q) glds16(gs_r + goff_src[q], gl + q * 1024);
+        const bool wrap = tc_r + 1 == a.t_chunks;
+        xs_r += wrap ? x_wrap : x_step;
+        gs_r += wrap ? g_wrap : g_step;
+        tc_r = wrap ? 0 : tc_r + 1;
     };
 
     // ---- transpose-read addresses.  lane (g, i): row = kk*32 + g*8 + h*4 + (i>>2); 8-B piece (i&3) of 16-col block c16
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
 
 #pragma unroll
     for (int i = 0; i < STAGES - 1; ++i)
-        if (i < n) stage(i, i);
+        if (i < n) stage(i);
     int cur = 0, nxt = STAGES - 1;
     for (int i = 0; i < n; ++i) {
         if (i + STAGES - 1 <= n)
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (i + STAGES - 1 < n) stage(i + STAGES - 1, nxt);
+        if (i + STAGES - 1 < n) stage(nxt);
         const unsigned sl = lds0 + cur * STAGE_BYTES;
         compute_step(sl);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
