@@ -170,7 +170,7 @@ __device__ __forceinline__ void store_run16(const NtArgs& a, float (&v)[16], con
             p0[i] = pack_bf16x2(v[i * 2], v[i * 2 + 1]);
             p1[i] = pack_bf16x2(v[8 + i * 2], v[8 + i * 2 + 1]);
         }
-        *(u32x4*)(yo) = p0;
+        *(u32x4*)(yo) = p0;  // (nontemporal stores measured: step 2.35 vs 2.30 ms)
         *(u32x4*)(yo + 8) = p1;
     }
 }

@@ -12,6 +12,7 @@ Master weights / gradients / Adam moments live in ONE flat fp32 buffer each (lay
 (k, Cin_pad, Cout_pad); the gradient buffer is what the data-parallel all-reduce operates on.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -310,6 +311,7 @@ class Engine:
         self.timeline = None
         self._side_stream = None
         self.overlap_wgrad = False
+        self.defer_bias_grads = os.environ.get("SL_DEFER_BGRAD", "1") != "0"  # A/B knob, see backward()
         # train_step_resident: Adam of a layer runs under the rest of backward (see backward()).  Measured on MI355X
         # (tools/step_ab.py): 2.546 ms/step either way -- the HBM-bound update slows the MFMA kernels it overlaps by as
         # much as it costs alone -- so it is off by default, which also keeps per-kernel timings clean.
@@ -588,25 +590,41 @@ class Engine:
             else:
                 bucket_layers.extend(layers)
 
+        # (those two need every layer's bias gradient at once; defer_bias_grads = False restores one hand-over per layer)
+        defer = self.defer_bias_grads and not (early_adam or self.overlap_wgrad)
+        pending, pending_bytes = [], 0  # layers whose bias-gradient launch is still owed to the side stream
         for p in reversed(self.plans[first:]):
             i = p.index
             x = (buf.x0_dropped if buf.dropped else buf.x0) if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
-            ready = torch.cuda.Event()
-            ready.record(main)  # g[i] (CTC gradient or the previous dgrad) is complete at this point of MAIN
-            wgrad_stream = side if self.overlap_wgrad else main
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                if self.overlap_wgrad:
-                    self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
-                                 dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
-                                 self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
-                                 buf.wgrad_ws.numel(), wgrad_stream.cuda_stream)
-                self._launch("bgrad:" + p.spec.name, "sl_bias_grad", buf.g[i].data_ptr(), db.data_ptr(),
-                             ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, buf.bias_ws.data_ptr(),
-                             buf.bias_ws.numel(), side.cuda_stream)
-                if self.overlap_wgrad and on_bucket_ready is not None and i == split:
-                    on_bucket_ready(0)
+            # bias gradient of layer i: deferred until enough work has piled up for one hand-over to the side stream.
+            # Every hand-over is an event record on MAIN, and the record costs MAIN ~6 us of pipeline drain
+            # (profiles/r01j: 11 records = the only gaps in the step's timeline); g[i] stays intact until the next step,
+            # so the small layers' bias gradients can wait for a common hand-over.
+            if os.environ.get("SL_DEFER_BGRAD") != "skip":  # ("skip": timing experiment only, no bias gradients)
+                pending.append(i)
+            pending_bytes += buf.g[i].numel() * buf.g[i].element_size()
+            if pending and (not defer or pending_bytes >= (64 << 20) or i <= first + 1 or
+                            (on_bucket_ready is not None and i == split)):
+                ready = torch.cuda.Event()
+                ready.record(main)  # g[j], j in pending (CTC gradient or a previous dgrad) are complete at this point of MAIN
+                wgrad_stream = side if self.overlap_wgrad else main
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    if self.overlap_wgrad:
+                        self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
+                                     dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
+                                     self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
+                                     buf.wgrad_ws.numel(), wgrad_stream.cuda_stream)
+                    for j in pending:
+                        _, db_j = self.layer_param_views(self.grads, self.plans[j])
+                        self._launch("bgrad:" + self.plans[j].spec.name, "sl_bias_grad", buf.g[j].data_ptr(),
+                                     db_j.data_ptr(), ctypes.byref(buf.wgrad_geom[j]), self.dtype_code,
+                                     buf.bias_ws.data_ptr(), buf.bias_ws.numel(), side.cuda_stream)
+                    if self.overlap_wgrad and on_bucket_ready is not None and i == split:
+                        on_bucket_ready(0)
+                del pending[:]
+                pending_bytes = 0
             if i in grouped:
                 lo, hi = grouped[i]
                 if i == lo:  # every g[lo..hi] is complete now: one launch for the whole run
