@@ -555,7 +555,7 @@ class Engine:
         buf = self.cur
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
+            self._side_stream = torch.cuda.Stream(device=self.device)  # (ROCm offers no priority below the default)
         side = self._side_stream
         first = self.frozen_layer_count
         _, split = self.bucket_ranges()
