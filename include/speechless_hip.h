@@ -86,9 +86,11 @@ const char* sl_last_error(void);
  *   y      : [B][rows][y_row_stride]; dtype, or float when out_f32 != 0
  *   cfg    : 0 = library picks the tile shape / pipeline depth / split-K for this geometry (measured table);
  *            otherwise (tuner / tests) wm | wn<<4 | stages<<8 | ksplit<<12 | it<<20 | m32<<24 | (1+log2 gm)<<25 |
- *            slab<<29: wm x wn waves, each a (16*it) x 64 patch (it = 0 means 4; m32: 32x32x16 MFMA, 64x64 patch);
+ *            slab<<29 | interleaved<<30: wm x wn waves, each a (16*it) x 64 patch (it = 0 means 4; it = 5: the it = 4
+ *            tile with eight waves, the two waves of a SIMD splitting the k-halves; m32: 32x32x16 MFMA, 64x64 patch);
  *            stages = ring slots, +8 = register-pipelined loop; gm = m-tiles per raster block; slab = chunk-major
- *            kernel with the activation slab in LDS.  SL_ERR_INVALID_ARGUMENT for a shape that is not instantiated
+ *            kernel with the activation slab in LDS; interleaved = hand-interleaved MFMA / LDS-read / request
+ *            streams.  SL_ERR_INVALID_ARGUMENT for a shape that is not instantiated
  *            or that the geometry rules out.  bf16 only; ignored for SL_F32.
  *   workspace: sl_conv1d_nt_workspace_bytes(geom, dtype, cfg) bytes (split-K partial tiles; 0 when not split).
  */

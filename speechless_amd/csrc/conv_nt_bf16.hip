@@ -979,6 +979,197 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 128x128 tile, EIGHT waves: the four 64x64 patches of the 4-wave interleaved kernel, each owned by the two waves that
+// share a SIMD (waves p and p + 4); wave p multiplies k-half 0 of every 64-deep step, wave p + 4 k-half 1, into private
+// accumulators that are added through LDS in the epilogue.  Same LDS bytes and MFMAs per step as four waves, but two
+// instruction streams per SIMD: a single wave issues in order, so every wait, request and address instruction it cannot
+// hide behind its own MFMAs is exposed (0.45 us per step against 0.244 us of MFMAs).
+// One phase and one barrier per step: [frags(i) in registers] wait for tile i+1, barrier, 16 MFMAs on tile i's
+// fragments with the 8 fragment reads of tile i+1 and the 4 requests of tile i+STAGES (into tile i's slot, which every
+// wave has finished reading before the barrier) interleaved.  Tap-major contraction, branch-free request stream.
+template <int STAGES, int MODE, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void conv_nt_ks2_bf16_kernel(NtArgs a) {
+    constexpr int IT = 4, WN = 2, NW = 8;
+    constexpr int WROWS = 64, BM = 128, BN = 128;
+    constexpr int X_BYTES = BM * 128;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int XPW = (BM / 8) / NW, WPW = (BN / 8) / NW, NI = XPW + WPW;  // 2 + 2 requests per wave and tile
+    static_assert(STAGES >= 3 && STAGES * STAGE_BYTES <= 160 * 1024, "ring depth");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2;  // the k-half this wave multiplies
+    const int pw = wave & 3;   // the patch it shares with wave pw + 4 * (1 - kh)
+    const int wm = pw / WN;
+    const int wn = pw % WN;
+
+    const int m_tiles = a.batch * a.t_tiles;
+    const int tiles = m_tiles * a.n_tiles;
+    const int id = xcd_remap(blockIdx.x, tiles * a.ksplit);
+    if (id >= tiles * a.ksplit) return;  // grid padding (xcd_grid)
+    const int split = id / tiles;
+    const int tile = id - split * tiles;
+    const int span = a.n_tiles * a.gm;  // 2-D raster, see conv_nt_bf16_kernel
+    const int blk = tile / span;
+    const int rem = tile - blk * span;
+    int cnt = m_tiles - blk * a.gm;
+    if (cnt > a.gm) cnt = a.gm;
+    const int n_tile = rem / cnt;
+    const int m_tile = blk * a.gm + (rem - n_tile * cnt);
+    const int b = m_tile / a.t_tiles;
+    const int t0 = (m_tile - b * a.t_tiles) * BM;
+    const int co0 = n_tile * BN;
+    const int s_begin = split * a.steps_per_split;
+    int n = a.nsteps - s_begin;
+    if (n > a.steps_per_split) n = a.steps_per_split;
+
+    const __bf16* xbase = a.x + (long)b * a.x_bs + (long)(a.x_row0 + t0) * a.x_rs;
+    const __bf16* wbase = a.w + (long)co0 * a.w_rs;
+    int xoff[XPW], woff[WPW];
+#pragma unroll
+    for (int q = 0; q < XPW; ++q) {
+        const int j = wave * XPW + q;
+        const int row = j * 8 + (lane >> 3);
+        xoff[q] = row * a.x_rs + (((lane & 7) ^ (lane >> 3)) << 3);
+    }
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+        const int j = wave * WPW + q;
+        const int row = j * 8 + (lane >> 3);
+        const int key = ((lane >> 4) & 1) | (((j >> 1) & 3) << 1);
+        woff[q] = row * a.w_rs + (((lane & 7) ^ key) << 3);
+    }
+    const int g = lane >> 4;
+    const int brow = wm * WROWS + (lane & 15);
+    const int arow = wn * 64 + ((lane & 15) >> 2) * 16 + (lane & 3);
+    const int akey = ((lane >> 1) & 1) | (((lane >> 2) & 3) << 1);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned boff = lds0 + ((brow * 128 + ((g ^ (lane & 7)) << 4)) ^ (kh << 6));
+    const unsigned aoff = lds0 + ((X_BYTES + arow * 128 + ((g ^ akey) << 4)) ^ (kh << 6));
+
+    f32x4 acc[4 * IT];
+#pragma unroll
+    for (int i = 0; i < 4 * IT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    NtArgs e = a;  // epilogue arguments pinned in SGPRs before the loop, see conv_nt_bf16_kernel
+    asm volatile("" : "+s"(e.y), "+s"(e.mask), "+s"(e.bias), "+s"(e.partial), "+s"(e.y_bs));
+    asm volatile("" : "+s"(e.y_row0), "+s"(e.y_rs), "+s"(e.t_out), "+s"(e.cout), "+s"(e.batch), "+s"(e.t_tiles));
+
+    // request stream (see conv_nt_bf16_kernel)
+    const __bf16* xs_n = nullptr;
+    const __bf16* ws_n = nullptr;
+    unsigned xl_n = 0, wl_n = 0;
+    const int chunks = a.cin / BK;
+    const int tap_first = s_begin / chunks;
+    int cc_r = s_begin - tap_first * chunks;
+    int r_left = n;
+    const __bf16* xs_r = xbase + (long)tap_first * a.x_rs + cc_r * BK;
+    const __bf16* ws_r = wbase + (long)s_begin * BK;
+    const int x_wrap = a.x_rs - (chunks - 1) * BK;
+    const unsigned wave_x = (wave * XPW) * 1024, wave_w = X_BYTES + (wave * WPW) * 1024;
+    auto next_tile = [&](int slot) {  // past the end the last tile is requested again (into a slot nobody reads)
+        xs_n = xs_r;
+        ws_n = ws_r;
+        xl_n = slot * STAGE_BYTES + wave_x;
+        wl_n = slot * STAGE_BYTES + wave_w;
+        const bool more = r_left > 1;
+        const bool wrap = cc_r + 1 == chunks;
+        int dx = wrap ? x_wrap : BK;
+        dx = more ? dx : 0;
+        xs_r += dx;
+        ws_r += more ? BK : 0;
+        const int cn = wrap ? 0 : cc_r + 1;
+        cc_r = more ? cn : cc_r;
+        r_left = more ? r_left - 1 : r_left;
+    };
+    int cur = 0;
+    auto pin_next = [&]() {
+        next_tile(cur);
+        asm volatile("" : "+s"(xs_n), "+s"(ws_n), "+s"(xl_n), "+s"(wl_n), "+s"(xs_r), "+s"(ws_r));
+    };
+    auto hook = [&](auto q_c) {  // group 0: addresses of the tile that re-uses slot cur; groups 1..4: its requests
+        constexpr int Q = decltype(q_c)::value;
+        if constexpr (Q == 0) pin_next();
+        if constexpr (Q >= 1 && Q <= XPW) glds16(xs_n + xoff[Q - 1], smem + xl_n + (Q - 1) * 1024);
+        if constexpr (Q > XPW && Q <= NI) glds16(ws_n + woff[Q - 1 - XPW], smem + wl_n + (Q - 1 - XPW) * 1024);
+    };
+#pragma unroll
+    for (int i = 0; i < STAGES; ++i) {
+        next_tile(i);
+#pragma unroll
+        for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], smem + xl_n + q * 1024);
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) glds16(ws_n + woff[q], smem + wl_n + q * 1024);
+    }
+    wait_vmcnt<NI*(STAGES - 1)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 a0[4], b0[IT], a1[4], b1[IT];
+    DsReadRun<0, 4, 512>::go(a0, aoff);
+    DsReadRun<0, IT, 2048>::go(b0, boff);
+    auto step = [&](bf16x8 (&ca)[4], bf16x8 (&cb)[IT], bf16x8 (&na)[4], bf16x8 (&nb)[IT]) {
+        const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
+        wait_frags<0>(ca, cb);          // tile i's fragments are in registers: nobody reads slot cur any more ...
+        wait_vmcnt<NI*(STAGES - 2)>();  // ... my part of tile i+1 has landed; the younger tiles stay in flight
+        __builtin_amdgcn_s_barrier();   // ... and so has everybody else's
+        asm volatile("" ::: "memory");
+        IlvPhase<IT, 2, 0, 2 * IT>::run(acc, ca, cb, na, nb, aoff + nxt * STAGE_BYTES, boff + nxt * STAGE_BYTES, hook);
+        cur = nxt;
+    };
+    for (int i = 0; i + 1 < n; i += 2) {
+        step(a0, b0, a1, b1);
+        step(a1, b1, a0, b0);
+    }
+    if (n & 1) {
+        step(a0, b0, a1, b1);
+        wait_frags<0>(a1, b1);  // the surplus fragment reads target these registers
+    } else {
+        wait_frags<0>(a0, b0);
+    }
+    wait_vmcnt<0>();  // the surplus requests still target this work-group's LDS
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---- the k-half-1 waves hand their accumulators over through LDS (16 KiB per patch, lane-linear 16-B slots)
+    f32x4* xch = (f32x4*)smem + (pw * 16) * 64 + lane;
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 4 * IT; ++i) xch[i * 64] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < 4 * IT; ++i) acc[i] += xch[i * 64];
+
+    // ---- epilogue (identical to conv_nt_bf16_kernel's 16x16 path)
+    const int co_base = co0 + wn * 64 + (lane >> 4) * 16;
+    float bias_v[16];
+    if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU || MODE == SL_EPI_BIAS_ELU) load_bias16(e.bias, co_base, bias_v);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int trow = wm * WROWS + it * 16 + (lane & 15);
+        float v[16];
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[jn * 4 + r] = acc[jn * IT + it][r];
+        if (MODE == MODE_PARTIAL) {
+            float* out = e.partial + ((long)(split * e.batch + b) * (e.t_tiles * BM) + t0 + trow) * e.cout + co_base;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(out + i * 4) = (f32x4){v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+        } else {
+            const int t = t0 + trow;
+            if (t < e.t_out) {
+                const long yidx = (long)b * e.y_bs + (long)(e.y_row0 + t) * e.y_rs + co_base;
+                store_run16<MODE, OUT_F32>(e, v, bias_v, yidx);
+            }
+        }
+    }
+}
+
 // split-K tail: out = epi(sum_split partial), 8 channels per thread, fixed summation order
 template <int MODE, bool OUT_F32>
 __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int rows_per_batch) {
@@ -1054,7 +1245,17 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
 template <bool M32, int IT, int WM, int WN, int STAGES, int MODE, bool OUT_F32>
 int launch_main(const NtArgs& a, hipStream_t s) {
     const int grid = xcd_grid(a.batch * a.t_tiles * a.n_tiles * a.ksplit);
-    if constexpr (!M32 && IT >= 100) {  // slab variant: IT - 100 is the real IT (IT - 200: interleaved schedule)
+    if constexpr (!M32 && IT == 50) {  // 128x128 tile, eight waves in k-half pairs (conv_nt_ks2_bf16_kernel)
+        constexpr int LDS_BYTES = (STAGES & 7) * 256 * 128;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_nt_ks2_bf16_kernel<(STAGES & 7), MODE, OUT_F32>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_nt_ks2_bf16_kernel<(STAGES & 7), MODE, OUT_F32>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+        return sl_check_launch("sl_conv1d_nt(bf16, k-half pairs)");
+    } else if constexpr (!M32 && IT >= 100) {  // slab variant: IT - 100 is the real IT (IT - 200: interleaved schedule)
         constexpr bool ILV = IT >= 200;
         constexpr int RIT = ILV ? IT - 200 : IT - 100;
         constexpr int LDS_BYTES = 2 * (16 * RIT * WM / 8 + 4) * 1024 + (STAGES & 7) * 64 * WN * 128;
@@ -1093,7 +1294,7 @@ int launch_tail(const NtArgs& a, int rows_per_batch, hipStream_t s) {
 
 template <bool M32, int IT, int WM, int WN, int STAGES>
 int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
-    constexpr int BM = (M32 ? 64 : 16 * (IT >= 200 ? IT - 200 : IT >= 100 ? IT - 100 : IT)) * WM;
+    constexpr int BM = (M32 ? 64 : 16 * (IT >= 200 ? IT - 200 : IT >= 100 ? IT - 100 : IT == 50 ? 4 : IT)) * WM;
     a.t_tiles = (a.t_out + BM - 1) / BM;
     a.n_tiles = a.cout / (64 * WN);
     if (a.ksplit > 1) {
@@ -1135,10 +1336,11 @@ struct Cfg {
     int gm = 0;  // m-tiles per raster block (0 = automatic)
     int slab = 0;  // chunk-major contraction with the activation slab kept in LDS (conv_nt_slab_bf16_kernel)
     int ilv = 0;   // slab kernel with the hand-interleaved MFMA / LDS-read / DMA-request schedule
+    int ks2 = 0;   // 128x128 tile with eight waves, the two waves of a SIMD splitting the k-halves (cfg it = 5)
     int bm() const { return (m32 ? 64 : 16 * it) * wm; }
 };
 
-// cfg word: wm | wn << 4 | stages << 8 | ksplit << 12 | it << 20 (it = 0 means 4) | m32 << 24 | (1 + log2 gm) << 25 (0 = auto)
+// cfg word: wm | wn << 4 | stages << 8 | ksplit << 12 | it << 20 (it = 0 means 4; 5 = 4 with k-half wave pairs) | m32 << 24 | (1 + log2 gm) << 25 (0 = auto)
 // | slab << 29 | interleaved << 30;  0 = choose everything automatically
 Cfg decode_cfg(int cfg) {
     Cfg c{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 15, (cfg >> 12) & 255, (cfg >> 20) & 15, (cfg >> 24) & 1};
@@ -1148,6 +1350,10 @@ Cfg decode_cfg(int cfg) {
     c.ilv = (cfg >> 30) & 1;
     if (c.it == 0) c.it = 4;
     if (c.m32) c.it = 4;
+    if (c.it == 5) {
+        c.ks2 = 1;
+        c.it = 4;
+    }
     return c;
 }
 
@@ -1191,6 +1397,11 @@ Cfg auto_cfg(const sl_conv_geom* g) {
 bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
     Cfg c = full;
     c.stages = full.stages & 7;  // bit 3 selects the register-pipelined loop, instantiated for the shapes listed below
+    if (c.ks2) {  // instantiated: 2x2 patches, 3 or 4 slots, interleaved tap-major only
+        if (c.m32 || c.slab || !c.ilv || c.wm != 2 || c.wn != 2 || (full.stages != 11 && full.stages != 12)) return false;
+        if (g->cout % 128 || c.ksplit < 1) return false;
+        return c.ksplit <= (long)g->taps * (g->cin / BK);
+    }
     if ((full.stages & 8) && (c.m32 || !((c.it == 4 && c.wm * c.wn >= 4 && c.wm * c.wn <= 8) || c.it == 8 ||
                                          (c.it == 2 && c.wm == 4 && c.wn == 2))))
         return false;
@@ -1291,6 +1502,8 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
             return SL_ERR_WORKSPACE_TOO_SMALL;
         }
     }
+    if (c.ks2 && c.stages == 11) return launch_cfg<false, 50, 2, 2, 11>(a, epilogue, out_f32, s);
+    if (c.ks2 && c.stages == 12) return launch_cfg<false, 50, 2, 2, 12>(a, epilogue, out_f32, s);
 #define SL_NT_SLAB_CASE(IT_, WM_, WN_, ST_)                                      \
     if (c.slab && c.it == IT_ && c.wm == WM_ && c.wn == WN_ && c.stages == ST_) \
         return launch_cfg<false, 100 + IT_, WM_, WN_, ST_>(a, epilogue, out_f32, s);

@@ -604,7 +604,7 @@ class Engine:
             if os.environ.get("SL_DEFER_BGRAD") != "skip":  # ("skip": timing experiment only, no bias gradients)
                 pending.append(i)
             pending_bytes += buf.g[i].numel() * buf.g[i].element_size()
-            if pending and (not defer or pending_bytes >= (64 << 20) or i <= first + 1 or
+            if pending and (not defer or pending_bytes >= (128 << 20) or i <= first + 1 or
                             (on_bucket_ready is not None and i == split)):
                 ready = torch.cuda.Event()
                 ready.record(main)  # g[j], j in pending (CTC gradient or a previous dgrad) are complete at this point of MAIN

@@ -739,6 +739,8 @@ NT_CONFIGS = (
      (2, 2, 11, 1, 4, 0, 0, 1), (2, 2, 12, 1, 4, 0, 0, 1), (2, 4, 10, 2, 8, 0, 0, 1), (4, 2, 11, 4, 2, 0, 0, 1),
      (2, 4, 10, 1, 8, 0, 2, 1), (4, 4, 2, 1, 4, 0, 1, 0), (4, 2, 11, 1, 2, 0, 3, 0),
      (2, 4, 10, 1, 8, 0, 0, 3), (2, 4, 10, 2, 8, 0, 0, 3), (2, 4, 10, 4, 8, 0, 1, 3),
+     # 128x128 tile with eight waves in k-half pairs (it = 5)
+     (2, 2, 11, 1, 5, 0, 0, 2), (2, 2, 12, 1, 5, 0, 0, 2), (2, 2, 11, 2, 5, 0, 0, 2), (2, 2, 12, 3, 5, 0, 3, 2),
      # 4-wave 128x128 interleaved slab kernel, ring of 2 / 3 / 4 weight slots
      (2, 2, 10, 1, 4, 0, 0, 3), (2, 2, 11, 1, 4, 0, 0, 3), (2, 2, 12, 1, 4, 0, 0, 3), (2, 2, 11, 2, 4, 0, 0, 3), (2, 2, 12, 4, 4, 0, 2, 3),
      # interleaved tap-major (slab = 2: only the interleave bit)

@@ -74,7 +74,7 @@ def main():
     # slab variant (chunk-major, activation slab kept in LDS): it + 100
     shapes += [(4, 2, 10, 302), (4, 2, 11, 302), (4, 2, 12, 302), (2, 2, 10, 304), (2, 2, 11, 304), (2, 2, 12, 304),
                (2, 4, 10, 308),  # it + 300: interleaved tap-major
-               (4, 4, 2, 104), (2, 4, 10, 108), (2, 4, 10, 208), (2, 2, 10, 204), (2, 2, 11, 204), (2, 2, 12, 204), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
+               (4, 4, 2, 104), (2, 4, 10, 108), (2, 4, 10, 208), (2, 2, 10, 204), (2, 2, 11, 204), (2, 2, 12, 204), (2, 2, 11, 405), (2, 2, 12, 405), (4, 2, 11, 102), (4, 2, 3, 102), (2, 2, 11, 104), (2, 2, 12, 104)]
     results = {}
     n = len(eng.plans)
     only = set(filter(None, args.layers.split(",")))
@@ -142,6 +142,7 @@ def main():
                 if slab and ks > geom.cin // 64:
                     continue
                 cfg = (cfg_word(wm, wn, stg, ks, 4, 1) if it == 32 else
+                       cfg_word(wm, wn, stg, ks, 5, ilv=1) if it == 405 else
                        cfg_word(wm, wn, stg, ks, it - 300, ilv=1) if it >= 300 else
                        cfg_word(wm, wn, stg, ks, it - 200, slab=1, ilv=1) if it >= 200 else
                        cfg_word(wm, wn, stg, ks, it - 100, slab=1) if slab else cfg_word(wm, wn, stg, ks, it))
