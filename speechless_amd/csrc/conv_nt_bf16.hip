@@ -191,29 +191,37 @@ __device__ __forceinline__ void load_bias16(const float* bias, int co, float (&b
 // fenced (sched_barrier), so the LDS-read / DMA issue slots sit in the shadow of the matrix pipe instead of in a clump
 // between two MFMA blocks; PMC on the un-interleaved loops showed ~110 non-MFMA instructions per step and wave issued
 // while the pipe drained (pipe busy 65 % on the 256x256 tile).
-template <int IT, int G, int Q, int NQ>
+template <int IT, int G, int Q, int NQ, int RPG = 1>
 struct IlvPhase {
+    // RPG = fragment reads per group: 1 spreads the 4+IT reads over the first 4+IT groups (two waves per SIMD cover
+    // each other's read latency); 2 packs them into the first (4+IT)/2 groups, so that the last read has half a phase of
+    // MFMAs behind it before the next phase waits for it (one wave per SIMD)
+    template <int R>
+    static __device__ __forceinline__ void read_one(bf16x8 (&na)[4], bf16x8 (&nb)[IT], unsigned a_addr, unsigned b_addr) {
+        if constexpr (R < 4)
+            ds_read128<R * 512>(na[R], a_addr);
+        else if constexpr (R < 4 + IT)
+            ds_read128<(R - 4) * 2048>(nb[R - 4], b_addr);
+    }
     template <typename Hook>
     static __device__ __forceinline__ void run(f32x4 (&acc)[4 * IT], const bf16x8 (&ca)[4], const bf16x8 (&cb)[IT],
                                                bf16x8 (&na)[4], bf16x8 (&nb)[IT], unsigned a_addr, unsigned b_addr,
                                                const Hook& hook) {
-        static_assert(NQ * G == 4 * IT && NQ >= 4 + IT, "groups must cover the MFMAs and offer a slot per fragment read");
+        static_assert(NQ * G == 4 * IT && NQ * RPG >= 4 + IT, "groups must cover the MFMAs and offer a slot per fragment read");
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int m = G * Q + j;
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[m / IT], cb[m % IT], acc[m], 0, 0, 0);
         }
-        if constexpr (Q < 4)
-            ds_read128<Q * 512>(na[Q], a_addr);
-        else if constexpr (Q < 4 + IT)
-            ds_read128<(Q - 4) * 2048>(nb[Q - 4], b_addr);
+        read_one<RPG * Q>(na, nb, a_addr, b_addr);
+        if constexpr (RPG == 2) read_one<RPG * Q + 1>(na, nb, a_addr, b_addr);
         hook(std::integral_constant<int, Q>{});
         __builtin_amdgcn_sched_barrier(0);
-        IlvPhase<IT, G, Q + 1, NQ>::template run<Hook>(acc, ca, cb, na, nb, a_addr, b_addr, hook);
+        IlvPhase<IT, G, Q + 1, NQ, RPG>::template run<Hook>(acc, ca, cb, na, nb, a_addr, b_addr, hook);
     }
 };
-template <int IT, int G, int NQ>
-struct IlvPhase<IT, G, NQ, NQ> {
+template <int IT, int G, int NQ, int RPG>
+struct IlvPhase<IT, G, NQ, NQ, RPG> {
     template <typename Hook>
     static __device__ __forceinline__ void run(f32x4 (&)[4 * IT], const bf16x8 (&)[4], const bf16x8 (&)[IT], bf16x8 (&)[4],
                                                bf16x8 (&)[IT], unsigned, unsigned, const Hook&) {}
@@ -403,6 +411,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         constexpr int G = (IT >= 4) ? 2 : 1;  // MFMAs per group: 4*IT / G groups must offer 4+IT read slots (G = 1 for IT = 4: measured slower)
         constexpr int NQ = 4 * IT / G;
         static_assert(NI <= NQ, "one DMA request per group");
+        constexpr int RPG = 1;  // (2 for the 4-wave tile -- all reads in the first half of a phase -- measured: no change)
         const __bf16* xs_n = nullptr;
         const __bf16* ws_n = nullptr;
         unsigned xl_n = 0, wl_n = 0;  // LDS byte offsets of this wave's part of the slot being refilled
@@ -485,16 +494,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         for (int i = 0; i < n; ++i) {
             const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
             wait_frags<0>(a0, b0);
-            IlvPhase<IT, G, 0, NQ>::run(acc, a0, b0, a1, b1, lds0 + cur * STAGE_BYTES + (aoff ^ 64),
-                                        lds0 + cur * STAGE_BYTES + (boff ^ 64), hook_a);
+            IlvPhase<IT, G, 0, NQ, RPG>::run(acc, a0, b0, a1, b1, lds0 + cur * STAGE_BYTES + (aoff ^ 64),
+                                             lds0 + cur * STAGE_BYTES + (boff ^ 64), hook_a);
             wait_frags<0>(a1, b1);  // my reads of slot cur are complete
             wait_vmcnt<NI*(STAGES - 2)>();  // tile i+1 has landed; the younger ones stay in flight
 #if !defined(SL_PROBE_NO_BARRIER)  // timing probe only (wrong results)
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
-            IlvPhase<IT, G, 0, NQ>::run(acc, a1, b1, a0, b0, lds0 + nxt * STAGE_BYTES + aoff,
-                                        lds0 + nxt * STAGE_BYTES + boff, hook_b);
+            IlvPhase<IT, G, 0, NQ, RPG>::run(acc, a1, b1, a0, b0, lds0 + nxt * STAGE_BYTES + aoff,
+                                             lds0 + nxt * STAGE_BYTES + boff, hook_b);
             cur = nxt;
         }
         wait_vmcnt<0>();        // the surplus requests still target this work-group's LDS

@@ -51,6 +51,56 @@ __global__ __launch_bounds__(256) void probe(const char* __restrict__ base, unsi
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[blockIdx.x * 256 + tid] = acc.x;
 }
 
+// mode 2: what one step of the 4-wave 128x128 NT kernel asks of the LDS, without the MFMAs: per wave 8 LDS-DMA requests
+// (32 KB per work-group) and/or 16 ds_read_b128 of the previous tile (64 KB per work-group), 2-slot ring, one barrier.
+template <bool DMA, bool READS>
+__global__ __launch_bounds__(256) void lds_mix(const char* __restrict__ base, unsigned* __restrict__ sink, int steps) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const char* src = base + (long)(blockIdx.x % 64) * 262144 + (tid >> 3) * 512 + (tid & 7) * 16;
+  const unsigned rd = (unsigned)(size_t)dyn + wave * 8192 + lane * 16;
+  uint4 f[16];
+  for (int i = 0; i < 16; ++i) f[i] = make_uint4(0, 0, 0, 0);
+  for (int s = 0; s < steps; ++s) {
+    char* slot = dyn + (s & 1) * 32768;
+    if (DMA) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(s & 3) * 128 + p * 16384),
+                                         (__attribute__((address_space(3))) void*)(slot + p * 4096 + wave * 1024), 16, 0, 0);
+    }
+    if (READS) {
+      const unsigned a = rd + ((s + 1) & 1) * 32768;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i]) : "v"(a), "n"(0) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  unsigned x = 0;
+  for (int i = 0; i < 16; ++i) x ^= f[i].x ^ f[i].w;
+  if (x == 0x12345u) sink[blockIdx.x * 256 + tid] = x;
+}
+
+template <bool DMA, bool READS>
+static void run_mix(const char* name, const char* buf, unsigned* sink, hipEvent_t a, hipEvent_t b) {
+  const int steps = 2000;
+  (void)hipFuncSetAttribute((const void*)lds_mix<DMA, READS>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  float best = 1e9f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(a));
+    lds_mix<DMA, READS><<<256, 256, 65536>>>(buf, sink, steps);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (ms < best) best = ms;
+  }
+  printf("lds-mix  %-52s %8.1f us  %.3f us/step\n", name, best * 1e3, best * 1e3 / steps);
+}
+
 int main() {
   const int wgs = 256, steps = 28 * 20;
   const size_t bytes = 512ull << 20;
@@ -92,5 +142,8 @@ int main() {
              best * 1e3, total / best / 1e9, total / (best * 1e-3) / 256 / 2.1e9, best * 1e3 / steps);
     }
   }
+  run_mix<true, false>("32 KB LDS-DMA per step", buf, sink, a, b);
+  run_mix<false, true>("64 KB ds_read_b128 per step", buf, sink, a, b);
+  run_mix<true, true>("both (one step of the 128x128 tile, no MFMAs)", buf, sink, a, b);
   return 0;
 }
