@@ -213,6 +213,7 @@ struct IlvPhase {
             const int m = G * Q + j;
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[m / IT], cb[m % IT], acc[m], 0, 0, 0);
         }
+        // (a fence here, forcing the group's MFMAs to issue before its read / request, measured slower: 2.291 vs 2.283 ms)
         read_one<RPG * Q>(na, nb, a_addr, b_addr);
         if constexpr (RPG == 2) read_one<RPG * Q + 1>(na, nb, a_addr, b_addr);
         hook(std::integral_constant<int, Q>{});
