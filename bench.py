@@ -211,6 +211,24 @@ def main():
         return {tag: float(np.sum(v)) / n_steps for tag, v in per_tag.items()}  # ms per step and tag
 
     live_ms = timeline_pass()  # same conditions as the timed region (bias gradients overlapped on the side stream)
+
+    def kernel_pass(tags):
+        """ms per launch of the MAIN kernel behind each tag: events recorded by the library immediately around that
+        kernel on its stream (sl_profile_next_kernel), nothing else instrumented"""
+        eng.kernel_timeline = (set(tags), [])
+        n_steps = args.profile_steps if args.config != 5 else len(resident)
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        per_tag = {}
+        for tag, start, stop in eng.kernel_timeline[1]:
+            per_tag.setdefault(tag, []).append(start.elapsed_time(stop))
+        eng.kernel_timeline = None
+        return {tag: float(np.mean(v)) for tag, v in per_tag.items()}
+
+    roof_tags = [t for t in live_ms if (t.startswith("wgrad:") and t not in ("wgrad:output_conv", "wgrad:striding_conv"))
+                 or t == "fwd:big_conv_1"]
+    kernel_ms = kernel_pass(roof_tags) if args.config in (2, 3) else {}
     names = [s.name for s in specs]
     groups = {}
     for prefix in ("fwd", "dgrad", "wgrad"):
@@ -269,7 +287,7 @@ def main():
         "kernels": groups,
     }
     if args.config == 3:
-        # Dominant kernel (largest share of main-stream GPU time, profiles/r01j_kernel_stats.csv): wgrad_tn_ilv_kernel,
+        # Dominant kernel (largest share of main-stream GPU time, profiles/r01k_kernel_stats.csv): wgrad_tn_ilv_kernel,
         # the 8-wave interleaved 256x256-tile weight-gradient kernel.  THREE launches per step use it (the library's
         # measured table picks it for big_conv_1, big_conv_2 and the grouped launch that covers the seven inner_conv_i);
         # algorithmic FLOPs per launch = (sum of those nine layers' wgrad FLOPs) / 3.
@@ -277,10 +295,10 @@ def main():
         dom_tags = [t for t in live_ms if t.startswith("wgrad:") and
                     t not in ("wgrad:output_conv", "wgrad:striding_conv")]
         dom_flops = sum(fl[i] for i, n in enumerate(names) if n in dom_layers) * BATCH_PER_GPU / len(dom_tags)
-        dom_ms = sum(live_ms[t] for t in dom_tags) / len(dom_tags)
+        dom_ms = sum(kernel_ms[t] for t in dom_tags) / len(dom_tags)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         traffic = None
-        pmc = ROOT / "profiles" / "r01j_pmc_traffic_wgrad_ilv.json"
+        pmc = ROOT / "profiles" / "r01k_pmc_traffic_wgrad_ilv.json"
         if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 correction)
             traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
         result["roofline"] = {
@@ -290,15 +308,15 @@ def main():
             "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
             "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits included), "
-                            "average of its launches per step, profiles/r01j_pmc_traffic_wgrad_ilv.json "
+                            "average of its launches per step, profiles/r01k_pmc_traffic_wgrad_ilv.json "
                             "(tools/pmc_traffic.sh)",
-            "duration_note": "HIP events around the sl_conv1d_wgrad call on its stream: the kernel plus, for the "
-                             "batch-split launches, the deterministic reduction kernel tail; compare "
-                             "with the kernel-only average in profiles/r01j_kernel_stats.csv",
+            "duration_note": "HIP events recorded by the library immediately around the kernel on its launch stream "
+                             "(sl_profile_next_kernel) in otherwise un-instrumented steps; compare with the average "
+                             "of wgrad_tn_ilv_kernel in profiles/r01k_kernel_stats.csv",
             "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms}
     if args.config in (2, 3):
         nt_flops = fl[names.index("big_conv_1")] * BATCH_PER_GPU
-        nt_ms = live_ms["fwd:big_conv_1"]
+        nt_ms = kernel_ms["fwd:big_conv_1"]
         nt = {"bound": "mfma", "kernel": "conv_nt_slab_bf16_kernel<IT=8,WM=2,WN=4,STAGES=2|pipelined,BIAS_RELU,bf16,interleaved> "
                                          "(forward of big_conv_1)",
               "achieved": nt_flops / (nt_ms * 1e-3) / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",

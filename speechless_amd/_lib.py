@@ -48,6 +48,7 @@ class ConvGeom(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/speechless_hip.h declares
 SIGNATURES = {
     "sl_version": (c_int, []),
+    "sl_profile_next_kernel": (c_int, [c_void_p, c_void_p]),
     "sl_last_error": (c_char_p, []),
     "sl_conv1d_nt_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int]),
     "sl_conv1d_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int, c_int,

@@ -14,6 +14,22 @@ void sl_set_error(const char* fmt, ...) {
 }
 
 extern "C" int sl_version(void) { return SL_VERSION; }
+
+// ---- measurement hook: see common.h / include/speechless_hip.h
+static hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+extern "C" int sl_profile_next_kernel(void* start_event, void* stop_event) {
+    g_prof_start = (hipEvent_t)start_event;
+    g_prof_stop = (hipEvent_t)stop_event;
+    return SL_OK;
+}
+void sl_prof_begin(hipStream_t s) {
+    if (g_prof_start) (void)hipEventRecord(g_prof_start, s);
+    g_prof_start = nullptr;
+}
+void sl_prof_end(hipStream_t s) {
+    if (g_prof_stop) (void)hipEventRecord(g_prof_stop, s);
+    g_prof_stop = nullptr;
+}
 extern "C" const char* sl_last_error(void) { return g_last_error; }
 
 static int check_geom(const sl_conv_geom* g, const char* who, int cin_mult, int cout_mult) {

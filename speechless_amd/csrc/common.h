@@ -28,6 +28,11 @@ void sl_set_error(const char* fmt, ...);
         }                                       \
     } while (0)
 
+// measurement hook (sl_profile_next_kernel, capi.hip): HIP events recorded on the launch stream immediately around the
+// MAIN kernel of the next sl_conv1d_nt / sl_conv1d_wgrad[_grouped] call (not around its split-K / reduction tail)
+void sl_prof_begin(hipStream_t s);
+void sl_prof_end(hipStream_t s);
+
 static inline int sl_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

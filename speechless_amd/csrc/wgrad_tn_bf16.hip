@@ -480,7 +480,9 @@ int launch_ilv(const TnArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)wgrad_tn_ilv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
+    sl_prof_begin(s);
     hipLaunchKernelGGL(wgrad_tn_ilv_kernel, dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(512), LDS_BYTES, s, a);
+    sl_prof_end(s);
     return sl_check_launch("sl_conv1d_wgrad(bf16, interleaved)");
 }
 
@@ -494,8 +496,10 @@ int launch(const TnArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
+    sl_prof_begin(s);
     hipLaunchKernelGGL((wgrad_tn_bf16_kernel<WM, WN, STAGES>), dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(64 * WM * WN),
                        LDS_BYTES, s, a);
+    sl_prof_end(s);
     return sl_check_launch("sl_conv1d_wgrad(bf16)");
 }
 

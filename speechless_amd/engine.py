@@ -309,6 +309,7 @@ class Engine:
         self._dropout_steps = 0
         self.cur = None
         self.timeline = None
+        self.kernel_timeline = None  # (set of tags, list of (tag, start, stop)): see _launch
         self._side_stream = None
         self.overlap_wgrad = False
         self.defer_bias_grads = os.environ.get("SL_DEFER_BGRAD", "1") != "0"  # A/B knob, see backward()
@@ -325,6 +326,17 @@ class Engine:
     def _launch(self, tag, name, *args):
         """One C-ABI call.  With self.timeline set (a list), brackets it with HIP events on the launch stream so
         that bench.py can read per-kernel durations live (tag = logical kernel instance, e.g. 'fwd:big_conv_1')."""
+        if self.kernel_timeline is not None and tag in self.kernel_timeline[0]:
+            # events immediately around the MAIN kernel of this call (sl_profile_next_kernel), none anywhere else: the
+            # step runs as in the timed region and the duration is what rocprofv3 reports for that kernel
+            start = torch.cuda.Event(enable_timing=True)
+            stop = torch.cuda.Event(enable_timing=True)
+            start.record()  # creates the HIP events; the library records them again around the kernel
+            stop.record()
+            self.lib.call("sl_profile_next_kernel", start.cuda_event, stop.cuda_event)
+            self.lib.call(name, *args)
+            self.kernel_timeline[1].append((tag, start, stop))
+            return
         if self.timeline is None:
             self.lib.call(name, *args)
             return

@@ -378,6 +378,25 @@ def test_ctc_and_decode_kernels_against_tensorflow_known_answers(hip_lib):
     assert out[0].tolist() == [0, 1, -1, -1, -1, -1]
 
 
+def test_profile_hook_brackets_the_main_kernel():
+    """sl_profile_next_kernel: the library records the two events around the main kernel of the NEXT conv call only."""
+    import torch
+    case = make_case(b=2, t=128, seed=5)
+    eng = make_engine(case, "bf16")
+    eng.forward(case["x"])
+    torch.cuda.synchronize()
+    eng.kernel_timeline = ({"fwd:big_conv_1"}, [])
+    eng.forward(case["x"])
+    torch.cuda.synchronize()
+    recorded = eng.kernel_timeline[1]
+    eng.kernel_timeline = None
+    assert [t for t, _, _ in recorded] == ["fwd:big_conv_1"]
+    ms = recorded[0][1].elapsed_time(recorded[0][2])
+    assert 0.0 < ms < 5.0
+    probs = eng.forward(case["x"]).cpu().numpy()  # the hook disarmed itself: a plain pass still works
+    assert np.isfinite(probs).all()
+
+
 # ------------------------------------------------------------------------------------------ decode, Adam
 def test_greedy_decode_known_answers(hip_lib):
     import torch
