@@ -32,6 +32,7 @@
 //     register-pipelined (+8: fragments read through inline asm with hand-counted lgkmcnt, barrier in the middle of a
 //     step); interleaved (cfg bit 30: IlvPhase, one LDS read / DMA request behind every one or two MFMAs).
 //   * conv_nt_slab_bf16_kernel (cfg bit 29) is the chunk-major variant that keeps the activation rows of all taps in LDS.
+//   * conv_nt_ks2_bf16_kernel (cfg it = 5) is the 128x128 tile with eight waves, the two waves of a SIMD splitting the k-halves.
 //   The library's measured table (auto_cfg) picks shape, flavour and kernel per launch; tools/tune_kernels.py sweeps them.
 #include "common.h"
 
@@ -1405,7 +1406,8 @@ Cfg auto_cfg(const sl_conv_geom* g) {
         }
     }
     // short layers (one 128x128 tile per CU at most): 4 waves of 64x64, 3-slot ring, register-pipelined and
-    // hand-interleaved: 17.7 us per 250-channel layer (8 waves of 32x64 un-interleaved 18.8, plain loop 20.7);
+    // hand-interleaved: 18.4 us per 250-channel layer back to back (8 waves of 32x64 un-interleaved 18.8, plain loop 20.7,
+    // eight waves in k-half pairs 18.4, interleaved slab 19.5-20.4: profiles/r01j_tune_kernels.json, r01j_nt_scaling.json);
     // striding_conv 48.5 us (54.0)
     return Cfg{2, 2, 11, 1, 4, 0, 0, 0, 1};
 }
