@@ -313,6 +313,9 @@ class Engine:
         self._side_stream = None
         self.overlap_wgrad = False
         self.defer_bias_grads = os.environ.get("SL_DEFER_BGRAD", "1") != "0"  # A/B knob, see backward()
+        # forward + CTC + backward of a resident step replayed from a hipGraph (one graph per batch geometry): the ~60
+        # launches and 4 cross-stream hand-overs of the step cost the host ~0.7 ms of Python / ctypes per step otherwise
+        self.use_graph = os.environ.get("SL_USE_GRAPH", "0") == "1"
         # train_step_resident: Adam of a layer runs under the rest of backward (see backward()).  Measured on MI355X
         # (tools/step_ab.py): 2.546 ms/step either way -- the HBM-bound update slows the MFMA kernels it overlaps by as
         # much as it costs alone -- so it is off by default, which also keeps per-kernel timings clean.
@@ -732,8 +735,47 @@ class Engine:
         self.set_labels(label_batch, label_lengths, prediction_lengths)
         return self.train_step_resident(reducer)
 
+    def _graph_eligible(self, reducer):
+        return (self.use_graph and reducer is None and self.dtype == "bf16" and not self.dropout_rate and
+                self.timeline is None and self.kernel_timeline is None and not self.early_adam and
+                not self.overlap_wgrad)
+
+    def _graph_step(self):
+        """forward + CTC + backward from a captured hipGraph.  The kernels read the step's inputs through fixed
+        pointers (x0 / labels / lengths of this geometry's buffers), so a replay computes on whatever was loaded into
+        them; Adam stays outside the graph (its step count is a kernel argument)."""
+        buf = self.cur
+        # everything a launch of the step reads through a pointer or takes as an argument and that can differ between
+        # two steps on this geometry: the label / length tensors are used in place (set_labels_resident) and the CTC
+        # workspace grows with the longest label row seen
+        key = (buf.labels.data_ptr(), buf.label_len.data_ptr(), buf.input_len.data_ptr(), int(buf.labels.shape[1]),
+               buf.ctc_ws.data_ptr())
+        graphs = buf.__dict__.setdefault("graphs", {})
+        g = graphs.get(key)
+        if g is None:
+            warm = buf.__dict__.setdefault("graph_warm", {})
+            if warm.get(key, 0) < 1 or self._packed_dirty:  # an eager step first: lazy allocations, clean operands
+                warm[key] = warm.get(key, 0) + 1
+                return None
+            if len(graphs) >= 8:  # label tensors that never repeat (no slot recycling): graphs cannot pay off
+                return None
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.forward(training=True)
+                self.ctc(grad_scale=1.0 / buf.batch)
+                self.backward()
+            graphs[key] = g
+        g.replay()
+        return buf.loss
+
     def train_step_resident(self, reducer=None):
         """Same, with input / labels / lengths already resident in HBM (bench.py's timed region)."""
+        if self._graph_eligible(reducer):
+            loss = self._graph_step()
+            if loss is not None:
+                self.adam_step()
+                return loss
         self.forward(training=True)
         world = reducer.world_size if reducer is not None else 1
         loss = self.ctc(grad_scale=1.0 / (self.cur.batch * world))

@@ -378,6 +378,30 @@ def test_ctc_and_decode_kernels_against_tensorflow_known_answers(hip_lib):
     assert out[0].tolist() == [0, 1, -1, -1, -1, -1]
 
 
+def test_graph_replay_trains_identically():
+    """Engine.use_graph (forward + CTC + backward replayed from a hipGraph, Adam outside): bit-identical weights and
+    losses to the eagerly launched steps, including after new inputs were loaded into the same buffers."""
+    import torch
+    case = make_case(b=3, t=130, seed=41)
+    case2 = make_case(b=3, t=130, seed=42)
+    results = []
+    for use_graph in (False, True):
+        eng = make_engine(case, "bf16")
+        eng.use_graph = use_graph
+        losses = []
+        for step in range(6):
+            c = case if step % 2 == 0 else case2
+            eng.load_input(c["x"])
+            eng.set_labels(case["labels"], case["label_lengths"], case["prediction_lengths"])  # same tensors' shapes
+            losses.append(eng.train_step_resident().cpu().numpy().copy())
+        torch.cuda.synchronize()
+        if use_graph:
+            assert len(eng.cur.__dict__.get("graphs", {})) >= 1, "the graph path was not taken"
+        results.append((np.stack(losses), eng.params.clone()))
+    assert np.array_equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1])
+
+
 def test_profile_hook_brackets_the_main_kernel():
     """sl_profile_next_kernel: the library records the two events around the main kernel of the NEXT conv call only."""
     import torch
