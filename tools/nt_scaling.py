@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cfgs", default="0")  # comma separated raw cfg words (0 = auto)
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "nt_scaling.json"))
+    ap.add_argument("--attribute", action="store_true", help="also time the launch behind kernels that rewrite only the "
+                    "activations / only the weights / 1 GiB of unrelated memory")
     args = ap.parse_args()
 
     import torch
@@ -72,18 +74,29 @@ def main():
             b.record()
             torch.cuda.synchronize()
             warm = a.elapsed_time(b) / args.reps
-            evs = []
-            for _ in range(args.reps):
-                fwd(0, 0)  # producer of the input (and evicts nothing else: the step's situation)
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                fwd(1, cfg)
-                e.record()
-                evs.append((s, e))
-            torch.cuda.synchronize()
-            cold = float(np.median([s.elapsed_time(e) for s, e in evs]))
-            g = buf.fwd_geom[1]
-            rows.append({"taps": k, "nsteps": g.taps * (g.cin // 64), "back_to_back_us": warm * 1e3, "after_producer_us": cold * 1e3})
+            def behind(producer):
+                evs = []
+                for _ in range(args.reps):
+                    producer()
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    fwd(1, cfg)
+                    e.record()
+                    evs.append((s, e))
+                torch.cuda.synchronize()
+                return float(np.median([s.elapsed_time(e) for s, e in evs])) * 1e3
+
+            cold = behind(lambda: fwd(0, 0))  # the producer of the input (the step's situation)
+            row = {"taps": k, "nsteps": buf.fwd_geom[1].taps * (buf.fwd_geom[1].cin // 64), "back_to_back_us": warm * 1e3,
+                   "after_producer_us": cold}
+            if args.attribute:  # which operand's cold first touch costs what
+                a_saved, w_saved = buf.y[0].clone(), eng.w_fwd[1].clone()
+                big = torch.empty((1 << 30,), dtype=torch.uint8, device=eng.device)
+                row["after_rewriting_activations_us"] = behind(lambda: buf.y[0].copy_(a_saved))
+                row["after_rewriting_weights_us"] = behind(lambda: eng.w_fwd[1].copy_(w_saved))
+                row["after_flushing_the_caches_us"] = behind(lambda: big.fill_(1))
+                del big
+            rows.append(row)
             print(cfg, rows[-1], flush=True)
             del eng, buf, ws
         n = np.array([r["nsteps"] for r in rows], dtype=np.float64)
