@@ -156,6 +156,19 @@ int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int d
 int sl_softmax_logq(const float* logits, float* probs, float* logq, int batch, int t_out, int k, int logit_stride,
                     int64_t logit_batch_stride, float eps, void* stream);
 
+/* ---- output layer fused with the softmax (bf16): the 1x1 convolution onto k <= 32 classes (net.py:326-330,
+ * Conv1D(grapheme_set_size, 1, activation="softmax")) and everything sl_softmax_logq computes, in one launch that
+ * streams the layer's input once and never writes the logits unless asked to.
+ *   x, geom (batch, t_out, taps = 1, cin, cout >= 32 rows of w, x_*): as for sl_conv1d_nt;  w: packed [cout][1][cin]
+ *   probs, logq: float[B][t_out][k];  logits: optional float, row t of utterance b at b*logit_batch_stride +
+ *   t*logit_stride (first k written), or NULL.   sl_output_softmax_supported() = 1 when the geometry fits the kernel
+ *   (otherwise use sl_conv1d_nt + sl_softmax_logq).
+ */
+int sl_output_softmax_supported(const sl_conv_geom* geom, int k, int dtype);
+int sl_output_softmax(const void* x, const void* w, const float* bias, float* probs, float* logq, float* logits,
+                      const sl_conv_geom* geom, int k, int logit_stride, int64_t logit_batch_stride, float eps, int dtype,
+                      void* stream);
+
 /* ---- CTC loss and gradient (net.py:402-406: keras.backend.ctc_batch_cost -> tf.nn.ctc_loss) --------------------
  * labels: int32[B][l_max] (padding ignored, grapheme_enconding.py:28 uses -1); blank = k-1 (grapheme_enconding.py:125).
  * loss:   float[B]  (-log p(label | x); +inf when no valid alignment exists)

@@ -49,6 +49,9 @@ class ConvGeom(ctypes.Structure):
 SIGNATURES = {
     "sl_version": (c_int, []),
     "sl_profile_next_kernel": (c_int, [c_void_p, c_void_p]),
+    "sl_output_softmax_supported": (c_int, [POINTER(ConvGeom), c_int, c_int]),
+    "sl_output_softmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int,
+                                  c_int, c_int64, c_float, c_int, c_void_p]),
     "sl_last_error": (c_char_p, []),
     "sl_conv1d_nt_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int]),
     "sl_conv1d_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int, c_int,

@@ -70,6 +70,27 @@ extern "C" int sl_conv1d_nt(const void* x, const void* w, const float* bias, con
     return SL_ERR_INVALID_ARGUMENT;
 }
 
+bool output_softmax_supported(const sl_conv_geom* g, int k);
+int output_softmax_bf16(const void* x, const void* w, const float* bias, float* probs, float* logq, float* logits,
+                        const sl_conv_geom* g, int k, int logit_stride, long logit_batch_stride, float eps, hipStream_t s);
+
+extern "C" int sl_output_softmax_supported(const sl_conv_geom* geom, int k, int dtype) {
+    if (!geom || dtype != SL_BF16 || geom->batch <= 0 || geom->t_out <= 0 || geom->cin <= 0) return 0;
+    return output_softmax_supported(geom, k) ? 1 : 0;
+}
+
+extern "C" int sl_output_softmax(const void* x, const void* w, const float* bias, float* probs, float* logq, float* logits,
+                                 const sl_conv_geom* geom, int k, int logit_stride, int64_t logit_batch_stride, float eps,
+                                 int dtype, void* stream) {
+    SL_CHECK_ARG(geom && x && w && bias && probs && logq, "sl_output_softmax: null pointer");
+    SL_CHECK_ARG(sl_output_softmax_supported(geom, k, dtype),
+                 "sl_output_softmax: needs bf16, a 1x1 layer, k <= 32 classes, cin a multiple of 64 with 32 weight rows in LDS");
+    SL_CHECK_ARG(geom->x_row0 >= 0 && geom->x_row_stride >= geom->cin && geom->x_row_stride % 8 == 0,
+                 "sl_output_softmax: bad input geometry");
+    return output_softmax_bf16(x, w, bias, probs, logq, logits, geom, k, logit_stride, (long)logit_batch_stride, eps,
+                               (hipStream_t)stream);
+}
+
 extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg) {
     if (!geom || geom->taps <= 0 || geom->cin <= 0 || geom->cout <= 0 || geom->batch <= 0) return 0;
     if (dtype == SL_BF16) {

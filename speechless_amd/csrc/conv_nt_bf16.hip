@@ -1181,6 +1181,154 @@ __global__ __launch_bounds__(512, 2) void conv_nt_ks2_bf16_kernel(NtArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Output layer: 1x1 convolution onto k <= 32 classes fused with the softmax and the log(p + eps) re-normalisation that
+// sl_softmax_logq computes.  As an NT launch this layer is a 128x128 tile of which three quarters is channel padding
+// (34 us, and another launch for the softmax); what it really needs is to stream its input once.  Here a work-group owns
+// 64 time rows and ALL classes: the whole weight matrix (32 x cin bf16, 128 KiB at cin = 2048, rows padded by 16 B
+// against bank conflicts) sits in LDS, the activation rows come through a 3-slot LDS-DMA ring (8 KiB per 64-channel
+// step), each of the four waves multiplies its 16 rows by the 32 classes (2 MFMA tiles x 2 k-halves per step) and ends
+// with the 32 logits of a time row in four lanes -> softmax by two butterfly steps, no logits round trip through HBM.
+// Summation order over the input channels is the NT kernels' (64-channel steps, two 32-deep MFMAs each).
+template <int SLOTS>
+__global__ __launch_bounds__(256, 1) void output_softmax_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ probs,
+                                                                float* __restrict__ logq, float* __restrict__ logits,
+                                                                int batch, int t_out, int t_tiles, int cin, int w_rs,
+                                                                int x_row0, int x_rs, long x_bs, int k, int logit_stride,
+                                                                long logit_batch_stride, float eps) {
+    constexpr int BM = 64, SLOT_BYTES = BM * 128, XPW = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = cin * 2 + 16;  // LDS bytes per weight row
+    const int wrows = k < 32 ? k : 32;  // weight rows kept in LDS (the MFMA rows behind them read ring bytes: classes >= k are masked)
+    const int ring_off = (wrows * wrow + 127) & ~127;  // the k-half XOR of the fragment addresses needs a 128-byte base
+    char* ring = smem + ring_off;
+    const int b = blockIdx.x / t_tiles;
+    const int t0 = (blockIdx.x - b * t_tiles) * BM;
+    const int nsteps = cin / BK;
+
+    const __bf16* xbase = x + (long)b * x_bs + (long)(x_row0 + t0) * x_rs;
+    int xoff[XPW];
+#pragma unroll
+    for (int q = 0; q < XPW; ++q) {
+        const int row = (wave * XPW + q) * 8 + (lane >> 3);
+        xoff[q] = row * x_rs + (((lane & 7) ^ (lane >> 3)) << 3);
+    }
+    auto request = [&](int step, int slot) {
+#pragma unroll
+        for (int q = 0; q < XPW; ++q)
+            glds16(xbase + step * BK + xoff[q], ring + slot * SLOT_BYTES + (wave * XPW + q) * 1024);
+    };
+    const int g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned boff = lds0 + ring_off + (wave * 16 + (lane & 15)) * 128 + ((g ^ (lane & 7)) << 4);
+    const unsigned aoff = lds0 + (lane & 15) * wrow + g * 16;  // + tile * 16 * wrow + step * 128 + k-half * 64
+
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < SLOTS - 1; ++i)
+        if (i < nsteps) request(i, i);
+    // ---- the weight matrix: 32 rows of cin bf16.  Rows of whole KiB go by LDS-DMA (one KiB per wave instruction, all
+    // in flight at once); other widths through registers, 16 bytes per thread and trip.
+    if ((cin & 511) == 0) {
+        const int chunks = cin / 512;  // KiB per row
+        for (int i = wave; i < wrows * chunks; i += 4) {
+            const int r = i / chunks, c = i - r * chunks;
+            glds16(w + (long)r * w_rs + c * 512 + lane * 8, smem + r * wrow + c * 1024);
+        }
+    } else {
+        const int per_row = cin / 8;  // 16-byte pieces per row
+        for (int i = tid; i < wrows * per_row; i += 256) {
+            const int r = i / per_row, c = i - r * per_row;
+            *(u32x4*)(smem + r * wrow + c * 16) = *(const u32x4*)(w + (long)r * w_rs + c * 8);
+        }
+    }
+    wait_vmcnt<0>();  // weights (and the first activation tiles): the counted waits below start from zero in flight
+    __syncthreads();
+    int slot = 0;
+    for (int c = 0; c < nsteps; ++c) {
+        if (c + SLOTS - 2 < nsteps)
+            wait_vmcnt<XPW*(SLOTS - 2)>();  // tile c has landed, the SLOTS-2 younger ones may still be in flight
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // ... everybody's part of it, and everybody is done reading tile c-1
+        asm volatile("" ::: "memory");
+        if (c + SLOTS - 1 < nsteps) request(c + SLOTS - 1, slot == 0 ? SLOTS - 1 : slot - 1);
+        bf16x8 af[4], bfr[2];
+        const unsigned a_addr = aoff + c * 128;
+        ds_read128<0>(af[0], a_addr);
+        ds_read128<64>(af[1], a_addr);
+        ds_read128<0>(af[2], a_addr + 16 * wrow);
+        ds_read128<64>(af[3], a_addr + 16 * wrow);
+        const unsigned b_addr = boff + slot * SLOT_BYTES;
+        ds_read128<0>(bfr[0], b_addr);
+        ds_read128<0>(bfr[1], b_addr ^ 64);
+        wait_frags<0>(af, bfr);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bfr[0], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3], bfr[1], acc[1], 0, 0, 0);
+        slot = (slot + 1 == SLOTS) ? 0 : slot + 1;
+    }
+
+    // ---- lane (g, i): time row t0 + wave*16 + i, classes tile*16 + 4g + r.  Softmax over the k valid classes of the row:
+    // 8 values here, the rest in the three lanes that differ in g (lane ^ 16, lane ^ 32).
+    const int t = t0 + wave * 16 + (lane & 15);
+    float z[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cls = j * 16 + 4 * g + r;
+            z[j * 4 + r] = cls < k ? acc[j][r] + bias[cls] : -INFINITY;
+            m = fmaxf(m, z[j * 4 + r]);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float e[8], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = z[i] == -INFINITY ? 0.f : expf(z[i] - m);
+        sum += e[i];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    // q = (p + eps) / sum_j (p_j + eps), computed the way TF does: log-softmax of u = log(p + eps)   (sl_softmax_logq)
+    float u[8], um = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = e[i] / sum;
+        u[i] = z[i] == -INFINITY ? -INFINITY : logf(e[i] + eps);
+        um = fmaxf(um, u[i]);
+    }
+    um = fmaxf(um, __shfl_xor(um, 16));
+    um = fmaxf(um, __shfl_xor(um, 32));
+    float usum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) usum += u[i] == -INFINITY ? 0.f : expf(u[i] - um);
+    usum += __shfl_xor(usum, 16);
+    usum += __shfl_xor(usum, 32);
+    const float lz = um + logf(usum);
+    if (t < t_out) {
+        const long f = (long)b * t_out + t;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cls = j * 16 + 4 * g + r;
+                if (cls < k) {
+                    probs[f * k + cls] = e[j * 4 + r];
+                    logq[f * k + cls] = u[j * 4 + r] - lz;
+                    if (logits) logits[(long)b * logit_batch_stride + (long)t * logit_stride + cls] = z[j * 4 + r];
+                }
+            }
+    }
+}
+
 // split-K tail: out = epi(sum_split partial), 8 channels per thread, fixed summation order
 template <int MODE, bool OUT_F32>
 __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int rows_per_batch) {
@@ -1597,4 +1745,35 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
 #undef SL_NT_CASE
     sl_set_error("sl_conv1d_nt(bf16): configuration not instantiated");
     return SL_ERR_UNSUPPORTED;
+}
+
+// ---- fused output layer (declared in capi.hip's dispatch: sl_output_softmax)
+bool output_softmax_supported(const sl_conv_geom* g, int k) {
+    if (g->taps != 1 || k < 1 || k > 32 || g->cout < 32 || g->cin % BK) return false;
+    return ((k * (g->cin * 2 + 16) + 127) & ~127) + 3 * 64 * 128 <= 160 * 1024;
+}
+
+int output_softmax_bf16(const void* x, const void* w, const float* bias, float* probs, float* logq, float* logits,
+                        const sl_conv_geom* g, int k, int logit_stride, long logit_batch_stride, float eps, hipStream_t s) {
+    const int wbytes = (k * (g->cin * 2 + 16) + 127) & ~127;
+    const int slots = wbytes + 5 * 64 * 128 <= 160 * 1024 ? 5 : 3;  // ring depth the rest of the LDS allows
+    const int lds = wbytes + slots * 64 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)output_softmax_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)output_softmax_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int t_tiles = (g->t_out + 63) / 64;
+    if (slots == 5)
+        hipLaunchKernelGGL(output_softmax_kernel<5>, dim3(g->batch * t_tiles), dim3(256), lds, s, (const __bf16*)x,
+                           (const __bf16*)w, bias, probs, logq, logits, g->batch, g->t_out, t_tiles, g->cin,
+                           g->taps * g->cin, g->x_row0, g->x_row_stride, (long)g->x_batch_stride, k, logit_stride,
+                           logit_batch_stride, eps);
+    else
+        hipLaunchKernelGGL(output_softmax_kernel<3>, dim3(g->batch * t_tiles), dim3(256), lds, s, (const __bf16*)x,
+                           (const __bf16*)w, bias, probs, logq, logits, g->batch, g->t_out, t_tiles, g->cin,
+                           g->taps * g->cin, g->x_row0, g->x_row_stride, (long)g->x_batch_stride, k, logit_stride,
+                           logit_batch_stride, eps);
+    return sl_check_launch("sl_output_softmax");
 }

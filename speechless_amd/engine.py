@@ -316,6 +316,7 @@ class Engine:
         # forward + CTC + backward of a resident step replayed from a hipGraph (one graph per batch geometry): the ~60
         # launches and 4 cross-stream hand-overs of the step cost the host ~0.7 ms of Python / ctypes per step otherwise
         self.use_graph = os.environ.get("SL_USE_GRAPH", "0") == "1"
+        self.fuse_output_softmax = os.environ.get("SL_FUSE_OUTPUT", "1") != "0"  # A/B knob: sl_output_softmax
         # train_step_resident: Adam of a layer runs under the rest of backward (see backward()).  Measured on MI355X
         # (tools/step_ab.py): 2.546 ms/step either way -- the HBM-bound update slows the MFMA kernels it overlaps by as
         # much as it costs alone -- so it is off by default, which also keeps per-kernel timings clean.
@@ -462,10 +463,18 @@ class Engine:
             self._launch("dropout:input", "sl_dropout", buf.x0.data_ptr(), buf.x0_dropped.data_ptr(), buf.x0.numel(),
                          self.dtype_code, rate, seed0, st)
             x = buf.x0_dropped
+        fuse_out = self.fuse_output_softmax and self.dtype == "bf16" and bool(self.lib.raw("sl_output_softmax_supported")(
+            ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size, self.dtype_code))
         for p in self.plans:
             last = p.index == n - 1
             y = buf.logits if last else buf.y[p.index]
             _, bias = self.layer_param_views(self.params, p)
+            if last and fuse_out:  # output layer + softmax + log(p + eps) re-normalisation in one launch
+                self._launch("fwd:" + p.spec.name, "sl_output_softmax", x.data_ptr(), self.w_fwd[p.index].data_ptr(),
+                             bias.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), None,
+                             ctypes.byref(buf.fwd_geom[p.index]), self.grapheme_set_size, p.cout_pad,
+                             buf.tt_pad * p.cout_pad, self.ctc_epsilon, self.dtype_code, st)
+                return buf.probs
             self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(), None,
                           y.data_ptr(), ctypes.byref(buf.fwd_geom[p.index]),
                           _lib.EPI_BIAS if last else

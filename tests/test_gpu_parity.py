@@ -402,6 +402,28 @@ def test_graph_replay_trains_identically():
     assert torch.equal(results[0][1], results[1][1])
 
 
+@pytest.mark.parametrize("k,t", [(29, 1000), (33, 130), (5, 77)])
+def test_fused_output_softmax_matches_the_two_launch_path(k, t):
+    """sl_output_softmax (1x1 output layer + softmax + log(p + eps) re-normalisation in one launch) against
+    sl_conv1d_nt + sl_softmax_logq on the same activations; k = 33 exceeds the fused kernel's 32 classes and must fall
+    back without a difference."""
+    import torch
+    case = make_case(b=3, t=t, k=k, seed=50 + k)
+    outs = []
+    for fuse in (False, True):
+        eng = make_engine(case, "bf16")
+        eng.fuse_output_softmax = fuse
+        probs = eng.forward(case["x"]).cpu().numpy().copy()
+        logq = eng.cur.logq.cpu().numpy().copy()
+        torch.cuda.synchronize()
+        outs.append((probs, logq))
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(outs[1][0].sum(-1), 1.0, atol=1e-5)
+    if k > 32:
+        assert np.array_equal(outs[0][0], outs[1][0])
+
+
 def test_profile_hook_brackets_the_main_kernel():
     """sl_profile_next_kernel: the library records the two events around the main kernel of the NEXT conv call only."""
     import torch
