@@ -1557,7 +1557,11 @@ Cfg auto_cfg(const sl_conv_geom* g) {
     // hand-interleaved: 18.4 us per 250-channel layer back to back (8 waves of 32x64 un-interleaved 18.8, plain loop 20.7,
     // eight waves in k-half pairs 18.4, interleaved slab 19.5-20.4: profiles/r01j_tune_kernels.json, r01j_nt_scaling.json);
     // striding_conv 48.5 us (54.0)
-    return Cfg{2, 2, 11, 1, 4, 0, 0, 0, 1};
+    Cfg c{2, 2, 11, 1, 4, 0, 0, 0, 1};
+    // long contractions on this tile (striding_conv: 96 steps): the eight-wave k-half-pair variant's shorter step
+    // outweighs its dearer epilogue (49.5 vs 51.7 us right behind the producer of the input)
+    if (nsteps >= 64 && g->cout % 128 == 0) c.ks2 = 1;
+    return c;
 }
 
 bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
