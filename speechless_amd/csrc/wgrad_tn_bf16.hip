@@ -542,7 +542,12 @@ WCfg auto_wcfg(const sl_conv_geom* g, int groups) {
         if (tiles256 >= 64 || (groups > 1 && tiles256 >= 48)) return WCfg{4, 4, 10, choose_splits(g, 256, 256, 256, groups)};
     }
     // short layers: 128x128 tiles, batch split so that ~2 work-groups land on every CU (deeper rings measured no gain)
-    return WCfg{2, 2, 2, choose_splits(g, 128, 128, 512, groups)};
+    const int splits = choose_splits(g, 128, 128, 512, groups);
+    // one column of tiles streaming a wide input (output_conv: 16 tiles, HBM-bound): a 3-slot ring and half the splits
+    // (fewer partial sums to reduce) measured 26.0 vs 30.2 us
+    if (groups == 1 && g->taps == 1 && g->cout == 128 && splits >= 2 && splits % 2 == 0 && g->cin >= 1024)
+        return WCfg{2, 2, 3, splits / 2};
+    return WCfg{2, 2, 2, splits};
 }
 
 bool valid_wcfg(const WCfg& c, const sl_conv_geom* g) {
