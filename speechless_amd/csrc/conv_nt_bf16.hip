@@ -493,16 +493,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         const unsigned lds0 = (unsigned)(size_t)smem;
         DsReadRun<0, NA, 512>::go(a0, lds0 + aoff);
         DsReadRun<0, NB, 2048>::go(b0, lds0 + boff);
+#if defined(SL_PROBE_TIMES)  // s_memtime stamps of one steady-state step of wave 0 of work-group 0 -> a.partial (see below)
+        unsigned long long tp1 = 0, tp3 = 0, tp4 = 0, tp5 = 0, t1 = 0, t3 = 0, t4 = 0, t5 = 0;
+#define SL_STAMP(v) asm volatile("s_memtime %0" : "=s"(v)::"memory")
+#else
+#define SL_STAMP(v)
+#endif
         for (int i = 0; i < n; ++i) {
             const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
             wait_frags<0>(a0, b0);
+#if defined(SL_PROBE_TIMES)
+            tp1 = t1; tp3 = t3; tp4 = t4; tp5 = t5;
+#endif
+            SL_STAMP(t1);
             IlvPhase<IT, G, 0, NQ, RPG>::run(acc, a0, b0, a1, b1, lds0 + cur * STAGE_BYTES + (aoff ^ 64),
                                              lds0 + cur * STAGE_BYTES + (boff ^ 64), hook_a);
             wait_frags<0>(a1, b1);  // my reads of slot cur are complete
+            SL_STAMP(t3);
             wait_vmcnt<NI*(STAGES - 2)>();  // tile i+1 has landed; the younger ones stay in flight
+            SL_STAMP(t4);
 #if !defined(SL_PROBE_NO_BARRIER)  // timing probe only (wrong results)
             __builtin_amdgcn_s_barrier();
 #endif
+            SL_STAMP(t5);
             asm volatile("" ::: "memory");
             IlvPhase<IT, G, 0, NQ, RPG>::run(acc, a1, b1, a0, b0, lds0 + nxt * STAGE_BYTES + aoff,
                                              lds0 + nxt * STAGE_BYTES + boff, hook_b);
@@ -510,6 +523,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         }
         wait_vmcnt<0>();        // the surplus requests still target this work-group's LDS
         wait_frags<0>(a0, b0);  // ... and the surplus fragment reads these registers
+#if defined(SL_PROBE_TIMES)
+        if (id == 0 && tid == 0 && a.partial != nullptr) {
+            unsigned long long* o = (unsigned long long*)a.partial;
+            o[0] = tp1; o[1] = tp3; o[2] = tp4; o[3] = tp5; o[4] = t1; o[5] = (unsigned long long)n;
+        }
+#endif
     } else if constexpr (PIPE && !M32) {
         // Register-pipelined ring.  All STAGES slots are filled up front; tile i's slot is refilled with tile
         // i+STAGES at the barrier in the MIDDLE of iteration i, by which time every wave has its whole tile i in
