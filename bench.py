@@ -78,17 +78,29 @@ def long_form_batches(rank):
     return out, waste
 
 
-def cpu_baseline(specs_oracle, weights, sample_utts=4, steps=2):
-    """The torch-CPU fp32 port of the same step (oracle/w2l_torch_cpu.py) timed on this node's host cores."""
+def cpu_model_string():
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(specs_oracle, weights, sample_utts=BATCH_PER_GPU, steps=3):
+    """The torch-CPU fp32 port of the same step (oracle/w2l_torch_cpu.py) timed on this node's host cores, on the SAME
+    batch as the GPU step (configuration 3, 32 utterances): 1 warm-up + `steps` timed steps."""
     import torch
     from oracle import w2l_torch_cpu as tc
     x, labels, lab_len, pred_len = synthetic_batch(0, sample_utts)
     times = tc.timed_training_steps(specs_oracle, weights, x, labels, pred_len, lab_len, steps=steps, warmup=1)
-    best = min(times)
-    return {"value": sample_utts / best, "unit": "utterances/sec", "cores": int(torch.get_num_threads()),
-            "kind": "port", "host_cpus": os.cpu_count(),
-            "sample": "{} utterances x {} frames, 1 warm-up + {} timed fwd+CTC+bwd+Adam steps (torch-CPU fp32, "
-                      "best step {:.2f} s)".format(sample_utts, FRAMES, steps, best)}
+    mean, best = float(np.mean(times)), float(min(times))
+    return {"value": sample_utts / mean, "unit": "utterances/sec", "cores": int(torch.get_num_threads()),
+            "kind": "port", "host_cpus": os.cpu_count(), "cpu_model": cpu_model_string(),
+            "value_best_step": sample_utts / best, "step_seconds": [round(t, 3) for t in times],
+            "sample": "{} utterances x {} frames (the GPU step's batch), 1 warm-up + {} timed fwd+CTC+bwd+Adam steps, "
+                      "torch-CPU fp32, mean step {:.2f} s, best {:.2f} s".format(sample_utts, FRAMES, steps, mean, best)}
 
 
 def main():
@@ -212,6 +224,26 @@ def main():
 
     live_ms = timeline_pass()  # same conditions as the timed region (bias gradients overlapped on the side stream)
 
+    # ---- host-buffer note: what handing over a HOST batch costs on top of the resident step (never part of `value`)
+    h2d = None
+    if args.config == 3 and rank == 0:
+        host = x  # (32, 1000, 128) float32, pageable -- what net.py:578-587 packs
+        for _ in range(2):
+            torch.from_numpy(host).to(device)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dev = torch.from_numpy(host).to(device)
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t1) / 10 * 1e3
+        h2d = {"h2d_ms_per_step": h2d_ms, "bytes": int(host.nbytes),
+               "GBps": host.nbytes / (h2d_ms * 1e-3) / 1e9,
+               "note": "pageable float32 host batch -> HBM (torch copy, synchronous); the fp32 -> bf16 halo'd repack on "
+                       "the GPU (sl_pack_input) is {:.3f} ms and is not in the resident step either; serial upper "
+                       "bound of the PCIe-inclusive rate below, speechless_amd/pipeline.py overlaps the copy with the "
+                       "previous step".format(live_ms.get("pack_input", 0.0))}
+        del dev
+
     def kernel_pass(tags):
         """ms per launch of the MAIN kernel behind each tag: events recorded by the library immediately around that
         kernel on its stream (sl_profile_next_kernel), nothing else instrumented"""
@@ -286,6 +318,10 @@ def main():
         "conv_stack_mfma_frac": (flops_per_step / 1e12) / (conv_ms * 1e-3) / BF16_DENSE_PEAK_TFLOPS,
         "kernels": groups,
     }
+    if h2d is not None:
+        step_ms = elapsed / args.steps * 1e3
+        h2d["utterances_per_sec_including_h2d_serial"] = batch_per_gpu / ((step_ms + h2d["h2d_ms_per_step"]) * 1e-3)
+        result["host_buffers"] = h2d
     if args.config == 3:
         # Dominant kernel (largest share of main-stream GPU time, profiles/r01k_kernel_stats.csv): wgrad_tn_ilv_kernel,
         # the 8-wave interleaved 256x256-tile weight-gradient kernel.  THREE launches per step use it (the library's
@@ -297,19 +333,24 @@ def main():
         dom_flops = sum(fl[i] for i, n in enumerate(names) if n in dom_layers) * BATCH_PER_GPU / len(dom_tags)
         dom_ms = sum(kernel_ms[t] for t in dom_tags) / len(dom_tags)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = ROOT / "profiles" / "r01k_pmc_traffic_wgrad_ilv.json"
-        if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 correction)
-            traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
+        traffic, traffic_source = None, None
+        for name in ("r02_pmc_traffic_wgrad_ilv.json", "r01k_pmc_traffic_wgrad_ilv.json"):
+            pmc = ROOT / "profiles" / name
+            if pmc.exists():  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh (gfx950 x2 correction)
+                traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_avg"]
+                traffic_source = "profiles/" + name
+                break
         result["roofline"] = {
             "bound": "mfma", "kernel": "wgrad_tn_ilv_kernel (weight gradient of big_conv_1, big_conv_2 and the grouped "
                                        "inner_conv_1..7 launch; average over its {} launches per "
                                        "step)".format(len(dom_tags)),
             "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE (Infinity-Cache hits included), "
-                            "average of its launches per step, profiles/r01k_pmc_traffic_wgrad_ilv.json "
-                            "(tools/pmc_traffic.sh)",
+            "traffic_source": traffic_source,
+            "traffic_note": "NOT measured in this run (PMC counters need rocprofv3 around the process): bytes per launch "
+                            "from the committed file named in traffic_source -- rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE "
+                            "in separate passes (tools/pmc_traffic.sh), Infinity-Cache hits included, average of the "
+                            "kernel's launches per step",
             "duration_note": "HIP events recorded by the library immediately around the kernel on its launch stream "
                              "(sl_profile_next_kernel) in otherwise un-instrumented steps; compare with the average "
                              "of wgrad_tn_ilv_kernel in profiles/r01k_kernel_stats.csv",
@@ -330,23 +371,40 @@ def main():
         t_pad = float(np.mean([len(tl) * (-(-int(tl.max()) // 2)) for (_, _, _, _, tl) in host_batches]))
         n_param = sum(s.kernel_size * s.cin * s.cout + s.cout for s in specs)
         ch = {s.name: s.cout for s in specs}
-        hbm_bytes = (
-            3 * t_pad * (2000 * 2 + 64 * 4) +                  # output_conv fwd / dgrad / wgrad: activation + logits
-            t_pad * K_CLASSES * 4 * 3 +                        # softmax: logits in, probs + log q out
-            t_pad * K_CLASSES * 4 * 2 + 2 * 2 * t_pad * 401 * 4 +  # CTC: log q, probs; alpha/beta written and read
-            sum(t_pad * ch[n] * 2 for n in names) +            # bias gradients: each layer's g read once
-            n_param * 32.0)                                    # Adam + repack: 4 fp32 reads, 3 fp32 + 2 bf16 writes
-        hbm_tags = [t for t in live_ms if t in ("softmax", "ctc") or t.endswith(":output_conv") or
-                    t.startswith("adam") or t.startswith("bgrad:")]
+        # algorithmic bytes per launch tag (each operand / result once, padded frames included; bf16 activations)
+        bytes_by_tag = {
+            "fwd:output_conv": t_pad * (2000 * 2 + 2 * K_CLASSES * 4),          # activation in, probs + log q out
+            "dgrad:output_conv": t_pad * (128 * 2 + 2000 * 2 + 2000 * 2),      # g in, mask in, g out
+            "wgrad:output_conv": t_pad * (2000 * 2 + 128 * 2),                 # activation + g in (dW is 0.5 MB)
+            "softmax": t_pad * K_CLASSES * 4 * 3,
+            # CTC: log q + probs in; alpha and beta lattices written by the lattice kernel, read by the gradient kernel;
+            # dL/dlogits out (bf16, 128 padded lanes)
+            "ctc": t_pad * (K_CLASSES * 4 * 2 + 2 * 2 * 401 * 4 + 128 * 2),
+        }
+        for n in names:
+            bytes_by_tag["bgrad:" + n] = t_pad * ch[n] * 2                     # each layer's g read once
+        adam_tags = [t for t in live_ms if t.startswith("adam")]
+        for t in adam_tags:                                                    # 4 fp32 reads, 3 fp32 + 2 bf16 writes
+            bytes_by_tag[t] = n_param * 32.0 / len(adam_tags)
+        per_kernel = []
+        for tag in sorted(bytes_by_tag):
+            if tag in live_ms and live_ms[tag] > 0:
+                gbps = bytes_by_tag[tag] / (live_ms[tag] * 1e-3) / 1e9
+                per_kernel.append({"launch": tag, "bytes": bytes_by_tag[tag], "ms": live_ms[tag], "GBps": gbps,
+                                   "frac_of_8TBps": gbps / 8000.0})
+        hbm_tags = [e["launch"] for e in per_kernel]
+        hbm_bytes = sum(e["bytes"] for e in per_kernel)
         hbm_ms = sum(live_ms[t] for t in hbm_tags)
         result["roofline"] = {"bound": "hbm", "kernel": "the step's HBM-bound kernels together: output_conv fwd/dgrad/"
-                                                        "wgrad, softmax, CTC lattice+gradient, bias gradients, Adam",
+                                                        "wgrad, softmax, CTC lattice+gradient, bias gradients, Adam "
+                                                        "(each one listed in per_kernel)",
                               "achieved": hbm_bytes / (hbm_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                               "frac": hbm_bytes / (hbm_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                              "bytes_per_step": hbm_bytes, "ms_per_step": hbm_ms,
+                              "bytes_per_step": hbm_bytes, "ms_per_step": hbm_ms, "per_kernel": per_kernel,
                               "note": "algorithmic bytes (each operand / result once, padded frames included) over "
-                                      "the summed live durations of those launches; the CTC lattice is latency- not "
-                                      "bandwidth-bound (4000 sequential frames), which is what holds this number down"}
+                                      "the live durations of those launches, averaged over the bucketed batches; the "
+                                      "CTC lattice is latency- not bandwidth-bound (up to 4000 sequential frames), "
+                                      "which is what holds the group's number down"}
         result["padding_waste"] = waste
     if world == 1 and not args.no_cpu_baseline and args.config == 3:
         from oracle import w2l_oracle as o

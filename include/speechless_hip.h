@@ -213,6 +213,11 @@ int sl_adam_pack_layers(float* param, const float* grad, float* m, float* v, con
  */
 int sl_dropout(const void* src, void* dst, size_t n, int dtype, float rate, uint64_t seed, void* stream);
 int sl_scale(void* x, size_t n, int dtype, float scale, void* stream);
+/* Dropout behind an ELU layer (activation="elu", main.py:71-78, with dropout=...): a stored zero cannot tell a dropped
+ * element from elu(z) == 0, so the input gradient is produced with SL_EPI_NONE and this pass applies both factors:
+ *   g[i] = keep_i ? g[i] / (1 - rate) * (y[i] > 0 ? 1 : y[i] * (1 - rate) + 1) : 0
+ * with y the stored post-dropout activation and keep_i recomputed from (seed, i) exactly as sl_dropout drew it. */
+int sl_elu_dropout_backward(void* g, const void* y, size_t n, int dtype, float rate, uint64_t seed, void* stream);
 
 /* ---- Keras-2.0 Adam (net.py:132): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps) ------------------- */
 int sl_adam_step(float* param, const float* grad, float* m, float* v, size_t n, int step, float lr, float beta1,

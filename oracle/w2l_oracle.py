@@ -325,6 +325,8 @@ def ctc_brute_force(probs_t_k, label, blank, eps=1e-8):
 def loss_and_gradients(specs, weights, input_batch, labels, prediction_lengths, label_lengths, eps=1e-8,
                        bf16_mirror=False, frozen_layer_count=0, input_scales=None):
     """Returns dict(probs, losses (B,), mean_loss, grads [(dW, db)] * n_layers, dlogits).
+    bf16_mirror: False | True (weights, stored activations and stored gradients rounded to bf16, as the HIP bf16 path
+    stores them) | "fp32_g" (the same with the back-propagated signal kept unrounded).
     input_scales: see forward_stack (explicit dropout masks); the input gradient of a layer passes through the same
     multiplier on its way to the previous layer's activation."""
     probs, xs, zs = forward_stack(specs, weights, input_batch, bf16_mirror=bf16_mirror, keep=True,
@@ -343,7 +345,8 @@ def loss_and_gradients(specs, weights, input_batch, labels, prediction_lengths, 
         w, _ = weights[li]
         if bf16_mirror:
             w = round_to_bf16(w).astype(w.dtype)
-            dz = round_to_bf16(dz).astype(dz.dtype)
+            if bf16_mirror != "fp32_g":  # "fp32_g": what-if experiment, back-propagated signal stored unrounded
+                dz = round_to_bf16(dz).astype(dz.dtype)
         dx, dw, db = conv1d_backward(xs[li], w, spec.stride, dz)
         grads[li] = (dw, db)
         dzs[li] = dz

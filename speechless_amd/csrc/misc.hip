@@ -385,7 +385,53 @@ __global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ x, long n, f
     }
 }
 
+// backward of Dropout behind an ELU layer: g holds dL/d(dropped activation) (dgrad with SL_EPI_NONE), y the stored
+// post-dropout activation m' = keep ? elu(z) / (1 - rate) : 0.  The keep decision is recomputed from (seed, index) --
+// a stored zero cannot tell "dropped" from elu(z) == 0 -- and elu'(z) = z > 0 ? 1 : elu(z) + 1 = m' * (1 - rate) + 1.
+template <typename T>
+__global__ __launch_bounds__(256) void elu_dropout_backward_kernel(T* __restrict__ g, const T* __restrict__ y, long n,
+                                                                   unsigned int threshold, float scale, float keep_prob,
+                                                                   unsigned long long seed) {
+    const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long i = i0 + j;
+        if (i < n) {
+            const bool keep = dropout_bits(seed, (unsigned long long)i) >= threshold;
+            float gv, m;
+            if (sizeof(T) == 2) {
+                gv = bf16_bits_to_f32((unsigned short)g[i]);
+                m = bf16_bits_to_f32((unsigned short)y[i]);
+            } else {
+                gv = (float)g[i];
+                m = (float)y[i];
+            }
+            const float d = m > 0.f ? 1.f : m * keep_prob + 1.f;
+            g[i] = cvt_out<T>(keep ? gv * scale * d : 0.f);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int sl_elu_dropout_backward(void* g, const void* y, size_t n, int dtype, float rate, uint64_t seed,
+                                       void* stream) {
+    SL_CHECK_ARG(g && y, "sl_elu_dropout_backward: null pointer");
+    SL_CHECK_ARG(rate >= 0.f && rate < 1.f, "sl_elu_dropout_backward: rate %f outside [0, 1)", (double)rate);
+    SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32, "sl_elu_dropout_backward: unknown dtype %d", dtype);
+    if (n == 0) return SL_OK;
+    const unsigned int threshold = (unsigned int)((double)rate * 4294967296.0);
+    const float scale = 1.f / (1.f - rate);
+    const unsigned blocks = (unsigned)((n + 1023) / 1024);
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL(elu_dropout_backward_kernel<unsigned short>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (unsigned short*)g, (const unsigned short*)y, (long)n, threshold, scale, 1.f - rate,
+                           (unsigned long long)seed);
+    else
+        hipLaunchKernelGGL(elu_dropout_backward_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (float*)g, (const float*)y, (long)n, threshold, scale, 1.f - rate, (unsigned long long)seed);
+    return sl_check_launch("sl_elu_dropout_backward");
+}
 
 extern "C" int sl_dropout(const void* src, void* dst, size_t n, int dtype, float rate, uint64_t seed, void* stream) {
     SL_CHECK_ARG(src && dst, "sl_dropout: null pointer");

@@ -86,17 +86,20 @@ class LayerPlan:
 
 
 class _Buffers:
-    """All HBM tensors of one (batch, frames) geometry."""
+    """All HBM tensors of one (batch, padded frames) geometry.  Batches of any length whose output frames round up to
+    the same multiple of TIME_TILE share one set of buffers (the reference's training generator, corpus.py:224-226,
+    pads every batch to its own longest member, so the frame count changes with nearly every step): set_length()
+    re-targets the geometry descriptors and keeps the layout invariant (rows beyond the valid time are zero) by clearing
+    only the rows between the new length and the previous high-water mark."""
 
-    def __init__(self, eng, batch, t_in):
+    def __init__(self, eng, batch, tt_pad):
         dev = eng.device
         dt = eng.torch_dtype
         p0 = eng.plans[0]
         self.batch = batch
-        self.t_in = t_in
-        self.t_out, pad_l, _ = same_padding(t_in, p0.spec.kernel_size, p0.spec.stride)
-        assert pad_l == p0.pad_left
-        self.tt_pad = _round_up(self.t_out, TIME_TILE)
+        self.tt_pad = tt_pad
+        self.t_in = None
+        self.t_out = None
         self.rows = HALO + self.tt_pad + HALO
         self.rows0 = 2 * (self.tt_pad + p0.taps_view)
         self.x0 = torch.zeros((batch, self.rows0, p0.cin_pad), dtype=dt, device=dev)
@@ -104,30 +107,34 @@ class _Buffers:
         self.dropped = False    # the activations of the last forward are post-dropout
         n = len(eng.plans)
         self.y = [None] * (n - 1)
+        self._blocks = []  # every halo'd allocation (runs of identical layers are one), for set_length()'s clearing
         # a run of identical layers (the seven inner_conv_i) keeps its inputs y[s-1..e-1] in ONE allocation so that
         # the grouped weight-gradient launch can address layer q as base + q*stride
         for (s0, e0) in eng.runs:
             block = torch.zeros((e0 - s0 + 1, batch, self.rows, eng.plans[s0].cin_pad), dtype=dt, device=dev)
+            self._blocks.append(block)
             for q in range(e0 - s0 + 1):
                 self.y[s0 - 1 + q] = block[q]
         for p in eng.plans[:-1]:
             if self.y[p.index] is None:
                 self.y[p.index] = torch.zeros((batch, self.rows, p.cout_pad), dtype=dt, device=dev)
+                self._blocks.append(self.y[p.index].unsqueeze(0))
         self.logits = torch.zeros((batch, self.tt_pad, eng.plans[-1].cout_pad), dtype=torch.float32, device=dev)
         k = eng.grapheme_set_size
-        self.probs = torch.zeros((batch, self.t_out, k), dtype=torch.float32, device=dev)
-        self.logq = torch.zeros((batch, self.t_out, k), dtype=torch.float32, device=dev)
+        # dense [B][T'][K] / [B][T'] results: flat allocations for the longest batch, viewed per length
+        self._probs_flat = torch.zeros((batch * self.tt_pad * k,), dtype=torch.float32, device=dev)
+        self._logq_flat = torch.zeros((batch * self.tt_pad * k,), dtype=torch.float32, device=dev)
+        self._decoded_flat = torch.zeros((batch * self.tt_pad,), dtype=torch.int32, device=dev)
+        self._argmax_flat = torch.zeros((batch * self.tt_pad,), dtype=torch.int32, device=dev)
         self.g = [None] * n  # allocated lazily by ensure_backward()
-        self.decoded = torch.zeros((batch, self.t_out), dtype=torch.int32, device=dev)
         self.decoded_len = torch.zeros((batch,), dtype=torch.int32, device=dev)
-        self.frame_argmax = torch.zeros((batch, self.t_out), dtype=torch.int32, device=dev)
         self.input_len = torch.zeros((batch,), dtype=torch.int32, device=dev)
         self.loss = torch.zeros((batch,), dtype=torch.float32, device=dev)
         self.fwd_geom = []
         for p in eng.plans:
             g = ConvGeom()
             g.batch = batch
-            g.t_out = self.t_out
+            g.t_out = self.tt_pad
             g.taps = p.taps_view
             g.cin = p.cin_view
             g.cout = p.cout_pad
@@ -148,9 +155,46 @@ class _Buffers:
                 g.y_row_stride = p.cout_pad
                 g.y_batch_stride = self.rows * p.cout_pad
             self.fwd_geom.append(g)
+        self.wgrad_geom = [None] * n
+        self.dgrad_geom = [None] * n
         self.bwd_ready = False
         self.nt_ws = None
-        self.size_nt_workspace(eng, self.fwd_geom, "fwd")
+        self.wgrad_ws = None
+        self._ws_sized = set()   # output lengths whose workspace needs have been checked
+        self._clean_in = 0       # input frames / output rows up to which stale data may sit in the buffers
+        self._clean_out = 0
+
+    def set_length(self, eng, t_in):
+        """Re-targets the buffers at batches of t_in input frames (same tt_pad)."""
+        p0 = eng.plans[0]
+        t_out, pad_l, _ = same_padding(t_in, p0.spec.kernel_size, p0.spec.stride)
+        assert pad_l == p0.pad_left and _round_up(t_out, TIME_TILE) == self.tt_pad
+        # rows [new length, high-water mark) still hold the previous, longer batch: the kernels never write rows
+        # beyond the valid time, so they are cleared here (nothing to do while the lengths grow)
+        if t_in < self._clean_in:
+            self.x0[:, p0.pad_left + t_in: p0.pad_left + self._clean_in].zero_()
+        if t_out < self._clean_out:
+            for block in self._blocks:
+                block[:, :, HALO + t_out: HALO + self._clean_out].zero_()
+        self._clean_in, self._clean_out = t_in, t_out
+        if t_in == self.t_in:
+            return
+        self.t_in, self.t_out = t_in, t_out
+        k = eng.grapheme_set_size
+        b = self.batch
+        self.probs = self._probs_flat[:b * t_out * k].view(b, t_out, k)
+        self.logq = self._logq_flat[:b * t_out * k].view(b, t_out, k)
+        self.decoded = self._decoded_flat[:b * t_out].view(b, t_out)
+        self.frame_argmax = self._argmax_flat[:b * t_out].view(b, t_out)
+        for geoms in (self.fwd_geom, self.wgrad_geom, self.dgrad_geom):
+            for g in geoms:
+                if g is not None:
+                    g.t_out = t_out
+        if t_out not in self._ws_sized:  # split counts (hence workspace sizes) depend on the number of time tiles
+            self._ws_sized.add(t_out)
+            self.size_nt_workspace(eng, self.fwd_geom, "fwd")
+            if self.bwd_ready:
+                self.size_backward_workspaces(eng)
 
     def size_nt_workspace(self, eng, geoms, kind):
         need = 16
@@ -165,22 +209,19 @@ class _Buffers:
         if self.bwd_ready:
             return
         dev, dt = eng.device, eng.torch_dtype
-        L = lib()
         n = len(eng.plans)
         first = eng.frozen_layer_count
-        self.wgrad_geom = [None] * n
-        self.dgrad_geom = [None] * n
-        ws_bytes = 0
-        bias_ws = 0
         for (s0, e0) in eng.runs:  # gradients g[s..e] of a run of identical layers: one allocation (grouped wgrad)
             lo = max(s0, first)
             if e0 >= lo:
                 block = torch.zeros((e0 - lo + 1, self.batch, self.rows, eng.plans[lo].cout_pad), dtype=dt, device=dev)
+                self._blocks.append(block)
                 for q in range(e0 - lo + 1):
                     self.g[lo + q] = block[q]
         for p in eng.plans[first:]:
             if self.g[p.index] is None:
                 self.g[p.index] = torch.zeros((self.batch, self.rows, p.cout_pad), dtype=dt, device=dev)
+                self._blocks.append(self.g[p.index].unsqueeze(0))
             wg = ConvGeom()
             f = self.fwd_geom[p.index]
             for name, _ in ConvGeom._fields_:
@@ -189,9 +230,6 @@ class _Buffers:
             wg.y_row_stride = p.cout_pad
             wg.y_batch_stride = self.rows * p.cout_pad
             self.wgrad_geom[p.index] = wg
-            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
-                ctypes.byref(wg), eng.dtype_code, eng.nt_cfg.get(("wgrad", p.spec.name), 0)))
-            bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
             if p.index > first:
                 dg = ConvGeom()
                 dg.batch = self.batch
@@ -206,6 +244,24 @@ class _Buffers:
                 dg.y_row_stride = p.cin_pad
                 dg.y_batch_stride = self.rows * p.cin_pad
                 self.dgrad_geom[p.index] = dg
+        self.bias_ws = None
+        self.ctc_ws = None
+        self.ctc_ws_lmax = -1
+        self.labels = None
+        self.label_len = torch.zeros((self.batch,), dtype=torch.int32, device=dev)
+        self.bwd_ready = True
+        self.size_backward_workspaces(eng)
+
+    def size_backward_workspaces(self, eng):
+        L = lib()
+        first = eng.frozen_layer_count
+        ws_bytes = 0
+        bias_ws = 0
+        for p in eng.plans[first:]:
+            wg = self.wgrad_geom[p.index]
+            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
+                ctypes.byref(wg), eng.dtype_code, eng.nt_cfg.get(("wgrad", p.spec.name), 0)))
+            bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
         self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
         if eng.dtype == "bf16":
             for (s0, e0) in eng.runs:
@@ -213,18 +269,15 @@ class _Buffers:
                 if e0 > lo:
                     ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_grouped_workspace_bytes")(
                         ctypes.byref(self.wgrad_geom[lo]), e0 - lo + 1, 0))
-        self.wgrad_ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
-        self.bias_ws = torch.empty((max(bias_ws, 16),), dtype=torch.uint8, device=dev)
-        self.ctc_ws = None
-        self.ctc_ws_lmax = -1
-        self.labels = None
-        self.label_len = torch.zeros((self.batch,), dtype=torch.int32, device=dev)
-        self.bwd_ready = True
+        if self.wgrad_ws is None or self.wgrad_ws.numel() < ws_bytes:
+            self.wgrad_ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=eng.device)
+        if self.bias_ws is None or self.bias_ws.numel() < bias_ws:
+            self.bias_ws = torch.empty((max(bias_ws, 16),), dtype=torch.uint8, device=eng.device)
 
     def ensure_ctc(self, eng, l_max):
         if self.ctc_ws is not None and l_max <= self.ctc_ws_lmax:
             return
-        need = lib().raw("sl_ctc_workspace_bytes")(self.batch, self.t_out, l_max)
+        need = lib().raw("sl_ctc_workspace_bytes")(self.batch, self.tt_pad, l_max)  # covers every length
         self.ctc_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=eng.device)
         self.ctc_ws_lmax = l_max
         self.labels = torch.zeros((self.batch, l_max), dtype=torch.int32, device=eng.device)
@@ -301,7 +354,7 @@ class Engine:
                         if p.index > 0 else None for p in self.plans]
         self._packed_dirty = True
         self._buffers = {}
-        self.max_cached_shapes = 4  # (batch, frames) geometries kept allocated (length-bucketed corpora: raise it)
+        self.max_cached_shapes = 4  # (batch, frames rounded up to 512) geometries kept allocated
         # Keras Dropout(rate) in front of every conv except the last three (net.py:301-303, 326-330); training steps
         # only.  None = off (every reference configuration).
         self.dropout_rate = None
@@ -352,13 +405,18 @@ class Engine:
         self.timeline.append((tag, start, stop))
 
     def buffers(self, batch, t_in):
-        key = (batch, t_in)
+        """Buffers for batches of `batch` utterances padded to t_in frames: one set per (batch, output frames rounded
+        up to TIME_TILE), re-targeted at t_in (see _Buffers.set_length)."""
+        p0 = self.plans[0]
+        t_out, _, _ = same_padding(t_in, p0.spec.kernel_size, p0.spec.stride)
+        key = (batch, _round_up(max(t_out, 1), TIME_TILE))
         buf = self._buffers.get(key)
         if buf is None:
             if len(self._buffers) >= self.max_cached_shapes:  # bound HBM use when many batch shapes are seen
                 self._buffers.pop(next(iter(self._buffers)))
-            buf = _Buffers(self, batch, t_in)
+            buf = _Buffers(self, batch, key[1])
             self._buffers[key] = buf
+        buf.set_length(self, t_in)
         return buf
 
     def layer_param_views(self, tensor, plan):
@@ -404,6 +462,25 @@ class Engine:
 
     def get_gradients(self):
         return self._unpad(self.grads)
+
+    def get_optimizer_state(self):
+        """Adam moments in the Keras layout (per layer (m_W, m_b), (v_W, v_b)), the step count and the dropout step
+        counter: everything beyond the weights that the next step depends on."""
+        return {"m": self._unpad(self.adam_m), "v": self._unpad(self.adam_v), "iterations": int(self.adam_iterations),
+                "dropout_steps": int(self._dropout_steps)}
+
+    def set_optimizer_state(self, state):
+        for name, flat in (("m", self.adam_m), ("v", self.adam_v)):
+            flat.zero_()
+            for p, (w, b) in zip(self.plans, state[name]):
+                s = p.spec
+                if tuple(w.shape) != (s.kernel_size, s.cin, s.cout) or tuple(b.shape) != (s.cout,):
+                    raise ValueError("optimizer state of layer {} has shape {} / {}".format(s.name, w.shape, b.shape))
+                wv, bv = self.layer_param_views(flat, p)
+                wv[:, :s.cin, :s.cout] = torch.as_tensor(np.ascontiguousarray(w, dtype=np.float32)).to(self.device)
+                bv[:s.cout] = torch.as_tensor(np.ascontiguousarray(b, dtype=np.float32)).to(self.device)
+        self.adam_iterations = int(state["iterations"])
+        self._dropout_steps = int(state.get("dropout_steps", 0))
 
     def repack_weights(self):
         st = self._stream()
@@ -453,11 +530,9 @@ class Engine:
         buf.dropped = bool(rate)
         x = buf.x0
         if rate:
-            if any(p.spec.activation == "elu" for p in self.plans[:-1]):
-                raise NotImplementedError("dropout with activation='elu': the backward pass recovers the keep mask from "
-                                          "the stored activation being > 0, which only holds for ReLU")
             self._dropout_steps += 1
             seed0 = (self.dropout_seed * 1000003 + self._dropout_steps) * 64
+            buf.dropout_seed0 = seed0  # ELU layers: backward recomputes the keep decisions (sl_elu_dropout_backward)
             if buf.x0_dropped is None:
                 buf.x0_dropped = torch.zeros_like(buf.x0)
             self._launch("dropout:input", "sl_dropout", buf.x0.data_ptr(), buf.x0_dropped.data_ptr(), buf.x0.numel(),
@@ -669,12 +744,21 @@ class Engine:
                     join_side()
                     on_bucket_ready(0)
             if i > first:
+                elu = self.specs[i - 1].activation == "elu"
+                elu_dropped = elu and buf.dropped and i in self._dropout_layers()
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(),
-                             None, buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]),
-                             _lib.EPI_ELU_MASK if self.specs[i - 1].activation == "elu" else _lib.EPI_RELU_MASK,
+                             None, None if elu_dropped else buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(),
+                             ctypes.byref(buf.dgrad_geom[i]),
+                             _lib.EPI_NONE if elu_dropped else (_lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK),
                              self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
                              buf.nt_ws.data_ptr(), buf.nt_ws.numel(), main.cuda_stream)
-                if buf.dropped and i in self._dropout_layers():
+                if elu_dropped:
+                    # a stored zero is ambiguous behind an ELU (dropped, or elu(z) == 0): both factors of the chain rule
+                    # in one elementwise pass that recomputes the keep decisions from the step's seed
+                    self._launch("dropout_elu_bwd:" + p.spec.name, "sl_elu_dropout_backward", buf.g[i - 1].data_ptr(),
+                                 buf.y[i - 1].data_ptr(), buf.g[i - 1].numel(), self.dtype_code, self.dropout_rate,
+                                 buf.dropout_seed0 + i, main.cuda_stream)
+                elif buf.dropped and i in self._dropout_layers():
                     # the dgrad epilogue's mask (stored activation > 0) already applied the keep mask: the stored
                     # activation is post-dropout; what is left of d dropout / dx is the 1 / (1 - rate) factor
                     self._launch("dropout_scale:" + p.spec.name, "sl_scale", buf.g[i - 1].data_ptr(), buf.g[i - 1].numel(),
@@ -758,7 +842,7 @@ class Engine:
         # two steps on this geometry: the label / length tensors are used in place (set_labels_resident) and the CTC
         # workspace grows with the longest label row seen
         key = (buf.labels.data_ptr(), buf.label_len.data_ptr(), buf.input_len.data_ptr(), int(buf.labels.shape[1]),
-               buf.ctc_ws.data_ptr())
+               buf.ctc_ws.data_ptr(), buf.t_in)
         graphs = buf.__dict__.setdefault("graphs", {})
         g = graphs.get(key)
         if g is None:
@@ -775,6 +859,8 @@ class Engine:
                 self.ctc(grad_scale=1.0 / buf.batch)
                 self.backward()
             graphs[key] = g
+        if self._packed_dirty:  # set_weights() since the capture: the operand repack is not part of the graph
+            self.repack_weights()
         g.replay()
         return buf.loss
 

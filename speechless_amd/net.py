@@ -201,9 +201,13 @@ class PredictiveNet:
                 group.create_dataset(names[1], data=b)
 
     def load_weights(self, path):
+        """Loads the file that was asked for; only when it does not exist the `.npz` twin that save_weights writes on
+        machines without h5py is used instead (and that is logged)."""
         path = Path(path)
         npz = path.with_suffix(".npz")
-        if npz.exists():
+        if path.suffix == ".npz" or (not path.exists() and npz.exists()):
+            if path.suffix != ".npz":
+                log("{} not found: loading {}".format(path.name, npz.name))
             data = np.load(str(npz))
             self.set_weights([(data[layer.name + "/kernel"], data[layer.name + "/bias"]) for layer in self.layers])
             return
@@ -235,7 +239,8 @@ class Wav2Letter:
                  reinitialize_trainable_loaded_layers=False, use_asg=False, asg_transition_probabilities=None,
                  asg_initial_probabilities=None, kenlm_directory=None,
                  # --- extensions of this implementation (keyword-only in spirit) ---
-                 compute_dtype="bf16", device="cuda:0", seed=None, ctc_epsilon=1e-8, layer_sizes=None):
+                 compute_dtype="bf16", device="cuda:0", seed=None, ctc_epsilon=1e-8, layer_sizes=None,
+                 load_optimizer_state=False):
         if frozen_layer_count > 0 and load_model_from_directory is None:
             raise ValueError("Layers cannot be frozen if model is trained from scratch.")
         if use_asg:
@@ -269,7 +274,9 @@ class Wav2Letter:
                              beta_1=self.optimizer.beta_1, beta_2=self.optimizer.beta_2,
                              adam_epsilon=self.optimizer.epsilon)
         self.engine.dropout_rate = dropout if dropout else None  # applied by training steps only (learning phase 1)
-        self.engine.dropout_seed = seed
+        # the reference signature has no seed: a plain Wav2Letter(..., dropout=0.1) draws one (Keras does the same)
+        self.engine.dropout_seed = int(seed) if seed is not None else \
+            int(np.random.SeedSequence().entropy & 0x7fffffff)
         self.engine.set_weights(self._glorot_uniform(specs, seed))
         self.predictive_net = PredictiveNet(self.engine)
         for layer in self.predictive_net.layers[:frozen_layer_count]:
@@ -281,6 +288,8 @@ class Wav2Letter:
             self.load_weights(allowed_characters_for_loaded_model, load_epoch, load_model_from_directory,
                               loaded_first_layers_count=frozen_layer_count if reinitialize_trainable_loaded_layers
                               else None)
+            if load_optimizer_state:
+                self.load_optimizer_state(load_model_from_directory, load_epoch)
 
     @staticmethod
     def _glorot_uniform(specs, seed):
@@ -297,6 +306,29 @@ class Wav2Letter:
     @staticmethod
     def model_file_name(epoch):
         return "weights-epoch{}.h5".format(epoch)
+
+    @staticmethod
+    def optimizer_state_file_name(epoch):
+        return "weights-epoch{}.opt.npz".format(epoch)
+
+    def save_optimizer_state(self, net_directory, epoch):
+        """Extension: the reference saves the weights only (net.py:564-572), so a resumed run
+        restarts Adam's moments and bias correction.  This writes them next to the weights file of the same epoch."""
+        state = self.engine.get_optimizer_state()
+        arrays = {"iterations": np.int64(state["iterations"]), "dropout_steps": np.int64(state["dropout_steps"])}
+        for layer, (mw, mb), (vw, vb) in zip(self.predictive_net.layers, state["m"], state["v"]):
+            arrays[layer.name + "/kernel/m"], arrays[layer.name + "/bias/m"] = mw, mb
+            arrays[layer.name + "/kernel/v"], arrays[layer.name + "/bias/v"] = vw, vb
+        Path(net_directory).mkdir(parents=True, exist_ok=True)
+        np.savez(str(Path(net_directory) / self.optimizer_state_file_name(epoch)), **arrays)
+
+    def load_optimizer_state(self, net_directory, epoch):
+        data = np.load(str(Path(net_directory) / self.optimizer_state_file_name(epoch)))
+        names = [layer.name for layer in self.predictive_net.layers]
+        self.engine.set_optimizer_state({
+            "m": [(data[n + "/kernel/m"], data[n + "/bias/m"]) for n in names],
+            "v": [(data[n + "/kernel/v"], data[n + "/bias/v"]) for n in names],
+            "iterations": int(data["iterations"]), "dropout_steps": int(data["dropout_steps"])})
 
     @staticmethod
     def indices_to_load_by_target_index(allowed_characters_for_loaded_model, allowed_characters):
@@ -463,12 +495,15 @@ class Wav2Letter:
         return mean
 
     def train(self, labeled_spectrogram_batches, preview_labeled_spectrogram_batch, tensor_board_log_directory,
-              net_directory, batches_per_epoch, max_epochs=100000000, reducer=None, prefetch_depth=3):
+              net_directory, batches_per_epoch, max_epochs=100000000, reducer=None, prefetch_depth=3,
+              save_optimizer_state=False):
         """Epoch loop of reference net.py:541-576: preview, then epochs of `batches_per_epoch` steps starting at
         `load_epoch or 0`; after every epoch the preview is logged and (epoch > 0) the weights are saved as
         weights-epoch{N}.  Ends when the batch iterable is exhausted or after max_epochs (Keras: 1e8).
         prefetch_depth > 0: batches are packed on a worker thread and copied to HBM on a side stream
-        (speechless_amd/pipeline.py) while the previous steps run; 0 = the reference's serial behaviour."""
+        (speechless_amd/pipeline.py) while the previous steps run; 0 = the reference's serial behaviour.
+        save_optimizer_state: also write weights-epoch{N}.opt.npz (Adam moments + step count) with every checkpoint,
+        for Wav2Letter(..., load_optimizer_state=True) to resume exactly where the run stopped."""
         def print_preview_batch():
             log(self.test_and_predict_batch(preview_labeled_spectrogram_batch))
 
@@ -508,6 +543,8 @@ class Wav2Letter:
                 if epoch > 0:
                     Path(net_directory).mkdir(parents=True, exist_ok=True)
                     self.predictive_net.save_weights(Path(net_directory) / self.model_file_name(epoch))
+                    if save_optimizer_state:
+                        self.save_optimizer_state(net_directory, epoch)
                 epoch += 1
         finally:
             if stager is not None:

@@ -52,6 +52,11 @@ def pack_spectrograms(spectrograms, dst, n_threads=4):
     dtype = spectrograms[0].dtype
     if dtype not in (np.float64, np.float32) or any(s.dtype != dtype for s in spectrograms):
         dtype = np.float64
+    if len(spectrograms) != b:
+        raise ValueError("{} spectrograms for a staging buffer of {} rows".format(len(spectrograms), b))
+    for i, a in enumerate(spectrograms):  # the native packer reads lengths[i] * f elements through a raw pointer
+        if a.ndim != 2 or a.shape[1] != f or a.shape[0] > t_max:
+            raise ValueError("spectrogram {} has shape {}; expected (T <= {}, {})".format(i, a.shape, t_max, f))
     arrays = [np.ascontiguousarray(s, dtype=dtype) for s in spectrograms]  # no copy when already in that form
     ptrs = (ctypes.c_void_p * b)(*[a.ctypes.data for a in arrays])
     lengths = (ctypes.c_int32 * b)(*[a.shape[0] for a in arrays])
