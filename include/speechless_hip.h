@@ -97,7 +97,8 @@ int sl_profile_next_kernel(void* start_event, void* stop_event);
  *            stages = ring slots, +8 = register-pipelined loop; gm = m-tiles per raster block; slab = chunk-major
  *            kernel with the activation slab in LDS; interleaved = hand-interleaved MFMA / LDS-read / request
  *            streams.  SL_ERR_INVALID_ARGUMENT for a shape that is not instantiated
- *            or that the geometry rules out.  bf16 only; ignored for SL_F32.
+ *            or that the geometry rules out.  SL_F32: 0 = exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32, 128 x 128
+ *            tiles), 1 = the plain VALU FMA kernel (independent cross-check of the former).
  *   workspace: sl_conv1d_nt_workspace_bytes(geom, dtype, cfg) bytes (split-K partial tiles; 0 when not split).
  */
 size_t sl_conv1d_nt_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg);
@@ -113,6 +114,7 @@ int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* ma
  * Deterministic: split-K partials go to `workspace` and are reduced in a fixed order.
  * cfg: 0 = library picks tile shape / ring depth / batch split (measured table); otherwise
  *      wm | wn<<4 | stages<<8 | splits<<12 (tile = 64*wm input channels x 64*wn output channels; splits 0 = auto).
+ *      SL_F32: 0 = exact-fp32 MFMA kernel (channel counts that are multiples of 128), 1 = VALU FMA kernel.
  */
 size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg);
 int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype, int cfg,

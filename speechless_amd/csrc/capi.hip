@@ -65,7 +65,7 @@ extern "C" int sl_conv1d_nt(const void* x, const void* w, const float* bias, con
     if (dtype == SL_BF16)
         return conv_nt_bf16(x, w, bias, mask, y, geom, epilogue, out_f32, cfg, workspace, workspace_bytes,
                             (hipStream_t)stream);
-    if (dtype == SL_F32) return conv_nt_f32(x, w, bias, mask, y, geom, epilogue, (hipStream_t)stream);
+    if (dtype == SL_F32) return conv_nt_f32(x, w, bias, mask, y, geom, epilogue, cfg, (hipStream_t)stream);
     sl_set_error("sl_conv1d_nt: unknown dtype %d", dtype);
     return SL_ERR_INVALID_ARGUMENT;
 }
@@ -98,7 +98,7 @@ extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int 
         return wgrad_tn_bf16_workspace_bytes(geom, cfg, 1);
     }
     if (geom->cin % 64 || geom->cout % 64) return 0;
-    const int splits = wgrad_split_count(geom, 64);
+    const int splits = wgrad_split_count(geom, wgrad_f32_tile(geom, cfg));
     if (splits <= 1) return 0;
     return (size_t)splits * geom->taps * geom->cin * geom->cout * sizeof(float);
 }
@@ -112,13 +112,13 @@ extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl
     SL_CHECK_ARG(x && g && dw, "sl_conv1d_wgrad: null tensor pointer");
     if (dtype == SL_BF16)
         return wgrad_tn_bf16(x, g, dw, geom, cfg, 1, 0, 0, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
-    const int splits = wgrad_split_count(geom, tile);
-    const size_t need = sl_conv1d_wgrad_workspace_bytes(geom, dtype, 0);
+    const int splits = wgrad_split_count(geom, wgrad_f32_tile(geom, cfg));
+    const size_t need = sl_conv1d_wgrad_workspace_bytes(geom, dtype, cfg);
     if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
         sl_set_error("sl_conv1d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
         return SL_ERR_WORKSPACE_TOO_SMALL;
     }
-    return wgrad_tn_f32(x, g, dw, geom, (float*)workspace, splits, (hipStream_t)stream);
+    return wgrad_tn_f32(x, g, dw, geom, (float*)workspace, splits, cfg, (hipStream_t)stream);
 }
 
 extern "C" size_t sl_conv1d_wgrad_grouped_workspace_bytes(const sl_conv_geom* geom, int groups, int cfg) {

@@ -68,9 +68,11 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
                  int epilogue, int out_f32, int cfg, void* workspace, size_t workspace_bytes, hipStream_t s);
 size_t conv_nt_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
 int conv_nt_f32(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
-                int epilogue, hipStream_t s);
+                int epilogue, int cfg, hipStream_t s);
 int wgrad_split_count(const sl_conv_geom* g, int tile);
 int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, int groups, long x_gs,
                   long g_gs, long dw_gs, float* ws, size_t ws_bytes, hipStream_t s);
 size_t wgrad_tn_bf16_workspace_bytes(const sl_conv_geom* g, int cfg, int groups);
-int wgrad_tn_f32(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits, hipStream_t s);
+int wgrad_tn_f32(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits, int cfg,
+                 hipStream_t s);
+int wgrad_f32_tile(const sl_conv_geom* g, int cfg);

@@ -164,33 +164,46 @@ def test_bf16_gradients_at_full_length_against_the_cpu_path():
 
 
 def test_bf16_and_fp32_training_trajectories_stay_together():
-    """200 Adam(1e-4) steps on one synthetic batch of 32 utterances (128 mel x 200 frames, labels 5..30), bf16 path
-    and fp32 path from the same initial weights: the two loss curves must stay within 1 % of each other at every step
-    (and both must fall) -- i.e. the gradient noise of bf16 storage is noise, not bias."""
+    """200 Adam(1e-4) steps on one synthetic batch of 32 utterances (128 mel x 200 frames), three runs from the same
+    data: the fp32 path, the fp32 path from initial weights perturbed by 1e-6 relative, and the bf16 path.
+    Measured (tools/trajectory_probe.py): through the well-conditioned first 100 steps (loss 270 -> 62) the bf16 curve
+    stays within 7e-4 .. 2e-3 of the fp32 one; after that the optimisation itself is chaotic -- the 1e-6 perturbation of the
+    fp32 run has grown to a 10 % loss gap by step 160 and to O(1) by step 180 -- and the bf16 gap follows the same
+    envelope a small factor above it.  So: (1) bf16 within 5e-3 of fp32 at each of the first 100 steps; (2) at every
+    later step the running maximum of the bf16 gap is at most 10x that of the perturbed fp32 run (+ 2e-3), while the
+    latter is below 0.3; (3) all three runs make progress.  I.e. the gradient noise of bf16 storage is noise of the
+    size the problem already amplifies, not a bias."""
     import torch
-    b, t = 32, 200
+    b, t, steps = 32, 200, 200
     case = make_case(b=b, t=t, seed=77)
     rng = np.random.RandomState(78)
     lab_len = rng.randint(5, 31, size=b)
     labels = o.pack_label_batch([list(rng.randint(0, 28, size=n)) for n in lab_len])
     pred_len = np.full((b,), t // 2, dtype=np.int32)
+    prng = np.random.RandomState(5)
+    perturbed = [((w * (1 + 1e-6 * prng.randn(*w.shape))).astype(np.float32), bb) for w, bb in case["weights"]]
     curves = {}
-    for dtype in ("f32", "bf16"):
+    for name, dtype, weights in (("f32", "f32", case["weights"]), ("f32_perturbed", "f32", perturbed),
+                                 ("bf16", "bf16", case["weights"])):
         eng = make_engine(case, dtype)
+        eng.set_weights(weights)
         eng.load_input(case["x"])
         eng.set_labels(labels, lab_len, pred_len)
-        means = []
-        for _ in range(200):
-            means.append(eng.train_step_resident().mean())
+        means = [eng.train_step_resident().mean() for _ in range(steps)]
         torch.cuda.synchronize()
-        curves[dtype] = np.array([float(m.item()) for m in means])
-    a, c = curves["f32"], curves["bf16"]
-    rel = np.abs(c / a - 1)
-    _report("trajectory_200_steps_max_rel_loss_gap_bf16_vs_f32", float(rel.max()))
-    _report("trajectory_200_steps_loss_first_last_f32", [float(a[0]), float(a[-1])])
-    _report("trajectory_200_steps_loss_first_last_bf16", [float(c[0]), float(c[-1])])
-    assert a[-1] < 0.7 * a[0] and c[-1] < 0.7 * c[0]
-    assert rel.max() < 1e-2, (rel.max(), int(rel.argmax()))
+        curves[name] = np.array([float(m.item()) for m in means])
+    a, p, c = curves["f32"], curves["f32_perturbed"], curves["bf16"]
+    gap_b = np.maximum.accumulate(np.abs(c / a - 1))
+    gap_p = np.maximum.accumulate(np.abs(p / a - 1))
+    _report("trajectory_bf16_vs_f32_gap_envelope_at_steps_50_100_150_200", [float(gap_b[i]) for i in (49, 99, 149, 199)])
+    _report("trajectory_f32_perturbed_1e-6_gap_envelope_at_steps_50_100_150_200",
+            [float(gap_p[i]) for i in (49, 99, 149, 199)])
+    _report("trajectory_losses_first_100th_last", {k: [float(v[0]), float(v[99]), float(v[-1])] for k, v in curves.items()})
+    assert gap_b[99] < 5e-3, gap_b[99]
+    comparable = gap_p < 0.3
+    assert np.all(gap_b[comparable] <= 10 * gap_p[comparable] + 2e-3), (gap_b[comparable], gap_p[comparable])
+    for v in curves.values():
+        assert v[99] < 0.3 * v[0] and v[:150].min() < 0.2 * v[0]
 
 
 # ------------------------------------------------------------------------------------------ transfer learning (f1)
@@ -412,8 +425,12 @@ def test_dropout_training_step_with_recomputed_masks(activation):
     ref = o.loss_and_gradients(ospecs, weights64(case), case["x"].astype(np.float64), case["labels"],
                                case["prediction_lengths"], case["label_lengths"], input_scales=scales)
     assert np.allclose(loss, ref["losses"], rtol=2e-5), (loss, ref["losses"])
-    for i, ((dw, db), (rw, rb)) in enumerate(zip(eng.get_gradients(), ref["grads"])):
-        assert rel_l2(dw, rw) < 2e-4 and rel_l2(db, rb) < 2e-4, (i, rel_l2(dw, rw), rel_l2(db, rb))
+    errs = [max(rel_l2(dw, rw), rel_l2(db, rb)) for (dw, db), (rw, rb) in zip(eng.get_gradients(), ref["grads"])]
+    # fp32 against float64: a pre-activation within fp32 rounding of zero may take the other ReLU branch (one mask
+    # element of ~36 000 here = 5e-3 of the signal from that layer DOWN, DESIGN.md "ReLU mask flips"); so the layers
+    # above the first such flip agree to 2e-4 and the ones below it, a prefix of the stack, to 1e-2
+    loose = [i for i, e in enumerate(errs) if e >= 2e-4]
+    assert max(errs) < 1e-2 and loose == list(range(len(loose))) and errs[-1] < 2e-4, errs
 
 
 def test_dropout_without_a_seed_draws_one():
@@ -437,6 +454,8 @@ def test_batches_of_different_lengths_share_one_set_of_buffers(dtype):
     import torch
     lengths = [300, 262, 131, 300, 508, 77]
     cases = {t: make_case(b=3, t=t, seed=50 + t) for t in set(lengths)}
+    for case in cases.values():
+        case["weights"] = cases[300]["weights"]  # (make_case draws the biases from its seed)
     shared = make_engine(cases[300], dtype)
     for t in lengths:
         case = cases[t]
@@ -451,5 +470,70 @@ def test_batches_of_different_lengths_share_one_set_of_buffers(dtype):
         dec_b, _ = fresh.greedy_decode(case["prediction_lengths"])
         assert dec_a == dec_b
     big = make_case(b=3, t=600, seed=1)  # T' = 300 -> the next buffer size
+    big["weights"] = cases[300]["weights"]
     run_loss_and_grads(shared, big)
     assert len(shared._buffers) == 2
+
+
+# ------------------------------------------------------------------------------------------ exact-fp32 MFMA path
+def test_fp32_mfma_kernels_against_the_valu_kernels_and_float64():
+    """The fp32 path's two GEMMs on v_mfma_f32_32x32x2_f32 (default) against the plain VALU FMA kernels of round 1
+    (cfg 1) and against float64, through a whole step: both are exact-fp32 fmaf chains in a different order, so they
+    agree to fp32 round-off."""
+    from speechless_amd.engine import HALO
+    case = make_case(b=3, t=150, seed=12)
+    engines = {}
+    for name, cfg in (("mfma", 0), ("valu", 1)):
+        eng = make_engine(case, "f32")
+        for spec in eng.specs:
+            for kind in ("fwd", "dgrad", "wgrad"):
+                eng.nt_cfg[(kind, spec.name)] = cfg
+        losses, grads = run_loss_and_grads(eng, case)
+        engines[name] = (eng, losses, grads)
+    ref = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), case["labels"],
+                               case["prediction_lengths"], case["label_lengths"])
+    (ea, la, ga), (eb, lb, gb) = engines["mfma"], engines["valu"]
+    np.testing.assert_allclose(la, ref["losses"], rtol=1e-5)
+    np.testing.assert_allclose(la, lb, rtol=2e-6)
+    assert float((ea.cur.probs - eb.cur.probs).abs().max()) < 2e-6
+    for i, ((dw, db), (vw, vb), (rw, rb)) in enumerate(zip(ga, gb, ref["grads"])):
+        assert rel_l2(dw, rw) < 2e-4 and rel_l2(db, rb) < 2e-4, (i, rel_l2(dw, rw))
+        assert rel_l2(dw, vw) < 2e-4, (i, rel_l2(dw, vw))
+    for i in range(len(ea.plans) - 1):
+        ya, _ = layer_activation(ea, ea.cur, i)
+        yb, _ = layer_activation(eb, eb.cur, i)
+        assert np.abs(ya - yb).max() <= 2e-5 * max(np.abs(yb).max(), 1e-30), i
+    # layout invariants of the MFMA kernels' masked stores: halo rows, rows beyond T' and padded channels stay zero
+    for tensors in (ea.cur.y, ea.cur.g[:-1]):
+        for i, t in enumerate(tensors):
+            raw = t.cpu().numpy()
+            c = ea.specs[i].cout
+            assert not raw[:, :HALO].any() and not raw[:, HALO + ea.cur.t_out:].any() and not raw[:, :, c:].any(), i
+
+
+def test_config2_greedy_decode_bit_exact_at_batch_32():
+    """BASELINE config 2 at its stated size on the path bench.py --config 2 reports: random-init Wav2Letter forward on
+    32 x 128-mel x 1000 frames, fp32 storage, exact-fp32 MFMA contraction; greedy-decoded label indices (and every
+    frame's argmax) bit-exact against the torch-CPU fp32 path.  The bf16 path's disagreements are counted, not hidden."""
+    import torch
+    from oracle import w2l_torch_cpu as tc
+    case = make_case(b=32, t=1000, seed=2)
+    pred_len = [500] * 32
+    with torch.no_grad():
+        ref_probs = tc.forward_probs(case["ospecs"], tc.to_torch_weights(case["weights"], requires_grad=False),
+                                     torch.from_numpy(case["x"])).numpy()
+    want = o.greedy_decode_indices(ref_probs, pred_len)
+    argmax, margin = o.frame_argmax_and_margin(ref_probs)
+    _report("config2_b32_min_top1_top2_margin", float(margin.min()))
+    eng = make_engine(case, "f32")
+    probs = eng.forward(case["x"]).cpu().numpy()
+    decoded, frame_argmax = eng.greedy_decode(pred_len)
+    assert np.abs(probs - ref_probs).max() < 2e-5
+    assert np.array_equal(frame_argmax, argmax)
+    assert decoded == want
+    eng16 = make_engine(case, "bf16")
+    eng16.forward(case["x"])
+    decoded16, frame_argmax16 = eng16.greedy_decode(pred_len)
+    _report("config2_b32_bf16_mismatching_frames_of_16000", int((frame_argmax16 != argmax).sum()))
+    _report("config2_b32_bf16_mismatching_sequences_of_32", int(sum(a != b for a, b in zip(decoded16, want))))
+    assert (frame_argmax16 != argmax).mean() < 5e-2  # measured 1.7 % of the frames: the softmax is nearly flat
