@@ -242,6 +242,63 @@ def main():
                             "the headline value above is the fp32 path, whose decoded indices are "
                             "(tests/test_gpu_round2.py::test_config2_greedy_decode_bit_exact_at_batch_32)"}
 
+    # ---- data-parallel diagnostics (N > 1): everything needed to read the first multi-GPU run from its one JSON line
+    dp = None
+    if reducer is not None:
+        def timed(n):
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step()
+            sync()
+            dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            return float(dt.item()) / n * 1e3
+        # one more step, then: are the reduced gradients and the updated weights bit-identical on every rank?
+        step()
+        torch.cuda.synchronize()
+        sums = torch.stack([eng.grads.double().sum(), eng.grads.view(torch.int32).long().sum().double(),
+                            eng.params.double().sum(), eng.params.view(torch.int32).long().sum().double()])
+        gathered = [torch.zeros_like(sums) for _ in range(world)]
+        dist.all_gather(gathered, sums)
+        same = all(bool(torch.equal(g, gathered[0])) for g in gathered)
+        # the exchange alone: both buckets back to back on the communication stream, nothing else running
+        ranges, _ = eng.bucket_ranges()
+        bucket_bytes = [int((hi - lo) * 4) for lo, hi in ranges]
+        scratch = torch.zeros_like(eng.grads)
+        for _ in range(3):
+            for lo, hi in ranges:
+                dist.all_reduce(scratch[lo:hi])
+        sync()
+        t1 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            for lo, hi in ranges:
+                dist.all_reduce(scratch[lo:hi])
+        sync()
+        ar_ms = (time.perf_counter() - t1) / reps * 1e3
+        del scratch
+        alg = sum(bucket_bytes) / (ar_ms * 1e-3) / 1e9
+        with_comm_ms = timed(args.steps)
+        reducer.skip_collective = True  # same choreography, no bytes on the wire (timing only: weights now differ per rank)
+        without_comm_ms = timed(args.steps)
+        reducer.skip_collective = False
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # gloo test hook / CPU build
+            rccl = None
+        dp = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
+              "bucket_bytes": bucket_bytes,
+              "reduced_gradients_and_weights_identical_on_all_ranks": same,
+              "gradient_checksum": float(gathered[0][0].item()), "weight_checksum": float(gathered[0][2].item()),
+              "allreduce_alone_ms": ar_ms, "allreduce_algbw_GBps": alg,
+              "allreduce_busbw_GBps": alg * 2 * (world - 1) / world,
+              "step_ms_with_allreduce": with_comm_ms, "step_ms_without_allreduce": without_comm_ms,
+              "exposed_communication_ms": with_comm_ms - without_comm_ms,
+              "note": "exposed communication = step time with the bucketed all-reduce minus the same step with the "
+                      "collective left out (streams and events unchanged); allreduce_alone = both buckets back to "
+                      "back with nothing else on the GPU; busbw = algbw * 2(n-1)/n"}
+
     # ---- roofline leg: a few more steps with HIP events around every launch (same stream as the kernels)
     def timeline_pass():
         eng.timeline = []
@@ -353,6 +410,8 @@ def main():
     }
     if bf16_leg is not None:
         result["bf16_path"] = bf16_leg
+    if dp is not None:
+        result["data_parallel"] = dp
     if h2d is not None:
         step_ms = elapsed / args.steps * 1e3
         h2d["utterances_per_sec_including_h2d_serial"] = batch_per_gpu / ((step_ms + h2d["h2d_ms_per_step"]) * 1e-3)

@@ -17,9 +17,16 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, flat_grads, ranges, process_group=None, overlap=True, force=False):
+    def __init__(self, flat_grads, ranges, process_group=None, overlap=True, force=False, compress=None):
         """force: issue the collectives even in a world of one rank (tests exercise the stream / event choreography and
-        the RCCL call on a single GPU that way)."""
+        the RCCL call on a single GPU that way).
+        compress: None (fp32 on the wire: the reduced gradient is the exact sum, identical on every rank) or "bf16"
+        (each rank's bucket is rounded to bf16, summed in bf16 by the collective and widened again: half the bytes per
+        link, ~3 significant digits per gradient element -- an option for link-bound scaling, off by default; the
+        result is still identical on every rank)."""
+        if compress not in (None, "bf16"):
+            raise ValueError("compress must be None or 'bf16'")
+        self.compress = compress
         self.force = force
         self.flat = flat_grads
         self.ranges = list(ranges)
@@ -29,6 +36,9 @@ class GradBucketReducer:
         self.overlap = overlap and self.cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if self.overlap else None
         self._pending = []
+        # measurement only (bench.py's exposed-communication figure): keep the stream / event choreography of a step
+        # but leave the collective itself out
+        self.skip_collective = False
 
     def reduce_bucket(self, index):
         """Called when every kernel writing bucket `index` has been enqueued on the current stream."""
@@ -41,13 +51,25 @@ class GradBucketReducer:
             ready.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                if not self.skip_collective:
+                    self._all_reduce(view)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
             self._pending.append(done)
+        elif not self.skip_collective:
+            if self.compress:
+                self._all_reduce(view)
+            else:
+                work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending.append(work)
+
+    def _all_reduce(self, view):
+        if self.compress == "bf16":
+            wire = view.to(torch.bfloat16)
+            dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(wire)
         else:
-            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append(work)
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
 
     def run_after_reduce(self, fn):
         """Enqueues fn(raw_stream) on the communication stream, i.e. behind every all-reduce issued so far, after the
