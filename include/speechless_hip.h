@@ -232,6 +232,29 @@ int sl_adam_pack_layer(float* param, const float* grad, float* m, float* v, void
                        int cin_pad, int cout_pad, int dtype, int step, float lr, float beta1, float beta2, float eps,
                        void* stream);
 
+/* ---- audio front end (speechless/labeled_example.py:99-160, 28-29) ---------------------------
+ * sl_stft_power_db: librosa.stft(y, n_fft, hop_length) with its defaults (periodic Hann window of n_fft samples,
+ * center=True with reflect padding of n_fft/2, 1 + len/hop frames, 1 + n_fft/2 bins; labeled_example.py:99-100), then
+ * |D|^2 (:93-97) and the power level 10 log10(.) with `min_db` for zero power and as the floor (:150-158), in one pass.
+ *   audio   : float, all utterances back to back; utterance b starts at audio + offsets[b] and has lengths[b] samples
+ *             (lengths[b] > n_fft / 2: reflect padding)
+ *   out     : float[B][max_frames][row_stride] at batch_stride; row t of utterance b holds its 1 + n_fft/2 levels followed
+ *             by zeros up to row_stride; rows t >= 1 + lengths[b] / hop are zero.  Time-major, so that the mel projection
+ *             (labeled_example.py:106-109: a matrix applied to the LEVEL spectrogram) is a 1 x 1 sl_conv1d_nt over it.
+ * n_fft: power of two in [64, 1024].
+ */
+int sl_stft_power_db(const float* audio, const int64_t* offsets, const int32_t* lengths, float* out, int batch,
+                     int max_frames, int n_fft, int hop, int row_stride, int64_t batch_stride, float min_db,
+                     void* stream);
+
+/* z_normalize (labeled_example.py:28-29, 136-140): per utterance (a - mean(a)) / std(a) over its frames[b] x f values
+ * (population standard deviation, float64 statistics like numpy), written densely as float[B][max_frames][f]; rows
+ * t >= frames[b] are zero -- exactly the zero-padded input batch of net.py:578-587, ready for sl_pack_input.
+ * workspace: sl_z_normalize_workspace_bytes(batch) bytes. */
+size_t sl_z_normalize_workspace_bytes(int batch);
+int sl_z_normalize(const float* src, const int32_t* frames, float* dst, int batch, int max_frames, int f,
+                   int src_row_stride, int64_t src_batch_stride, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,11 @@ SIGNATURES = {
                              c_float, c_void_p]),
     "sl_adam_pack_layer": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_float, c_float, c_float, c_float, c_void_p]),
+    "sl_stft_power_db": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64,
+                                 c_float, c_void_p]),
+    "sl_z_normalize_workspace_bytes": (c_size_t, [c_int]),
+    "sl_z_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t,
+                               c_void_p]),
     "sl_adam_pack_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AdamLayer), c_int, c_int, c_int,
                                     c_float, c_float, c_float, c_float, c_void_p]),
 }

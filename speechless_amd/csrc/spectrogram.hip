@@ -1,0 +1,179 @@
+// spectrogram.hip -- audio -> power-level spectrogram and z-normalisation on the GPU.
+//
+// Replaces the librosa / numpy front end of the reference (speechless/labeled_example.py:99-100 librosa.stft(n_fft 512,
+// hop 128), :93-97 |D|^2, :150-158 10 log10 with the -150 dB floor, :28-29 z_normalize).  The mel projection in between
+// (labeled_example.py:106-109: a (128 x 257) matrix applied to the dB matrix) is a 1 x 1 convolution and runs on the
+// exact-fp32 MFMA kernel of conv_f32.hip through sl_conv1d_nt; see speechless_amd/spectrogram.py.
+//
+// HBM-bound by nature (0.5 MB of samples in, 1.3 MB of dB values out per 1000 frames); the Fourier transform is a
+// radix-2 FFT in LDS, one wave per frame, several frames resident per CU.
+#include "common.h"
+
+namespace {
+
+constexpr int FFT_MAX = 1024;
+
+// One 64-lane work-group per (frame, utterance): reflect-padded, Hann-windowed frame -> in-place radix-2 decimation-in-
+// time FFT in LDS (input written in bit-reversed order) -> |X_k|^2 -> dB with floor -> row t of the output.
+__global__ __launch_bounds__(64) void stft_power_db_kernel(const float* __restrict__ audio,
+                                                          const long* __restrict__ offsets,
+                                                          const int* __restrict__ lengths, float* __restrict__ out,
+                                                          int n_fft, int log2n, int hop, int row_stride,
+                                                          long batch_stride, float min_db) {
+    __shared__ float re[FFT_MAX];
+    __shared__ float im[FFT_MAX];
+    __shared__ float twr[FFT_MAX / 2];
+    __shared__ float twi[FFT_MAX / 2];
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x;
+    const int b = blockIdx.y;
+    const int len = lengths[b];
+    const int n_frames = 1 + len / hop;
+    const int bins = n_fft / 2 + 1;
+    float* row = out + (long)b * batch_stride + (long)t * row_stride;
+    if (t >= n_frames) {  // frames beyond this utterance: zero rows (the batch is padded with zeros, net.py:583)
+        for (int k = lane; k < row_stride; k += 64) row[k] = 0.f;
+        return;
+    }
+    const float* y = audio + offsets[b];
+    const int half = n_fft / 2;
+    for (int n = lane; n < n_fft; n += 64) {
+        int idx = t * hop + n - half;          // center=True: the frame is centred on sample t * hop
+        if (idx < 0) idx = -idx;               // np.pad(mode="reflect"): edge sample not repeated
+        if (idx >= len) idx = 2 * (len - 1) - idx;
+        float s, c;
+        sincospif(2.f * (float)n / (float)n_fft, &s, &c);
+        const float w = 0.5f - 0.5f * c;       // periodic Hann window
+        const int r = (int)(__brev((unsigned)n) >> (32 - log2n));
+        re[r] = w * y[idx];
+        im[r] = 0.f;
+    }
+    for (int k = lane; k < half; k += 64) {
+        float s, c;
+        sincospif(-2.f * (float)k / (float)n_fft, &s, &c);
+        twr[k] = c;
+        twi[k] = s;
+    }
+    __syncthreads();
+    for (int s = 1; s <= log2n; ++s) {
+        const int m = 1 << s, mh = m >> 1, tstep = n_fft >> s;
+        for (int j = lane; j < half; j += 64) {
+            const int pos = j & (mh - 1);
+            const int i0 = ((j >> (s - 1)) << s) + pos;
+            const int i1 = i0 + mh;
+            const float wr = twr[pos * tstep], wi = twi[pos * tstep];
+            const float xr = re[i1], xi = im[i1];
+            const float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
+            const float ur = re[i0], ui = im[i0];
+            re[i0] = ur + tr;
+            im[i0] = ui + ti;
+            re[i1] = ur - tr;
+            im[i1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    for (int k = lane; k < row_stride; k += 64) {
+        float v = 0.f;
+        if (k < bins) {
+            const float p = re[k] * re[k] + im[k] * im[k];
+            v = p == 0.f ? min_db : fmaxf(10.f * log10f(p), min_db);
+        }
+        row[k] = v;  // padded lanes are zero: the mel projection contracts over the padded row
+    }
+}
+
+// z-normalisation statistics of one utterance: mean and population standard deviation over frames[b] x f values, two
+// passes, double accumulation (numpy computes them in float64).  One 1024-thread work-group per utterance.
+__global__ __launch_bounds__(1024) void znorm_stats_kernel(const float* __restrict__ src, const int* __restrict__ frames,
+                                                           double* __restrict__ stats, int f, int row_stride,
+                                                           long batch_stride) {
+    __shared__ double part[1024];
+    __shared__ double mean_s;
+    const int b = blockIdx.x;
+    const long n = (long)frames[b] * f;
+    const float* base = src + (long)b * batch_stride;
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)base[(i / f) * row_stride + (i % f)];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean_s = part[0] / (double)n;
+    __syncthreads();
+    const double mean = mean_s;
+    acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const double d = (double)base[(i / f) * row_stride + (i % f)] - mean;
+        acc += d * d;
+    }
+    __syncthreads();
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[2 * b] = mean;
+        stats[2 * b + 1] = sqrt(part[0] / (double)n);
+    }
+}
+
+// dst[b][t][c] = (src - mean_b) / std_b for t < frames[b], 0 beyond (the zero padding of the batch, net.py:583-586)
+__global__ __launch_bounds__(256) void znorm_apply_kernel(const float* __restrict__ src, const int* __restrict__ frames,
+                                                          const double* __restrict__ stats, float* __restrict__ dst,
+                                                          int max_frames, int f, int row_stride, long batch_stride) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)max_frames * f) return;
+    const int t = (int)(i / f), c = (int)(i % f);
+    float v = 0.f;
+    if (t < frames[b]) {
+        const double mean = stats[2 * b], sd = stats[2 * b + 1];
+        v = (float)(((double)src[(long)b * batch_stride + (long)t * row_stride + c] - mean) / sd);
+    }
+    dst[((long)b * max_frames + t) * f + c] = v;
+}
+
+}  // namespace
+
+extern "C" int sl_stft_power_db(const float* audio, const int64_t* offsets, const int32_t* lengths, float* out, int batch,
+                                int max_frames, int n_fft, int hop, int row_stride, int64_t batch_stride, float min_db,
+                                void* stream) {
+    SL_CHECK_ARG(audio && offsets && lengths && out, "sl_stft_power_db: null pointer");
+    SL_CHECK_ARG(batch > 0 && max_frames > 0 && hop > 0, "sl_stft_power_db: batch, max_frames and hop must be positive");
+    int log2n = 0;
+    while ((1 << log2n) < n_fft) ++log2n;
+    SL_CHECK_ARG((1 << log2n) == n_fft && n_fft >= 64 && n_fft <= FFT_MAX,
+                 "sl_stft_power_db: n_fft = %d must be a power of two in [64, %d]", n_fft, FFT_MAX);
+    SL_CHECK_ARG(row_stride >= n_fft / 2 + 1 && batch_stride >= (int64_t)max_frames * row_stride,
+                 "sl_stft_power_db: output rows are too short for %d bins", n_fft / 2 + 1);
+    hipLaunchKernelGGL(stft_power_db_kernel, dim3(max_frames, batch), dim3(64), 0, (hipStream_t)stream, audio,
+                       (const long*)offsets, lengths, out, n_fft, log2n, hop, row_stride, (long)batch_stride, min_db);
+    return sl_check_launch("sl_stft_power_db");
+}
+
+extern "C" size_t sl_z_normalize_workspace_bytes(int batch) { return batch > 0 ? (size_t)batch * 2 * sizeof(double) : 0; }
+
+extern "C" int sl_z_normalize(const float* src, const int32_t* frames, float* dst, int batch, int max_frames, int f,
+                              int src_row_stride, int64_t src_batch_stride, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    SL_CHECK_ARG(src && frames && dst, "sl_z_normalize: null pointer");
+    SL_CHECK_ARG(batch > 0 && max_frames > 0 && f > 0 && src_row_stride >= f, "sl_z_normalize: bad shape");
+    if (workspace == nullptr || workspace_bytes < sl_z_normalize_workspace_bytes(batch)) {
+        sl_set_error("sl_z_normalize: workspace too small (%zu < %zu)", workspace_bytes,
+                     sl_z_normalize_workspace_bytes(batch));
+        return SL_ERR_WORKSPACE_TOO_SMALL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(znorm_stats_kernel, dim3(batch), dim3(1024), 0, s, src, frames, (double*)workspace, f,
+                       src_row_stride, (long)src_batch_stride);
+    int rc = sl_check_launch("sl_z_normalize(stats)");
+    if (rc != SL_OK) return rc;
+    const long n = (long)max_frames * f;
+    hipLaunchKernelGGL(znorm_apply_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, s, src, frames,
+                       (const double*)workspace, dst, max_frames, f, src_row_stride, (long)src_batch_stride);
+    return sl_check_launch("sl_z_normalize(apply)");
+}

@@ -424,6 +424,20 @@ class Wav2Letter:
         decoded, _ = self.engine.greedy_decode(prediction_lengths)
         return [self.grapheme_encoding.decode_graphemes(d, merge_repeated=False) for d in decoded]
 
+    def predict_batch_greedily_from_audio(self, raw_audio_batch, sample_rate=16000, fourier_window_length=512,
+                                          hop_length=128):
+        """Extension: predict_batch_greedily for raw audio (1-D float arrays).  STFT, power level, mel projection and
+        z-normalisation (labeled_example.py:99-160, 28-29) run on the GPU (speechless_amd/spectrogram.py) and their result
+        feeds the conv stack directly in HBM -- no spectrogram crosses PCIe."""
+        from .spectrogram import shared_extractor
+        bins = 1 + fourier_window_length // 2
+        mel = None if self.input_size_per_time_step == bins else self.input_size_per_time_step
+        extractor = shared_extractor(sample_rate, fourier_window_length, hop_length, mel, self.device)
+        x, frames = extractor.batch(raw_audio_batch)
+        self.engine.forward(x)
+        decoded, _ = self.engine.greedy_decode([n // self.input_to_prediction_length_ratio for n in frames])
+        return [self.grapheme_encoding.decode_graphemes(d, merge_repeated=False) for d in decoded]
+
     def test_and_predict_batch(self, labeled_spectrogram_batch):
         """ONE forward pass yields both the greedy transcription and the per-utterance CTC loss."""
         inputs = self._input_dictionary_for_loss_net(labeled_spectrogram_batch)
