@@ -9,7 +9,7 @@ PACKAGE_DIR = Path(__file__).resolve().parent
 CSRC = PACKAGE_DIR / "csrc"
 LIB_PATH = PACKAGE_DIR / "libspeechless_hip.so"
 HOST_LIB_PATH = PACKAGE_DIR / "libspeechless_host.so"  # plain C++ helpers of the host input pipeline (no HIP)
-HOST_SOURCES = [PACKAGE_DIR / "csrc_host" / "pack_batch.cpp"]
+HOST_SOURCES = [PACKAGE_DIR / "csrc_host" / "pack_batch.cpp", PACKAGE_DIR / "csrc_host" / "beam_search.cpp"]
 CXX = os.environ.get("CXX", "g++")
 SOURCES = ["capi.hip", "conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_f32.hip", "ctc.hip", "misc.hip", "spectrogram.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -247,8 +247,6 @@ class Wav2Letter:
             raise NotImplementedError("ASG is not yet implemented.")  # as reference net.py:396-399
         if use_raw_wave_input:
             raise NotImplementedError("raw-wave input (wave_conv, net.py:310-312) is outside the MI355X hot path")
-        if kenlm_directory is not None:
-            raise NotImplementedError("KenLM beam-search decoding (net.py:444-451) is outside the MI355X hot path")
         if dropout is not None and not 0.0 <= dropout < 1.0:
             raise ValueError("dropout must be a rate in [0, 1)")
         self.kenlm_directory = kenlm_directory
@@ -284,6 +282,15 @@ class Wav2Letter:
         if frozen_layer_count > 0:
             log("All but {} layers frozen.".format(len(specs) - frozen_layer_count))
         self.prediction_phase_flag = 0.
+        self._beam_decoder = None
+        if self.kenlm_directory is not None:  # net.py:171-177
+            from .decoder import CtcBeamSearchDecoder, expected_characters
+            expected = expected_characters(self.kenlm_directory)
+            if list(allowed_characters) != expected:
+                raise ValueError("Allowed characters {} differ from those expected by kenlm decoder: {}".format(
+                    allowed_characters, expected))
+            self._beam_decoder = CtcBeamSearchDecoder.from_kenlm_directory(self.kenlm_directory, allowed_characters,
+                                                                           epsilon=ctc_epsilon)
         if load_model_from_directory is not None:
             self.load_weights(allowed_characters_for_loaded_model, load_epoch, load_model_from_directory,
                               loaded_first_layers_count=frozen_layer_count if reinitialize_trainable_loaded_layers
@@ -446,7 +453,11 @@ class Wav2Letter:
         self.engine.set_labels(inputs[names.label_batch], inputs[names.label_lengths],
                                inputs[names.prediction_lengths])
         losses = self.engine.ctc().cpu().numpy()
-        decoded, _ = self.engine.greedy_decode()
+        if self._beam_decoder is not None:  # net.py:444-451: beam search scored by the language model
+            decoded, _ = self._beam_decoder.decode(self.engine.cur.probs.cpu().numpy(),
+                                                   inputs[names.prediction_lengths])
+        else:
+            decoded, _ = self.engine.greedy_decode()
         predictions = [self.grapheme_encoding.decode_graphemes(d, merge_repeated=False) for d in decoded]
         return ExpectationsVsPredictions(
             [ExpectationVsPrediction(predicted=p, expected=x.label, loss=float(l))
