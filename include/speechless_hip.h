@@ -177,13 +177,24 @@ int sl_output_softmax(const void* x, const void* w, const float* bias, float* pr
  * dlogits: gradient of  grad_scale * sum_b loss[b]  w.r.t. the PRE-softmax logits of output_conv, written into the
  *          halo'd tensor described by (g_row0, g_row_stride, g_batch_stride), dtype `dtype`; frames >=
  *          input_len[b] get zeros.  grad_scale = 1/B realises Keras' mean over the batch (net.py:389).
- * workspace: sl_ctc_workspace_bytes(...) bytes (alpha/beta lattices, fp32 log-space).
+ * workspace: sl_ctc_workspace_bytes(...) bytes (alpha/beta lattices).
+ * Two lattice kernels: the log-domain one (one thread per lattice state, LDS row exchange + barrier per frame), and for
+ * long utterances (t_out >= 1024) with labels of up to 255 graphemes a probability-domain one (doubles with an exponent
+ * per 16 frames, one wave per utterance and direction, no transcendental and no barrier on the T'-long sequential path);
+ * there the gradient kernel checks every frame's posteriors against 1 and an utterance that lost mass to underflow is
+ * redone by the log-domain kernels.  Results agree to fp32 round-off either way.
  */
 size_t sl_ctc_workspace_bytes(int batch, int t_out, int l_max);
 int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* labels, const int32_t* label_len,
                      const int32_t* input_len, float* loss, void* dlogits, int batch, int t_out, int k, int l_max,
                      int g_row0, int g_row_stride, int64_t g_batch_stride, int dtype, float eps, float grad_scale,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement / test hook: which lattice sl_ctc_loss_grad runs.  0 (default) = as described above, 1 = log-domain lattice
+ * only, 2 = probability-domain lattice without the repair launches, 3 = probability-domain lattice and then EVERY
+ * utterance redone by the repair pass, 4 = probability-domain lattice + repair whenever the labels fit, whatever the
+ * length.  Process-wide; not for concurrent use with sl_ctc_loss_grad. */
+int sl_ctc_select(int variant);
 
 /* ---- greedy decode (net.py:452-454 tf.nn.ctc_greedy_decoder, merge_repeated=True; numpy twin
  *      grapheme_enconding.py:34-57): per-frame argmax (first max wins) for t < input_len, merge repeats, drop blank.

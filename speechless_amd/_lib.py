@@ -9,7 +9,10 @@ from pathlib import Path
 # Loading ours first would pull /opt/rocm's runtime in and torch would then find "no ROCm-capable device".
 import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
 
-LIB_PATH = Path(__file__).resolve().parent / "libspeechless_hip.so"
+import os
+
+# SL_LIB_PATH: experiments only (a probe build of the library next to the real one)
+LIB_PATH = Path(os.environ.get("SL_LIB_PATH") or Path(__file__).resolve().parent / "libspeechless_hip.so")
 
 SL_BF16 = 0
 SL_F32 = 1
@@ -71,6 +74,7 @@ SIGNATURES = {
     "sl_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "sl_softmax_logq": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float,
                                 c_void_p]),
+    "sl_ctc_select": (c_int, [c_int]),
     "sl_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sl_ctc_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_float, c_void_p, c_size_t,

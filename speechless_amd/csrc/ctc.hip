@@ -78,10 +78,12 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
                                                            const int32_t* __restrict__ input_len,
                                                            float* __restrict__ alpha, float* __restrict__ beta,
                                                            float* __restrict__ loss, int32_t* __restrict__ cls,
-                                                           int t_out, int k, int l_max, int sp, int blank) {
+                                                           int t_out, int k, int l_max, int sp, int blank,
+                                                           const int32_t* __restrict__ only_flagged) {
     extern __shared__ float rowbuf[];  // 2 x (blockDim + 4)   (list builder: l_max + k + 1 ints)
     const int b = blockIdx.x;
     const int dir = blockIdx.y;
+    if (only_flagged != nullptr && only_flagged[b] == 0) return;  // repair pass of the wave lattice: nothing to redo
     const int s = threadIdx.x;
     const int L = label_len[b];
     if (dir == 2) {
@@ -215,18 +217,34 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
     }
 }
 
+// log2 of a non-negative double, as float (the gradient kernel's lattice units); 0 -> -inf
+__device__ __forceinline__ float log2_of_double(double x) {
+    if (x == 0.0) return -INFINITY;
+    int e;
+    const double m = frexp(x, &e);
+    return (float)e + __builtin_amdgcn_logf((float)m);
+}
+
 // one wave per frame; work-group = 4 waves x FRAMES_PER_WAVE frames.  NJ = SP / 64 lattice columns per lane: all of a
 // frame's alpha / beta loads are issued before the first one is used (one HBM/L2 round trip per frame instead of NJ).
-template <int NJ>
+// LIN: the lattice comes from ctc_lattice_wave_kernel (doubles in linear units with one exponent per frame, emissions
+// u = p + eps instead of q) and is brought to log2 units on the fly; the sum of a frame's state posteriors must then be
+// 1 -- if the linear lattice lost mass to underflow it is not, and the utterance is flagged for the log-domain repair
+// pass.  only_flagged: this launch IS the repair pass (log-domain lattice): utterances that are not flagged are skipped.
+template <int NJ, bool LIN>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ probs, const float* __restrict__ logq,
                                                        const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ label_len,
                                                        const int32_t* __restrict__ input_len,
-                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                       const float* __restrict__ loss, const int32_t* __restrict__ cls,
-                                                       void* __restrict__ dlogits, int t_out, int k, int l_max, int sp,
-                                                       int blank, int frames_per_wg, int g_row0, int g_rs, long g_bs,
-                                                       int out_f32, float eps, float grad_scale) {
+                                                       const void* __restrict__ alpha_v, const void* __restrict__ beta_v,
+                                                       const int32_t* __restrict__ ea, const int32_t* __restrict__ eb,
+                                                       const float* __restrict__ logz2, const int32_t* __restrict__ zint,
+                                                       float* __restrict__ loss,
+                                                       const int32_t* __restrict__ cls, void* __restrict__ dlogits,
+                                                       int t_out, int k, int l_max, int sp, int blank, int frames_per_wg,
+                                                       int g_row0, int g_rs, long g_bs, int out_f32, float eps,
+                                                       float grad_scale, int32_t* __restrict__ flags,
+                                                       const int32_t* __restrict__ only_flagged) {
     // LDS: labels[l_max] | class_pos[l_max] | class_start[k+1] | lq[4][64] | gamma[4][l_max]
     extern __shared__ int lds_i[];
     int* s_lab = lds_i;
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     float* s_lq = (float*)(s_start + (k + 1));
     float* s_gam = s_lq + 4 * 64;
     const int b = blockIdx.y;
+    if (only_flagged != nullptr && only_flagged[b] == 0) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -251,9 +270,11 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     if (tid <= k) s_start[tid] = cpos[l_max + tid];
     __syncthreads();
 
+    // LIN: log2 of the partition sum in u units = zint[b] + logz2[b], integer part and fraction kept apart
+    // (loss[b] = -ln Z_u - sum_t ln c_t was written by the lattice wave)
     const float nll = loss[b];
     const bool feasible = nll < INFINITY;
-    const float log_p = -nll * LOG2E;  // lattice units are log2
+    const float log_p = LIN ? logz2[b] : -nll * LOG2E;  // lattice units are log2
     float* gam = s_gam + wave * l_max;
     float* wlq = s_lq + wave * 64;
     const int t_begin = blockIdx.x * frames_per_wg;
@@ -267,38 +288,80 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
             const float pk = lane < k ? probs[fidx * k + lane] : 0.f;
             float occ = 0.f;
             if (feasible) {
-                const float* al = alpha + fidx * sp;
-                const float* be = beta + fidx * sp;
-                float av[NJ], bv[NJ];
+                float av[NJ], bv[NJ];  // LIN: av = fractional part (log2 of the two mantissas), bv unused, ai = integer part
+                int ai[NJ];
+                if (LIN) {
+                    const double* al = (const double*)alpha_v + fidx * sp;
+                    const double* be = (const double*)beta_v + fidx * sp;
+                    double ad[NJ], bd[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {  // rows are sp (a multiple of 64) wide: a wave-uniform bound
-                    const bool in = 64 * j < sp;
-                    av[j] = in ? al[lane + 64 * j] : -INFINITY;
-                    bv[j] = in ? be[lane + 64 * j] : -INFINITY;
+                    for (int j = 0; j < NJ; ++j) {  // only the live part of the row was written: s < S rounded up to 8
+                        const bool in = lane + 64 * j < ((S + 7) & ~7);
+                        ad[j] = in ? al[lane + 64 * j] : 0.0;
+                        bd[j] = in ? be[lane + 64 * j] : 0.0;
+                    }
+                    // exponents: one per block of 16 steps of the respective direction (alpha: step = t, beta: T-1-t)
+                    // Exponents add up to tens of thousands over a long utterance while the posterior needs the FRACTION of
+                    // the log2 to 1e-3: integer parts (block exponents, frexp exponents, the integer part of log2 Z) are
+                    // summed exactly, only the mantissa logarithms go through fp32.
+                    // (one exponent per lattice lane = 8 states and block of 16 steps of the respective direction)
+                    const int32_t* eap = ea + ((long)b * (t_out / 16 + 1) + (t >> 4)) * 64;
+                    const int32_t* ebp = eb + ((long)b * (t_out / 16 + 1) + ((T - 1 - t) >> 4)) * 64;
+                    const int zi = zint[b];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int wl = (lane + 64 * j) >> 3;
+                        const int eab = eap[wl] + ebp[wl] - zi;
+                        // a state the other direction cannot reach has posterior 0 whatever this direction holds
+                        const bool dead = ad[j] == 0.0 || bd[j] == 0.0;
+                        int xa, xb;
+                        const double ma = frexp(dead ? 1.0 : ad[j], &xa), mb = frexp(dead ? 1.0 : bd[j], &xb);
+                        av[j] = dead ? -INFINITY : __builtin_amdgcn_logf((float)ma) + __builtin_amdgcn_logf((float)mb);
+                        ai[j] = eab + xa + xb;
+                        bv[j] = 0.f;
+                    }
+                } else {
+                    const float* al = (const float*)alpha_v + fidx * sp;
+                    const float* be = (const float*)beta_v + fidx * sp;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {  // rows are sp (a multiple of 64) wide: a wave-uniform bound
+                        const bool in = 64 * j < sp;
+                        av[j] = in ? al[lane + 64 * j] : -INFINITY;
+                        bv[j] = in ? be[lane + 64 * j] : -INFINITY;
+                        ai[j] = 0;
+                    }
                 }
-                wlq[lane] = lqv * LOG2E;
+                // emission in lattice units: log2 q (log-domain lattice) or log2 (p + eps) (linear lattice)
+                wlq[lane] = LIN ? __builtin_amdgcn_logf(pk + eps) : lqv * LOG2E;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const float lq_blank = wlq[blank];
                 // blank states (even s) -> butterfly sum; grapheme states (odd s) -> gamma[] in LDS
-                float blank_part = 0.f;
+                float blank_part = 0.f, label_part = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int s = lane + 64 * j;
                     if (s < S) {
                         const float ab = av[j] + bv[j];
+                        const float add = LIN ? (float)ai[j] : 0.f;  // (LIN: log_p is the fraction of log2 Z only)
                         if (s & 1) {
                             const int pos = s >> 1;
-                            const float lg = ab - wlq[s_lab[pos]] - log_p;
-                            gam[pos] = (ab == -INFINITY) ? 0.f : exp2f(lg);
+                            const float lg = (ab - wlq[s_lab[pos]] - log_p) + add;
+                            const float gv = (ab == -INFINITY) ? 0.f : exp2f(lg);
+                            gam[pos] = gv;
+                            label_part += gv;
                         } else {
-                            const float lg = ab - lq_blank - log_p;
+                            const float lg = (ab - lq_blank - log_p) + add;
                             blank_part += (ab == -INFINITY) ? 0.f : exp2f(lg);
                         }
                     }
                 }
                 blank_part = wave_sum(blank_part);
+                if (LIN && flags != nullptr) {
+                    const float total = blank_part + wave_sum(label_part);
+                    if (lane == 0 && !(fabsf(total - 1.f) < 4e-3f)) atomicOr(&flags[b], 1);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -326,6 +389,375 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
             else
                 ((unsigned short*)dlogits)[gi] = f32_to_bf16_bits(dz);
         }
+    }
+}
+
+// ---- linear-domain lattice: ONE WAVE per (utterance, direction), eight extended-label states per lane ----------------------
+// The log-domain kernel above pays, on every one of the T' sequential frames, three v_exp + one v_log, an LDS round trip
+// and a 7-wave barrier (0.23 us per frame).  In the probability domain a frame is two additions and one multiplication
+// per state; with the whole row of S <= 512 states in ONE wave (lane l owns states 8l .. 8l+7: even j blanks, odd j
+// label position 4l + j/2) the only cross-lane traffic is one value (alpha: state 8l-1; beta: 8l+8 and 8l+9) through a
+// DPP wave shift -- no LDS, no barrier.  Range: doubles, the emissions are u = p + eps (the per-frame constant
+// 1 / sum_j (p_j + eps) that turns u into TF's q is common to a row and goes into the loss as sum_t ln c_t), and every
+// 16 frames the row is rescaled by a power of two so that the largest RELEVANT state (alpha: one that can still reach
+// the end; beta: one the start can reach) sits at 2^TARGET, the exponent travelling per frame; irrelevant states are
+// zeroed at the same time (they never feed relevant ones).  A state more than ~2^1500 below the relevant maximum
+// underflows; whether that lost anything is checked by the gradient kernel (sum of a frame's posteriors = 1), and a
+// flagged utterance is redone by the log-domain kernels (repair pass, normally two empty launches).
+constexpr int WNS = 8;         // states per lane
+constexpr int WTARGET = 500;   // exponent the relevant maximum is rescaled to
+constexpr int WRESCALE = 16;   // frames between rescales (two prefetch chunks)
+
+__device__ __forceinline__ double dpp_from_lower_lane(double v) {  // lane l <- lane l-1, lane 0 <- 0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_upper_lane(double v) {  // lane l <- lane l+1, lane 63 <- 0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int dpp_int_from_lower_lane(int v, int lane0_value) {
+    return __builtin_amdgcn_update_dpp(lane0_value, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_int_from_upper_lane(int v, int lane63_value) {
+    return __builtin_amdgcn_update_dpp(lane63_value, v, 0x130, 0xf, 0xf, false);
+}
+
+// The recursion of one direction (compile-time DIR: 0 = alpha, forwards; 1 = beta, backwards).  Every store is
+// unconditional (dead lanes write their row slice to a dump row with stride 0, every lane writes the frame's exponent to
+// the same word): an exec-masked store between a prefetch load and its use would force s_waitcnt vmcnt(0) per frame.
+template <int DIR>
+__device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, const int32_t* __restrict__ lab,
+                                                 double* __restrict__ rows, double* __restrict__ dump,
+                                                 int32_t* __restrict__ eout, int lane, int L, int S, int T, int k,
+                                                 int blank, float eps, double* a, int* e_final) {
+    // label slots of this lane: position 4 * lane + i sits in state 8 * lane + 2 * i + 1
+    int col[4];
+    bool slot_live[4];
+    double sk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pos = 4 * lane + i;
+        slot_live[i] = pos < L;
+        const int me = slot_live[i] ? lab[pos] : blank;
+        col[i] = me;
+        bool skip;
+        if (DIR == 0)
+            skip = slot_live[i] && pos >= 1 && lab[pos - 1] != me;
+        else
+            skip = pos + 1 < L && lab[pos + 1] != me;
+        sk[i] = skip ? 1.0 : 0.0;
+    }
+    float livef[4], epsf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        livef[i] = slot_live[i] ? 1.f : 0.f;
+        epsf[i] = slot_live[i] ? eps : 0.f;
+    }
+    const int tstart = DIR == 0 ? 0 : T - 1;
+    const int tstep = DIR == 0 ? 1 : -1;
+    const bool lane_live = WNS * lane < S;
+    double* rowp = lane_live ? rows + (long)tstart * (64 * WNS) + WNS * lane : dump + WNS * lane;
+    const long row_inc = lane_live ? (long)tstep * (64 * WNS) : 0;
+
+    // Emissions: the raw probabilities of an 8-frame chunk are ONE contiguous span of 8 * k floats; it is fetched one
+    // chunk ahead with four coalesced loads per lane and handed out through LDS (a lone wave executes its LDS operations
+    // in order, so the read after the write needs no barrier).  Per-lane gathers straight from global memory would put
+    // ten vector-memory operations per frame behind the 6-bit vmcnt counter, whose 63 slots divided by the store round
+    // trip (~1.5 us) is what paced the first version of this kernel (0.235 us per frame).
+    __shared__ float emis[2][8 * 64];
+    auto fetch_chunk = [&](int base, float* e4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = lane + 64 * r;
+            const int jf = idx / k, c = idx - jf * k;
+            const int step = base + (jf < 8 ? jf : 7);
+            const int st = step < T ? step : T - 1;
+            e4[r] = pr[(long)(tstart + tstep * st) * k + c];
+        }
+    };
+    auto stage_chunk = [&](int buf, const float* e4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = lane + 64 * r;
+            const int jf = idx / k, c = idx - jf * k;
+            if (jf < 8) emis[buf][jf * 64 + c] = e4[r];
+        }
+    };
+    float e4[4];
+    fetch_chunk(0, e4);
+    stage_chunk(0, e4);
+#pragma unroll
+    for (int j = 0; j < WNS; ++j) a[j] = 0.0;
+    int E = 0;              // this lane's exponent: true value = stored value * 2^E
+    bool lane_zero = true;  // nothing has reached this lane's states yet
+
+    // Block floating point PER LANE: lane l's eight states share the exponent E (true value = stored * 2^E), brought
+    // back to 2^WTARGET every WRESCALE steps with no cross-lane reduction; the one value (beta: two) that crosses a lane
+    // boundary per frame is rescaled by the exponent difference on the way (frame()).  A single exponent per ROW is not
+    // enough: early in training the net says "blank" with p ~ 1 and every label with p ~ eps, so each label a state has
+    // consumed costs 2^-26 and the states of one row span thousands of binades -- per lane (four labels) they span a
+    // few hundred at most.  Also zeroes the states that cannot matter any more (they never feed ones that do).
+    // The row in registers is that of step base - 1.  Branch-free.
+    auto rescale = [&](int base) {
+        const int tp = tstart + tstep * (base - 1);
+        const int lo_edge = DIR == 0 ? S - 2 * (T - tp) : 0;  // alpha: states below cannot reach the end any more
+        const int hi_edge = DIR == 0 ? S : 2 * tp + 1;        // beta: states above are unreachable from the start
+        // the exponent the block that ends here was stored under (a lane may have taken over its neighbour's exponent
+        // in the middle of the block; its rows before that are zeros, which any exponent describes)
+        eout[max(base / WRESCALE - 1, 0) * 64 + lane] = E;
+        double m = 0.0;
+#pragma unroll
+        for (int j = 0; j < WNS; ++j) {
+            const int st = WNS * lane + j;
+            a[j] = (st < lo_edge || st > hi_edge) ? 0.0 : a[j];
+            m = fmax(m, a[j]);
+        }
+        lane_zero = !(m > 0.0);
+        const int shift = lane_zero ? 0 : WTARGET - __builtin_amdgcn_frexp_exp(m);
+#pragma unroll
+        for (int j = 0; j < WNS; ++j) a[j] = ldexp(a[j], shift);
+        E -= shift;
+    };
+    // one frame: emissions from LDS, three phases of mutually independent operations (a lone wave hides no latency by
+    // itself: the eight two-term sums, the four skip terms, the eight products; the empty asm statements pin the phase
+    // order), store of the row.
+    auto frame = [&](bool first, const float* erow) {
+#if defined(SL_PROBE_CTC_NOEMIS)  // timing probe (wrong results): no emission reads
+        const double ub = 0.03;
+        double uq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uq[i] = 0.03 * livef[i];
+#else
+        const double ub = (double)(erow[blank] + eps);
+        double uq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uq[i] = (double)fmaf(erow[col[i]], livef[i], epsf[i]);  // dead label slots: 0
+#endif
+        double n[WNS];
+        if (DIR == 0) {
+            // state 8l - 1 (a label state) of the lane below, brought to this lane's exponent; a lane that holds nothing
+            // yet takes over its neighbour's exponent when the first mass arrives
+            const double below_raw = dpp_from_lower_lane(a[7]);
+            const int e_below = dpp_int_from_lower_lane(E, E);
+            const bool adopt = lane_zero && below_raw != 0.0;
+            E = adopt ? e_below : E;
+            lane_zero = lane_zero && !adopt;
+            const double below = ldexp(below_raw, min(e_below - E, 400));
+            n[0] = a[0] + below;
+#pragma unroll
+            for (int i = 1; i < WNS; ++i) n[i] = a[i] + a[i - 1];
+            asm volatile("" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]));
+            n[1] = fma(sk[0], below, n[1]);
+            n[3] = fma(sk[1], a[1], n[3]);
+            n[5] = fma(sk[2], a[3], n[5]);
+            n[7] = fma(sk[3], a[5], n[7]);
+        } else {
+            const double up0_raw = dpp_from_upper_lane(a[0]);  // state 8l + 8 (blank)
+            const double up1_raw = dpp_from_upper_lane(a[1]);  // state 8l + 9 (label)
+            const int e_up = dpp_int_from_upper_lane(E, E);
+            const bool adopt = lane_zero && (up0_raw != 0.0 || up1_raw != 0.0);
+            E = adopt ? e_up : E;
+            lane_zero = lane_zero && !adopt;
+            const int de = min(e_up - E, 400);
+            const double up0 = ldexp(up0_raw, de), up1 = ldexp(up1_raw, de);
+            n[7] = a[7] + up0;
+#pragma unroll
+            for (int i = 0; i < WNS - 1; ++i) n[i] = a[i] + a[i + 1];
+            asm volatile("" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]));
+            n[7] = fma(sk[3], up1, n[7]);
+            n[5] = fma(sk[2], a[7], n[5]);
+            n[3] = fma(sk[1], a[5], n[3]);
+            n[1] = fma(sk[0], a[3], n[1]);
+        }
+        asm volatile("" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            n[2 * i] *= ub;
+            n[2 * i + 1] *= uq[i];
+        }
+        if (first) {  // step 0: the recursion above ran on zeros; only the entry states are set
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bool blank_entry, label_entry;
+                if (DIR == 0) {
+                    blank_entry = lane == 0 && i == 0;                       // state 0
+                    label_entry = lane == 0 && i == 0;                       // state 1 (u = 0 for an empty label)
+                } else {
+                    blank_entry = WNS * lane + 2 * i == S - 1;               // state S - 1
+                    label_entry = L > 0 && WNS * lane + 2 * i + 1 == S - 2;  // state S - 2
+                }
+                n[2 * i] = blank_entry ? ub : 0.0;
+                n[2 * i + 1] = label_entry ? uq[i] : 0.0;
+                lane_zero = lane_zero && !(blank_entry || label_entry);
+            }
+        }
+        // dead blank states (s >= S, even) only ever see zeros: their label neighbours have u = 0
+#pragma unroll
+        for (int i = 0; i < WNS; ++i) a[i] = n[i];
+#if !defined(SL_PROBE_CTC_NOSTORE)  // (timing probe: no lattice stores)
+#pragma unroll
+        for (int i = 0; i < WNS; i += 2) *(double2*)(rowp + i) = make_double2(a[i], a[i + 1]);
+#endif
+        rowp += row_inc;
+    };
+
+    // Full blocks of WRESCALE = 16 steps run as straight-line code: the waitcnt pass can then count the stores that are
+    // younger than a chunk's prefetch loads exactly (with a branch per frame it assumed none and waited for the stores'
+    // round trip once per chunk).
+    int base = 0;
+    if (T >= WRESCALE) {
+        rescale(0);
+        fetch_chunk(8, e4);
+        frame(true, &emis[0][0]);  // (peeled: the only frame with the entry-state special case)
+#pragma unroll
+        for (int j = 1; j < 8; ++j) frame(false, &emis[0][j * 64]);
+        stage_chunk(1, e4);
+        fetch_chunk(16, e4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) frame(false, &emis[1][j * 64]);
+        stage_chunk(0, e4);
+        base = WRESCALE;
+    }
+    for (; base + WRESCALE <= T; base += WRESCALE) {
+        rescale(base);
+        fetch_chunk(base + 8, e4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) frame(false, &emis[0][j * 64]);
+        stage_chunk(1, e4);
+        fetch_chunk(base + 16, e4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) frame(false, &emis[1][j * 64]);
+        stage_chunk(0, e4);
+    }
+    // tail: fewer than 16 steps left (the next chunk is already staged in buffer 0)
+    if (base < T) {
+        rescale(base);
+        fetch_chunk(base + 8, e4);
+        for (int j = 0; j < 8 && base + j < T; ++j) frame(base + j == 0, &emis[0][j * 64]);
+        stage_chunk(1, e4);
+        for (int j = 0; j < 8 && base + 8 + j < T; ++j) frame(false, &emis[1][j * 64]);
+    }
+    eout[((T - 1) / WRESCALE) * 64 + lane] = E;  // the last (possibly partial) block
+    *e_final = E;
+}
+
+// workspace: alpha, beta double[B][T][512] (+ one dump row per utterance and direction); ea, eb int32[B][T/16+1][64];
+// logz2 float[B]; cls as for the log-domain kernel
+__global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __restrict__ probs,
+                                                              const float* __restrict__ logq,
+                                                              const int32_t* __restrict__ labels,
+                                                              const int32_t* __restrict__ label_len,
+                                                              const int32_t* __restrict__ input_len,
+                                                              double* __restrict__ alpha, double* __restrict__ beta,
+                                                              double* __restrict__ dump, int32_t* __restrict__ ea,
+                                                              int32_t* __restrict__ eb, float* __restrict__ logz2,
+                                                              int32_t* __restrict__ zint, float* __restrict__ loss,
+                                                              int32_t* __restrict__ cls,
+                                                              int32_t* __restrict__ flags, int t_out, int k, int l_max,
+                                                              int blank, float eps) {
+    extern __shared__ int wl_lds[];  // list builder: l_max + k + 1 ints; alpha wave: 2 doubles
+    const int b = blockIdx.x;
+    const int dir = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int L = label_len[b];
+    if (dir == 2) {
+        // per-class position lists for the gradient kernel (same as in ctc_lattice_kernel, 64 threads)
+        int* s_lab = wl_lds;
+        int* s_start = s_lab + l_max;
+        int32_t* pos_out = cls + (long)b * (l_max + k + 1);
+        int32_t* start_out = pos_out + l_max;
+        for (int i = lane; i < L; i += 64) s_lab[i] = labels[(long)b * l_max + i];
+        for (int i = lane; i <= k; i += 64) s_start[i] = 0;
+        __syncthreads();
+        int ranks[8];  // l_max <= 255 -> at most 4 positions per thread
+        int nmine = 0;
+        for (int i = lane; i < L; i += 64) {
+            const int c = s_lab[i];
+            int r = 0;
+            for (int j = 0; j < i; ++j) r += (s_lab[j] == c);
+            ranks[nmine++] = r;
+            atomicAdd(&s_start[c + 1], 1);
+        }
+        __syncthreads();
+        if (lane == 0)
+            for (int c = 0; c < k; ++c) s_start[c + 1] += s_start[c];
+        __syncthreads();
+        nmine = 0;
+        for (int i = lane; i < L; i += 64) pos_out[s_start[s_lab[i]] + ranks[nmine++]] = i;
+        for (int i = lane; i <= k; i += 64) start_out[i] = s_start[i];
+        return;
+    }
+    const int S = 2 * L + 1;
+    int T = input_len[b];
+    if (T > t_out) T = t_out;
+    if (T <= 0) {
+        if (dir == 0 && lane == 0) {
+            loss[b] = INFINITY;
+            logz2[b] = 0.f;
+            zint[b] = 0;
+            flags[b] = 0;
+        }
+        return;
+    }
+    const int32_t* lab = labels + (long)b * l_max;
+    const float* pr = probs + (long)b * t_out * k;
+    double a[WNS];
+    int E;
+    if (dir == 0) {
+        // sum over the scored frames of ln c_t, c_t = 1 / sum_j (p_j + eps) = q_blank / (p_blank + eps): what separates
+        // the u lattice from TF's (q) one
+        float csum = 0.f;
+        for (int t = lane; t < T; t += 64)
+            csum += logq[((long)b * t_out + t) * k + blank] - logf(pr[(long)t * k + blank] + eps);
+        csum = wave_sum(csum);
+#if defined(SL_PROBE_CTC_CLOCK)
+        const long long probe_t0 = clock64();
+#endif
+        wave_lattice_run<0>(pr, lab, alpha + (long)b * t_out * (64 * WNS), dump + (long)(2 * b) * (64 * WNS),
+                            ea + (long)b * (t_out / WRESCALE + 1) * 64, lane, L, S, T, k, blank, eps, a, &E);
+        // Z_u = alpha_{T-1}(S-1) + alpha_{T-1}(S-2)
+        double* fin = (double*)wl_lds;
+        int* fin_e = (int*)(fin + 2);
+#pragma unroll
+        for (int i = 0; i < WNS; ++i) {
+            if (WNS * lane + i == S - 1) {
+                fin[0] = a[i];
+                fin_e[0] = E;
+            }
+            if (WNS * lane + i == S - 2) {
+                fin[1] = a[i];
+                fin_e[1] = E;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            // the two end states may sit in different lanes, i.e. under different exponents
+            const double z1 = fin[0], z2 = S >= 2 ? fin[1] : 0.0;
+            const int e1 = fin_e[0], e2 = S >= 2 ? fin_e[1] : e1;
+            const int ez = (z2 > 0.0 && (z1 == 0.0 || e2 > e1)) ? e2 : e1;
+            const double z = ldexp(z1, max(e1 - ez, -2000)) + ldexp(z2, max(e2 - ez, -2000));
+            int xz = 0;
+            const double mz = frexp(z > 0.0 ? z : 1.0, &xz);
+            const float frac = __builtin_amdgcn_logf((float)mz);  // log2 of the mantissa, in [-1, 0)
+            logz2[b] = frac;
+            zint[b] = xz + ez;
+            // -ln Z_u in double: the integer part is in the tens of thousands for a long utterance
+            loss[b] = z > 0.0 ? (float)(-((double)(xz + ez) + (double)frac) * 0.6931471805599453 - (double)csum) : INFINITY;
+            // no alignment at all, or every one of them underflowed: the log-domain repair pass tells which
+            flags[b] = z > 0.0 ? 0 : 1;
+#if defined(SL_PROBE_CTC_CLOCK)  // timing probe: s_memtime ticks per frame of the alpha recursion instead of the loss
+            loss[b] = (float)(clock64() - probe_t0) / (float)T;
+#endif
+        }
+    } else {
+        wave_lattice_run<1>(pr, lab, beta + (long)b * t_out * (64 * WNS), dump + (long)(2 * b + 1) * (64 * WNS),
+                            eb + (long)b * (t_out / WRESCALE + 1) * 64, lane, L, S, T, k, blank, eps, a, &E);
     }
 }
 
@@ -393,7 +825,51 @@ __global__ __launch_bounds__(256) void greedy_decode_kernel(const float* __restr
 
 __host__ int lattice_sp(int l_max) { return ((2 * l_max + 1) + 63) / 64 * 64; }
 
+// which lattice sl_ctc_loss_grad runs (sl_ctc_select): 0 = automatic -- the probability-domain wave lattice with the
+// log-domain repair pass for LONG utterances (t_out >= 1024 and 2 * l_max + 1 <= 512: measured 807 vs 915 us per call at
+// 8 x 4000 frames), the log-domain lattice otherwise (at 32 x 500 frames the two are level, 130 vs 132 us, and the wave
+// path pays two more launches); 1 = log-domain lattice only; 2 = wave lattice without the repair launches
+// (measurement); 3 = wave lattice, then every utterance redone by the repair pass (tests); 4 = wave lattice + repair
+// whenever the labels fit (tests)
+int g_ctc_variant = 0;
+constexpr int WAVE_MIN_FRAMES = 1024;
+
+struct CtcLayout {
+    size_t log_alpha, log_beta, cls, lin_alpha, lin_beta, dump, ea, eb, logz2, zint, flags, total;
+};
+__host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
+    CtcLayout w;
+    const size_t rows = (size_t)batch * t_out;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    w.log_alpha = take(rows * lattice_sp(l_max) * sizeof(float));
+    w.log_beta = take(rows * lattice_sp(l_max) * sizeof(float));
+    w.cls = take((size_t)batch * (l_max + 65) * sizeof(int32_t));
+    const bool wave = 2 * l_max + 1 <= 64 * WNS;
+    w.lin_alpha = take(wave ? rows * 64 * WNS * sizeof(double) : 0);
+    w.lin_beta = take(wave ? rows * 64 * WNS * sizeof(double) : 0);
+    w.dump = take(wave ? (size_t)2 * batch * 64 * WNS * sizeof(double) : 0);
+    const size_t eblocks = (size_t)batch * (t_out / WRESCALE + 1) * 64;  // one exponent per lane and block of 16 steps
+    w.ea = take(wave ? eblocks * sizeof(int32_t) : 0);
+    w.eb = take(wave ? eblocks * sizeof(int32_t) : 0);
+    w.logz2 = take((size_t)batch * sizeof(float));
+    w.zint = take((size_t)batch * sizeof(int32_t));
+    w.flags = take((size_t)batch * sizeof(int32_t));
+    w.total = off;
+    return w;
+}
+
 }  // namespace
+
+extern "C" int sl_ctc_select(int variant) {
+    SL_CHECK_ARG(variant >= 0 && variant <= 4, "sl_ctc_select: variant %d outside 0..4", variant);
+    g_ctc_variant = variant;
+    return SL_OK;
+}
 
 extern "C" int sl_softmax_logq(const float* logits, float* probs, float* logq, int batch, int t_out, int k,
                                int logit_stride, int64_t logit_batch_stride, float eps, void* stream) {
@@ -407,8 +883,9 @@ extern "C" int sl_softmax_logq(const float* logits, float* probs, float* logq, i
 
 extern "C" size_t sl_ctc_workspace_bytes(int batch, int t_out, int l_max) {
     if (batch <= 0 || t_out <= 0 || l_max < 0) return 0;
-    // alpha + beta lattices, then per utterance the class position lists: pos[l_max] | start[k + 1], k <= 64
-    return (size_t)2 * batch * t_out * lattice_sp(l_max) * sizeof(float) + (size_t)batch * (l_max + 65) * sizeof(int32_t);
+    // log-domain alpha + beta lattices and the class position lists (pos[l_max] | start[k + 1], k <= 64) per utterance;
+    // when the labels fit the wave lattice: its double lattices, per-frame exponents, log2 Z and repair flags as well
+    return ctc_layout(batch, t_out, l_max).total;
 }
 
 extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* labels, const int32_t* label_len,
@@ -422,29 +899,65 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
         sl_set_error("sl_ctc_loss_grad: label length %d > 511 unsupported (one lattice state per thread)", l_max);
         return SL_ERR_UNSUPPORTED;
     }
-    if (workspace_bytes < sl_ctc_workspace_bytes(batch, t_out, l_max)) {
+    const CtcLayout w = ctc_layout(batch, t_out, l_max);
+    if (workspace_bytes < w.total) {
         sl_set_error("sl_ctc_loss_grad: workspace too small");
         return SL_ERR_WORKSPACE_TOO_SMALL;
     }
     hipStream_t s = (hipStream_t)stream;
-    float* alpha = (float*)workspace;
-    float* beta = alpha + (size_t)batch * t_out * sp;
-    int32_t* cls = (int32_t*)(beta + (size_t)batch * t_out * sp);
+    char* base = (char*)workspace;
+    float* alpha = (float*)(base + w.log_alpha);
+    float* beta = (float*)(base + w.log_beta);
+    int32_t* cls = (int32_t*)(base + w.cls);
+    int32_t* flags = (int32_t*)(base + w.flags);
+    const bool wave = g_ctc_variant != 1 && 2 * l_max + 1 <= 64 * WNS && (g_ctc_variant != 0 || t_out >= WAVE_MIN_FRAMES);
+    const bool repair = wave && g_ctc_variant != 2;
+    const int frames_per_wg = 8;  // two frames per wave: 16000 frames -> 8000 waves in flight
+    const size_t lds2 = (size_t)(2 * l_max + (k + 1)) * sizeof(int) + (size_t)(4 * 64 + 4 * l_max) * sizeof(float);
+    const dim3 grid((t_out + frames_per_wg - 1) / frames_per_wg, batch);
+    const int out_f32 = dtype == SL_F32 ? 1 : 0;
+    int rc;
+    if (wave) {
+        double* la = (double*)(base + w.lin_alpha);
+        double* lb = (double*)(base + w.lin_beta);
+        int32_t* ea = (int32_t*)(base + w.ea);
+        int32_t* eb = (int32_t*)(base + w.eb);
+        float* logz2 = (float*)(base + w.logz2);
+        int32_t* zint = (int32_t*)(base + w.zint);
+        size_t lds = (size_t)(l_max + k + 1) * sizeof(int);
+        if (lds < 2 * sizeof(double) + 2 * sizeof(int)) lds = 2 * sizeof(double) + 2 * sizeof(int);
+        hipLaunchKernelGGL(ctc_lattice_wave_kernel, dim3(batch, 3), dim3(64), lds, s, probs, logq, labels, label_len,
+                           input_len, la, lb, (double*)(base + w.dump), ea, eb, logz2, zint, loss, cls, flags, t_out, k,
+                           l_max, k - 1, eps);
+        rc = sl_check_launch("sl_ctc_loss_grad(wave lattice)");
+        if (rc != SL_OK) return rc;
+        // rows are 512 doubles wide; the kernel reads 8 columns per lane
+        hipLaunchKernelGGL((ctc_grad_kernel<8, true>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
+                           input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
+                           l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32, eps,
+                           grad_scale, g_ctc_variant == 3 ? nullptr : flags, nullptr);
+        rc = sl_check_launch("sl_ctc_loss_grad(grad)");
+        if (rc != SL_OK || !repair) return rc;
+        if (g_ctc_variant == 3) {  // tests: redo everything
+            rc = (int)hipMemsetAsync(flags, 1, (size_t)batch * sizeof(int32_t), s);
+            if (rc != 0) return SL_ERR_LAUNCH_FAILED;
+        }
+    }
+    const int32_t* only = wave ? flags : nullptr;
     const int threads = sp;  // multiple of 64, >= S
     size_t lds = 2 * (threads + 4) * sizeof(float);
     const size_t lds_lists = (size_t)(l_max + k + 1) * sizeof(int);
     if (lds < lds_lists) lds = lds_lists;
     hipLaunchKernelGGL(ctc_lattice_kernel, dim3(batch, 3), dim3(threads), lds, s, logq, labels, label_len, input_len,
-                       alpha, beta, loss, cls, t_out, k, l_max, sp, k - 1);
-    int rc = sl_check_launch("sl_ctc_loss_grad(lattice)");
+                       alpha, beta, loss, cls, t_out, k, l_max, sp, k - 1, only);
+    rc = sl_check_launch("sl_ctc_loss_grad(lattice)");
     if (rc != SL_OK) return rc;
-    const int frames_per_wg = 8;  // two frames per wave: 16000 frames -> 8000 waves in flight
-    const size_t lds2 = (size_t)(2 * l_max + (k + 1)) * sizeof(int) + (size_t)(4 * 64 + 4 * l_max) * sizeof(float);
-    const dim3 grid((t_out + frames_per_wg - 1) / frames_per_wg, batch);
 #define SL_CTC_GRAD(NJ_)                                                                                              \
-    hipLaunchKernelGGL(ctc_grad_kernel<NJ_>, grid, dim3(256), lds2, s, probs, logq, labels, label_len, input_len, alpha, \
-                       beta, loss, cls, dlogits, t_out, k, l_max, sp, k - 1, frames_per_wg, g_row0, g_row_stride,     \
-                       (long)g_batch_stride, dtype == SL_F32 ? 1 : 0, eps, grad_scale)
+    hipLaunchKernelGGL((ctc_grad_kernel<NJ_, false>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,        \
+                       input_len, (const void*)alpha, (const void*)beta, nullptr, nullptr, nullptr, nullptr, loss, cls,   \
+                       dlogits,                                                                                        \
+                       t_out, k, l_max, sp, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,  \
+                       eps, grad_scale, nullptr, only)
     if (sp <= 256) {
         SL_CTC_GRAD(4);
     } else if (sp <= 512) {

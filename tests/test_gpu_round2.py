@@ -537,3 +537,102 @@ def test_config2_greedy_decode_bit_exact_at_batch_32():
     _report("config2_b32_bf16_mismatching_frames_of_16000", int((frame_argmax16 != argmax).sum()))
     _report("config2_b32_bf16_mismatching_sequences_of_32", int(sum(a != b for a, b in zip(decoded16, want))))
     assert (frame_argmax16 != argmax).mean() < 5e-2  # measured 1.7 % of the frames: the softmax is nearly flat
+
+
+# ------------------------------------------------------------------------------------------ CTC lattice variants
+def _ctc_variant(hip_lib, variant):
+    hip_lib.call("sl_ctc_select", variant)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_ctc_lattice_variants_against_the_oracle(hip_lib, variant):
+    """sl_ctc_loss_grad's two lattices -- probability domain (doubles + an exponent per 16 frames, one wave per utterance
+    and direction; variants 2, 3, 4 and the default for long utterances) and log domain (variants 0 at these lengths and
+    1; also the repair pass that variant 3 forces for every utterance) -- on the edge cases of round 1 (repeats, empty label, input_len < T', no valid alignment), on labels of
+    200 graphemes over 500 frames and on TensorFlow's known answers: same tolerances for all of them."""
+    import json
+    from test_gpu_parity import run_ctc_kernel
+    try:
+        _ctc_variant(hip_lib, variant)
+        rng = np.random.RandomState(9)
+        k, t = 7, 40
+        labels_list = [[0, 1, 2, 3], [4, 4, 4, 4, 4], [], [0, 5, 0, 5, 0, 5, 0], list(rng.randint(0, 6, size=19)),
+                       list(rng.randint(0, 6, size=30))]
+        input_len = [40, 40, 12, 13, 40, 25]  # last: 30 labels in 25 frames -> no valid alignment
+        logits = (rng.randn(len(labels_list), t, k) * 2).astype(np.float32)
+        labels = o.pack_label_batch([l if l else [-1] for l in labels_list])
+        lab_len = [len(l) for l in labels_list]
+        probs, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
+        ref_p = o.softmax(logits.astype(np.float64))
+        ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
+        ref_dl = o.softmax_backward(ref_p, ref_dp)
+        assert np.isinf(ref_loss[5]) and np.isinf(loss[5])
+        np.testing.assert_allclose(loss[:5], ref_loss[:5], rtol=1e-5)
+        for i in range(len(labels_list)):
+            assert np.abs(dl[i] - ref_dl[i]).max() < 1e-4, (i, np.abs(dl[i] - ref_dl[i]).max())
+            assert not dl[i, input_len[i]:].any()
+        # long labels, full length
+        rng = np.random.RandomState(10)
+        k, t, b = 29, 500, 4
+        lab_len = [200, 137, 1, 60]
+        labels = o.pack_label_batch([list(rng.randint(0, 28, size=n)) for n in lab_len])
+        logits = rng.randn(b, t, k).astype(np.float32)
+        input_len = [500, 480, 500, 333]
+        _, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
+        ref_p = o.softmax(logits.astype(np.float64))
+        ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
+        np.testing.assert_allclose(loss, ref_loss, rtol=1e-5)
+        err = rel_l2(dl, o.softmax_backward(ref_p, ref_dp))
+        _report("ctc_long_labels_gradient_rel_l2_variant{}".format(variant), err)
+        assert err < 1e-3
+        # TensorFlow's ctc_loss_op_test.py::testBasic (eps = 0: the op's own arithmetic): loss and gradient
+        cases = json.loads((GOLDEN / "tf_known_answers.json").read_text())["ctc_loss"]
+        lg = np.stack([np.log(np.array(c["probs"], dtype=np.float64)) for c in cases]).astype(np.float32)
+        lab = -np.ones((len(cases), 5), dtype=np.int32)
+        for i, c in enumerate(cases):
+            lab[i, :len(c["labels"])] = c["labels"]
+        _, loss, dl = run_ctc_kernel(hip_lib, lg, lab, [len(c["labels"]) for c in cases], [5] * len(cases), eps=0.0)
+        for i, c in enumerate(cases):
+            assert abs(loss[i] - c["loss"]) < 1e-5, (i, loss[i])
+            assert np.abs(dl[i] - np.array(c["grad_logits"])).max() < 3e-6, i
+    finally:
+        _ctc_variant(hip_lib, 0)
+
+
+def test_ctc_probability_domain_lattice_in_the_blank_collapse_regime(hip_lib):
+    """What a single exponent per lattice ROW could not hold (the first version of the wave lattice reported Z = 0 here):
+    140 x 'a' over 300 frames whose first half predicts nothing but blank (p_a at the 1e-8 floor), so that every alignment
+    pays ~65 floor emissions (2^-1700) before frame 150 while the all-blank prefix costs nothing; and, more generally, the
+    regime every CTC training run passes through early on -- p(blank) ~ 1, every label at the floor -- where the states
+    of one row span thousands of binades.  With one exponent per LANE (8 states) the probability-domain lattice handles
+    both without the repair pass (variant 2 = no repair launches), to fp32 round-off of the float64 oracle."""
+    from test_gpu_parity import run_ctc_kernel
+    k, t, n = 3, 300, 140
+    logits = np.zeros((2, t, k), dtype=np.float32)
+    logits[:, :150, 2] = 40.0
+    logits[:, 150::2, 0] = 6.0
+    logits[:, 151::2, 2] = 6.0
+    labels = o.pack_label_batch([[0] * n, [0, 1, 0]])
+    lab_len, input_len = [n, 3], [t, t]
+    ref_p = o.softmax(logits.astype(np.float64))
+    ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
+    assert np.isfinite(ref_loss).all() and ref_loss[0] > 1000
+    rng = np.random.RandomState(4)
+    k2, t2, n2 = 29, 1500, 120
+    logits2 = rng.randn(1, t2, k2).astype(np.float32)
+    logits2[:, :, k2 - 1] += 25.0  # blank collapse
+    labels2 = o.pack_label_batch([list(rng.randint(0, 28, size=n2))])
+    ref_p2 = o.softmax(logits2.astype(np.float64))
+    ref_loss2, ref_dp2 = o.ctc_batch_cost(ref_p2, labels2, [t2], [n2])
+    ref_dl2 = o.softmax_backward(ref_p2, ref_dp2)
+    try:
+        for variant in (2, 4):
+            _ctc_variant(hip_lib, variant)
+            _, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
+            np.testing.assert_allclose(loss, ref_loss, rtol=2e-6)
+            assert np.abs(dl - o.softmax_backward(ref_p, ref_dp)).max() < 2e-5
+            _, loss2, dl2 = run_ctc_kernel(hip_lib, logits2, labels2, [n2], [t2])
+            np.testing.assert_allclose(loss2, ref_loss2, rtol=2e-6)
+            assert rel_l2(dl2, ref_dl2) < 1e-4, rel_l2(dl2, ref_dl2)
+    finally:
+        _ctc_variant(hip_lib, 0)

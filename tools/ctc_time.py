@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Times sl_ctc_loss_grad alone (lattice + gradient [+ repair launches]) at a BASELINE shape, per lattice variant.
+    python tools/ctc_time.py [--batch 32] [--frames 500] [--lmax 200]        (SL_LIB_PATH selects a probe build)"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--lmax", type=int, default=200)
+    ap.add_argument("--reps", type=int, default=50)
+    args = ap.parse_args()
+    import torch
+    from speechless_amd import _lib
+    lib = _lib.lib()
+    b, t, k = args.batch, args.frames, 29
+    rng = np.random.RandomState(0)
+    dev = "cuda:0"
+    logits = torch.tensor(rng.randn(b, t, k).astype(np.float32), device=dev)
+    probs = torch.zeros((b, t, k), dtype=torch.float32, device=dev)
+    logq = torch.zeros_like(probs)
+    lab_len = rng.randint(20, args.lmax + 1, size=b).astype(np.int32)
+    labels = np.zeros((b, args.lmax), dtype=np.int32)
+    for i, n in enumerate(lab_len):
+        labels[i, :n] = rng.randint(0, k - 1, size=n)
+    lab = torch.tensor(labels, device=dev)
+    ll = torch.tensor(lab_len, device=dev)
+    il = torch.full((b,), t, dtype=torch.int32, device=dev)
+    loss = torch.zeros((b,), dtype=torch.float32, device=dev)
+    dl = torch.zeros((b, t, 128), dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.call("sl_softmax_logq", logits.data_ptr(), probs.data_ptr(), logq.data_ptr(), b, t, k, k, t * k, 1e-8, st)
+    need = lib.raw("sl_ctc_workspace_bytes")(b, t, args.lmax)
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    for variant, name in ((1, "log-domain lattice"), (2, "wave lattice, no repair launches"), (0, "wave lattice + repair launches")):
+        lib.call("sl_ctc_select", variant)
+
+        def run():
+            lib.call("sl_ctc_loss_grad", probs.data_ptr(), logq.data_ptr(), lab.data_ptr(), ll.data_ptr(), il.data_ptr(),
+                     loss.data_ptr(), dl.data_ptr(), b, t, k, args.lmax, 0, 128, t * 128, _lib.SL_BF16, 1e-8, 1.0 / b,
+                     ws.data_ptr(), need, st)
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        print("{:40s} {:8.1f} us per call   (mean loss {:.3f})".format(name, e0.elapsed_time(e1) / args.reps * 1e3,
+                                                                     float(loss.mean())))
+    lib.call("sl_ctc_select", 0)
+
+
+if __name__ == "__main__":
+    main()
