@@ -109,7 +109,10 @@ class HipLibrary:
                 "{} not found: build it with `python -m speechless_amd.build` (or __graft_entry__.build()). "
                 "The speechless_amd hot path has no CPU fallback.".format(path))
         self.path = path
-        self._dll = ctypes.CDLL(str(path))
+        # PyDLL: the GIL is NOT released around a call.  Every entry point only enqueues work (microseconds); with CDLL
+        # each of the ~60 launches of a step hands the GIL to the input pipeline's worker threads and has to win it back
+        # (up to the interpreter's 5 ms switch interval) before the next launch can be issued.
+        self._dll = ctypes.PyDLL(str(path)) if os.environ.get("SL_RELEASE_GIL", "0") != "1" else ctypes.CDLL(str(path))
         self._fn = {}
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(self._dll, name)  # AttributeError if the symbol is missing -> loud

@@ -160,6 +160,7 @@ class _Buffers:
         self.bwd_ready = False
         self.nt_ws = None
         self.wgrad_ws = None
+        self.launch_lists = {}   # recorded launch lists (Engine._replay); dropped whenever a pointer they hold changes
         self._ws_sized = set()   # output lengths whose workspace needs have been checked
         self._clean_in = 0       # input frames / output rows up to which stale data may sit in the buffers
         self._clean_out = 0
@@ -204,6 +205,7 @@ class _Buffers:
                     ctypes.byref(g), eng.dtype_code, eng.nt_cfg.get((kind, p.spec.name), 0)))
         if self.nt_ws is None or self.nt_ws.numel() < need:
             self.nt_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
+            self.launch_lists = {}
 
     def ensure_backward(self, eng):
         if self.bwd_ready:
@@ -271,8 +273,10 @@ class _Buffers:
                         ctypes.byref(self.wgrad_geom[lo]), e0 - lo + 1, 0))
         if self.wgrad_ws is None or self.wgrad_ws.numel() < ws_bytes:
             self.wgrad_ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=eng.device)
+            self.launch_lists = {}
         if self.bias_ws is None or self.bias_ws.numel() < bias_ws:
             self.bias_ws = torch.empty((max(bias_ws, 16),), dtype=torch.uint8, device=eng.device)
+            self.launch_lists = {}
 
     def ensure_ctc(self, eng, l_max):
         if self.ctc_ws is not None and l_max <= self.ctc_ws_lmax:
@@ -375,6 +379,14 @@ class Engine:
         # much as it costs alone -- so it is off by default, which also keeps per-kernel timings clean.
         self.early_adam = False
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
+        # Launch lists: the ~60 C-ABI calls and 4 stream hand-overs of a step are recorded the first time a buffer set
+        # runs them and replayed afterwards with their arguments already marshalled -- the Python around each launch
+        # (tensor views of the flat parameter buffers, data_ptr() calls, geometry look-ups: ~10 us per launch) was what
+        # capped the host-fed loop below the rate of the resident step.  Geometries are passed by reference and
+        # re-targeted in place (_Buffers.set_length), so one list serves every batch length of a buffer set.
+        self.use_launch_lists = os.environ.get("SL_LAUNCH_LISTS", "1") != "0"
+        self._rec = None
+        self._adam_tables = {}
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -396,6 +408,8 @@ class Engine:
             return
         if self.timeline is None:
             self.lib.call(name, *args)
+            if self._rec is not None:  # building a launch list (see _replay): the raw entry point and its arguments
+                self._rec.append((0, self.lib.raw(name), args, name))
             return
         start = torch.cuda.Event(enable_timing=True)
         stop = torch.cuda.Event(enable_timing=True)
@@ -403,6 +417,35 @@ class Engine:
         self.lib.call(name, *args)
         stop.record()
         self.timeline.append((tag, start, stop))
+
+    def _hand_over(self, src, dst):
+        """dst waits for everything enqueued on src so far (event record on src + wait on dst)."""
+        ev = torch.cuda.Event()
+        ev.record(src)
+        dst.wait_event(ev)
+        if self._rec is not None:
+            self._rec.append((1, ev, src, dst))
+
+    def _replay(self, ops, callback=None):
+        for op in ops:
+            kind = op[0]
+            if kind == 0:
+                rc = op[1](*op[2])
+                if rc != 0:
+                    raise _lib.HipLibraryError("{} failed with status {}: {}".format(op[3], rc, self.lib.last_error()))
+            elif kind == 1:
+                op[1].record(op[2])
+                op[3].wait_event(op[1])
+            else:
+                callback(op[1])
+
+    def _launch_list(self, buf, key):
+        """The recorded launch list of `key` for this buffer set, or None (then the caller runs eagerly; with
+        self._rec set by start_recording() that run records the list)."""
+        if not self.use_launch_lists or self.timeline is not None or self.kernel_timeline is not None or \
+                self._rec is not None:
+            return None
+        return buf.launch_lists.get(key)
 
     def buffers(self, batch, t_in):
         """Buffers for batches of `batch` utterances padded to t_in frames: one set per (batch, output frames rounded
@@ -528,6 +571,29 @@ class Engine:
         n = len(self.plans)
         rate = self.dropout_rate if training else None
         buf.dropped = bool(rate)
+        fuse_out = self.fuse_output_softmax and self.dtype == "bf16" and bool(self.lib.raw("sl_output_softmax_supported")(
+            ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size, self.dtype_code))
+        # launch list (no dropout): everything below takes its frame count from the geometries, except the unfused
+        # softmax, which gets it by value -> then the list is per length
+        key = None if rate else ("fwd", st, fuse_out, tuple(sorted(self.nt_cfg.items())), None if fuse_out else buf.t_out)
+        ops = self._launch_list(buf, key) if key is not None else None
+        if ops is not None:
+            self._replay(ops)
+            return buf.probs
+        record = key is not None and self.use_launch_lists and self.timeline is None and \
+            self.kernel_timeline is None and self._rec is None
+        if not record:
+            return self._forward_eager(buf, rate, fuse_out, st)
+        self._rec = []
+        try:
+            probs = self._forward_eager(buf, rate, fuse_out, st)
+            buf.launch_lists[key] = self._rec
+            return probs
+        finally:
+            self._rec = None
+
+    def _forward_eager(self, buf, rate, fuse_out, st):
+        n = len(self.plans)
         x = buf.x0
         if rate:
             self._dropout_steps += 1
@@ -538,8 +604,6 @@ class Engine:
             self._launch("dropout:input", "sl_dropout", buf.x0.data_ptr(), buf.x0_dropped.data_ptr(), buf.x0.numel(),
                          self.dtype_code, rate, seed0, st)
             x = buf.x0_dropped
-        fuse_out = self.fuse_output_softmax and self.dtype == "bf16" and bool(self.lib.raw("sl_output_softmax_supported")(
-            ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size, self.dtype_code))
         for p in self.plans:
             last = p.index == n - 1
             y = buf.logits if last else buf.y[p.index]
@@ -656,6 +720,27 @@ class Engine:
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)  # (ROCm offers no priority below the default)
         side = self._side_stream
+        # launch list: the default schedule only (no dropout masks to rescale, no early Adam, no second wgrad stream)
+        plain = not (early_adam or self.overlap_wgrad or buf.dropped or os.environ.get("SL_DEFER_BGRAD") == "skip")
+        key = ("bwd", main.cuda_stream, on_bucket_ready is not None, self.defer_bias_grads, self.frozen_layer_count,
+               self.group_wgrad, tuple(sorted(self.nt_cfg.items()))) if plain else None
+        ops = self._launch_list(buf, key) if key is not None else None
+        if ops is not None:
+            self._replay(ops, on_bucket_ready)
+            return
+        record = key is not None and self.use_launch_lists and self.timeline is None and \
+            self.kernel_timeline is None and self._rec is None
+        if not record:
+            self._backward_eager(buf, main, side, on_bucket_ready, early_adam, reducer)
+            return
+        self._rec = []
+        try:
+            self._backward_eager(buf, main, side, on_bucket_ready, early_adam, reducer)
+            buf.launch_lists[key] = self._rec
+        finally:
+            self._rec = None
+
+    def _backward_eager(self, buf, main, side, on_bucket_ready, early_adam, reducer):
         first = self.frozen_layer_count
         _, split = self.bucket_ranges()
         grouped = {}  # layer index -> (lo, hi) of the run whose weight gradients are computed in one grouped launch
@@ -667,9 +752,12 @@ class Engine:
                         grouped[q] = (lo, e0)
 
         def join_side():
-            done = torch.cuda.Event()
-            done.record(side)
-            main.wait_event(done)
+            self._hand_over(side, main)
+
+        def bucket_ready(index):
+            on_bucket_ready(index)
+            if self._rec is not None:
+                self._rec.append((2, index))
 
         if early_adam:
             if self._packed_dirty:
@@ -705,11 +793,10 @@ class Engine:
             pending_bytes += buf.g[i].numel() * buf.g[i].element_size()
             if pending and (not defer or pending_bytes >= (128 << 20) or i <= first + 1 or
                             (on_bucket_ready is not None and i == split)):
-                ready = torch.cuda.Event()
-                ready.record(main)  # g[j], j in pending (CTC gradient or a previous dgrad) are complete at this point of MAIN
+                # g[j], j in pending (CTC gradient or a previous dgrad) are complete at this point of MAIN
+                self._hand_over(main, side)
                 wgrad_stream = side if self.overlap_wgrad else main
                 with torch.cuda.stream(side):
-                    side.wait_event(ready)
                     if self.overlap_wgrad:
                         self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
                                      dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
@@ -721,7 +808,7 @@ class Engine:
                                      db_j.data_ptr(), ctypes.byref(buf.wgrad_geom[j]), self.dtype_code,
                                      buf.bias_ws.data_ptr(), buf.bias_ws.numel(), side.cuda_stream)
                     if self.overlap_wgrad and on_bucket_ready is not None and i == split:
-                        on_bucket_ready(0)
+                        bucket_ready(0)
                 del pending[:]
                 pending_bytes = 0
             if i in grouped:
@@ -742,7 +829,7 @@ class Engine:
                              buf.wgrad_ws.numel(), main.cuda_stream)
                 if on_bucket_ready is not None and i == split:
                     join_side()
-                    on_bucket_ready(0)
+                    bucket_ready(0)
             if i > first:
                 elu = self.specs[i - 1].activation == "elu"
                 elu_dropped = elu and buf.dropped and i in self._dropout_layers()
@@ -775,12 +862,12 @@ class Engine:
         if self.overlap_wgrad:
             if on_bucket_ready is not None and split > first:
                 with torch.cuda.stream(side):
-                    on_bucket_ready(1)
+                    bucket_ready(1)
             join_side()
         else:
             join_side()
             if on_bucket_ready is not None and split > first:
-                on_bucket_ready(1)
+                bucket_ready(1)
         if early_adam and dp:
             if split > first:
                 reducer.run_after_reduce(lambda st, ls=list(bucket_layers): self._adam_layers(ls, st))
@@ -808,14 +895,17 @@ class Engine:
         layers = list(layers)
         for lo in range(0, len(layers), 16):
             chunk = layers[lo:lo + 16]
-            table = (_lib.AdamLayer * len(chunk))()
-            for entry, i in zip(table, chunk):
-                p = self.plans[i]
-                wd = self.w_dgrad[p.index]
-                entry.offset = p.w_off
-                entry.w_fwd = self.w_fwd[p.index].data_ptr()
-                entry.w_dgrad = wd.data_ptr() if wd is not None else None
-                entry.k, entry.cin_pad, entry.cout_pad = p.spec.kernel_size, p.cin_pad, p.cout_pad
+            table = self._adam_tables.get(tuple(chunk))
+            if table is None:  # (the operand copies never move: built once per set of layers)
+                table = (_lib.AdamLayer * len(chunk))()
+                for entry, i in zip(table, chunk):
+                    p = self.plans[i]
+                    wd = self.w_dgrad[p.index]
+                    entry.offset = p.w_off
+                    entry.w_fwd = self.w_fwd[p.index].data_ptr()
+                    entry.w_dgrad = wd.data_ptr() if wd is not None else None
+                    entry.k, entry.cin_pad, entry.cout_pad = p.spec.kernel_size, p.cin_pad, p.cout_pad
+                self._adam_tables[tuple(chunk)] = table
             self._launch("adam:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name),
                          "sl_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                          self.adam_v.data_ptr(), table, len(chunk), self.dtype_code, self.adam_iterations, self.lr,

@@ -94,14 +94,18 @@ class BatchStager:
     `workers` threads (the native packer runs without the GIL); the batch iterable itself is only ever advanced by
     the consuming thread, and batches are delivered in order."""
 
-    def __init__(self, batches, pack, device, blank, depth=3, workers=3):
+    def __init__(self, batches, pack, device, blank, depth=3, workers=3, spare_slots=5):
         from concurrent.futures import ThreadPoolExecutor
         self.device = torch.device(device)
         self.pack = pack
         self.blank = blank  # labels must lie in [0, blank)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.depth = max(1, depth)
-        self.slots = [_Slot() for _ in range(self.depth + 1)]
+        # A slot (host staging buffer + device buffer) may be refilled only after the step that read it has RUN on the
+        # GPU.  With just depth + 1 slots every worker spent most of its time blocked on that (7 ms per batch, of which
+        # 1 ms packing) and three workers could not quite feed a 2.3 ms step (cadence 2.65 ms); with spare slots the
+        # reuse distance exceeds the GPU's backlog and the loop runs at the GPU's own cadence (2.31 ms).
+        self.slots = [_Slot() for _ in range(self.depth + 1 + max(0, spare_slots))]
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="speechless-stager")
         self.source = iter(batches)
         self.pending = []  # futures, oldest first

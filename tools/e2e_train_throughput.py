@@ -18,7 +18,7 @@ sys.path.insert(0, str(ROOT))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=200)
     args = ap.parse_args()
     import torch
     from speechless_amd import Wav2Letter, english_frequent_characters
