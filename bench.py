@@ -447,7 +447,7 @@ def main():
                             "kernel's launches per step",
             "duration_note": "HIP events recorded by the library immediately around the kernel on its launch stream "
                              "(sl_profile_next_kernel) in otherwise un-instrumented steps; compare with the average "
-                             "of wgrad_tn_ilv_kernel in profiles/r01k_kernel_stats.csv",
+                             "of wgrad_tn_ilv_kernel in profiles/r02j_kernel_stats.csv",
             "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms}
     if args.config in (2, 3):
         nt_flops = fl[names.index("big_conv_1")] * BATCH_PER_GPU
