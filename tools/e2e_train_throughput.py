@@ -19,6 +19,9 @@ sys.path.insert(0, str(ROOT))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--ragged", action="store_true",
+                    help="utterances of 600..1000 frames: every batch is padded to its own longest member, as the "
+                         "reference's generator does (corpus.py:224-226), so the frame count changes from step to step")
     args = ap.parse_args()
     import torch
     from speechless_amd import Wav2Letter, english_frequent_characters
@@ -29,8 +32,10 @@ def main():
     pool = []
     for i in range(64):
         label = "".join(rng.choice(list(chars), size=rng.randint(20, 201))).strip() or "a"
-        pool.append(LabeledSpectrogram(id=str(i), label=" ".join(label.split()), spectrogram=rng.randn(1000, 128)))
-    batches = [[pool[(j * 7 + i) % 64] for i in range(32)] for j in range(args.steps + 8)]
+        frames = int(rng.randint(600, 1001)) if args.ragged else 1000
+        pool.append(LabeledSpectrogram(id=str(i), label=" ".join(label.split())[:frames // 5],
+                                       spectrogram=rng.randn(frames, 128)))
+    batches = [[pool[(j * 7 + i * (3 if args.ragged else 1)) % 64] for i in range(32)] for j in range(args.steps + 8)]
     net = Wav2Letter(128, english_frequent_characters, seed=0)
     for b in batches[:4]:
         net.train_on_batch(b)
@@ -56,6 +61,10 @@ def main():
         eng.train_step_resident()
     torch.cuda.synchronize()
     resident = time.perf_counter() - t0
+    if args.ragged:
+        print("ragged batches: padded lengths {} .. {} frames over the run, {} buffer set(s) allocated".format(
+            min(max(e._spectrogram.shape[0] for e in b) for b in batches), max(max(e._spectrogram.shape[0] for e in b)
+                                                                               for b in batches), len(eng._buffers)))
     print("resident input (the bench.py regime): {:8.1f} utt/s ({:.2f} ms per batch)".format(
         32 * args.steps / resident, resident / args.steps * 1e3))
     print("serial loop   : {:8.1f} utt/s ({:.2f} ms per batch of 32, host packing + pageable H2D on the critical path)".format(
