@@ -106,6 +106,21 @@ int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* ma
                  const sl_conv_geom* geom, int epilogue, int dtype, int out_f32, int cfg, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* ---- a RUN of identical stride-1 convolutions in one launch (bf16) --------------------------------------------------
+ * Replaces: the seven Conv1D(250, 7) `inner_conv_i` of net.py:321-323 -- n_layers consecutive sl_conv1d_nt calls of the
+ * same geometry (256 padded channels in and out, odd taps <= 9, every tensor in the same halo'd layout) whose
+ * intermediate activations stay in LDS; each layer's output is still written to HBM (ys[i]: the backward pass needs it).
+ *   epilogue SL_EPI_BIAS_RELU: forward; layer i: ys[i] = relu(conv(i == 0 ? x : ys[i-1], ws[i]) + biases[i])
+ *   epilogue SL_EPI_RELU_MASK: input gradients; layer i: ys[i] = conv(i == 0 ? x : ys[i-1], ws[i]) * (masks[i] > 0),
+ *            ws[i] the dgrad operand (taps flipped) of the i-th convolution from the TOP of the run
+ *   geom: the geometry ONE layer of the run would pass to sl_conv1d_nt.  sl_conv1d_chain_supported() = 1 when the run
+ *   fits; otherwise (or for fp32 / ELU / dropout between the layers) use n_layers calls of sl_conv1d_nt.
+ */
+int sl_conv1d_chain_supported(const sl_conv_geom* geom, int n_layers, int dtype);
+int sl_conv1d_chain(const void* x, void* const* ys, const void* const* ws, const float* const* biases,
+                    const void* const* masks, const sl_conv_geom* geom, int n_layers, int epilogue, int dtype,
+                    void* stream);
+
 /* ---- conv weight gradient -------------------------------------------------------------------------------------
  * Replaces: TF Conv2DBackpropFilter reached by autodiff from net.py:389,550.
  *   dw[tap][c][co] = sum_b sum_{t < t_pad} x[b][x_row0 + t + tap][c] * g[b][g_row0 + t][co]     (fp32 out)

@@ -91,6 +91,29 @@ extern "C" int sl_output_softmax(const void* x, const void* w, const float* bias
                                (hipStream_t)stream);
 }
 
+extern "C" int sl_conv1d_chain_supported(const sl_conv_geom* geom, int n_layers, int dtype) {
+    return geom != nullptr && dtype == SL_BF16 && geom->batch > 0 && geom->t_out > 0 && conv_chain_bf16_supported(geom, n_layers);
+}
+
+extern "C" int sl_conv1d_chain(const void* x, void* const* ys, const void* const* ws, const float* const* biases,
+                               const void* const* masks, const sl_conv_geom* geom, int n_layers, int epilogue, int dtype,
+                               void* stream) {
+    SL_CHECK_ARG(x && ys && ws && geom, "sl_conv1d_chain: null pointer");
+    SL_CHECK_ARG(epilogue == SL_EPI_BIAS_RELU || epilogue == SL_EPI_RELU_MASK,
+                 "sl_conv1d_chain: epilogue must be SL_EPI_BIAS_RELU (forward) or SL_EPI_RELU_MASK (input gradient)");
+    SL_CHECK_ARG(epilogue == SL_EPI_BIAS_RELU ? biases != nullptr : masks != nullptr,
+                 "sl_conv1d_chain: the epilogue's per-layer operand (biases / masks) is null");
+    if (!sl_conv1d_chain_supported(geom, n_layers, dtype)) {
+        sl_set_error("sl_conv1d_chain: this run does not fit the fused kernel (256 padded channels, odd taps <= 9, 2..8 "
+                     "layers, bf16)");
+        return SL_ERR_UNSUPPORTED;
+    }
+    for (int i = 0; i < n_layers; ++i)
+        SL_CHECK_ARG(ys[i] && ws[i] && (epilogue == SL_EPI_BIAS_RELU ? (const void*)biases[i] : masks[i]),
+                     "sl_conv1d_chain: null pointer for layer %d", i);
+    return conv_chain_bf16(x, ys, ws, biases, masks, geom, n_layers, epilogue, (hipStream_t)stream);
+}
+
 extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg) {
     if (!geom || geom->taps <= 0 || geom->cin <= 0 || geom->cout <= 0 || geom->batch <= 0) return 0;
     if (dtype == SL_BF16) {

@@ -69,6 +69,9 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
 size_t conv_nt_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
 int conv_nt_f32(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
                 int epilogue, int cfg, hipStream_t s);
+bool conv_chain_bf16_supported(const sl_conv_geom* g, int n_layers);
+int conv_chain_bf16(const void* x, void* const* ys, const void* const* ws, const float* const* biases,
+                    const void* const* masks, const sl_conv_geom* g, int n_layers, int epilogue, hipStream_t s);
 int wgrad_split_count(const sl_conv_geom* g, int tile);
 int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, int groups, long x_gs,
                   long g_gs, long dw_gs, float* ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,334 @@
+// conv_chain_bf16.hip -- a RUN of identical stride-1 convolutions (the seven 250 -> 250 channel, 7-tap inner_conv_i of
+// the Wav2Letter stack, reference speechless/net.py:321-323) in ONE launch, forward (bias + ReLU) or input-gradient
+// (ReLU mask) direction, with the activations of a time tile held in LDS from layer to layer.
+//
+// Why: as single launches these layers are 14 GFLOP each -- 5.6 us at the bf16 MFMA peak -- and pay a fixed 6-8 us per
+// launch (launch, first-touch of weights and activations that the previous kernel just wrote, pipeline fill and drain)
+// plus an L2 -> LDS stream of 32 KB per 64-deep step that is as long as the step's MFMAs: 23.8 us forward / 26 us
+// input gradient inside the step = 22-24 % of the peak, 0.37 ms of a 2.28 ms step for 8.5 % of its FLOPs
+// (VERDICT r1 item 3).  Here a work-group owns 64 consecutive output frames of one utterance through the WHOLE run:
+//   * it loads the input rows it needs ONCE (64 + 2 * pad * layers rows x 256 channels -> LDS), computes every layer
+//     for its rows plus the halo the following layers still need (the halo is recomputed, not exchanged: +39 % MFMA
+//     work at seven layers, no inter-work-group synchronisation), and hands a layer's output to the next one through
+//     LDS (bf16, exactly the value that is also stored to HBM for the backward pass);
+//   * per 64-deep step it streams only the 256 x 64 weight tile (32 KB) through a 3-slot LDS-DMA ring
+//     (global_load_lds, counted vmcnt), two steps ahead and across layer boundaries;
+//   * eight waves = two per SIMD; wave w owns output channels [32w, 32w + 32) for all rows: per step 2 weight fragments
+//     + up to 7 activation fragments per k-half feed up to 28 MFMAs (v_mfma_f32_16x16x32_bf16), D^T orientation (MFMA rows
+//     = channels) so that a lane ends with 4 consecutive channels of one time row: 8-byte LDS / HBM stores.
+// STATUS (round 2): parity-tested (tests/test_gpu_round2.py::test_fused_run_of_inner_layers_against_the_single_launches)
+// but not yet faster than the launches it replaces -- forward 179 us against 7 x 24.4 us, input gradients 207 against 185 --
+// so the engine keeps it opt-in (Engine.use_chain / SL_CHAIN=1).  A step takes 0.91 us against 0.45 us of MFMA issue time:
+// the LDS array is busy ~1000 cycles per step (144 KB of fragment reads at 256 B/clk + the 32 KB DMA write) and, with all
+// eight waves in lockstep behind one barrier per step, that time does not overlap the MFMA phase.  History: a
+// wave-uniform `if (m < mt)` around every tile 1.26 us per step; compiler-visible LDS reads (vmcnt(0) before the first read
+// of every step) 0.96; per-read address arithmetic 0.91.  Next: reads of step g + 1 under the MFMAs of step g (barrier in
+// the middle of a step) and a 2 x 4 wave layout (-17 % fragment bytes).
+// LDS: activations 4 chunk-slabs x 120 rows x 128 B = 60 KB (row r, 16-byte slot s stored at slot s ^ (r & 7): a fragment
+// read at any tap offset stays conflict-free, as in the slab kernel of conv_nt_bf16.hip) + 3 x 32 KB weight slots.
+// Rows outside [0, T') are forced to zero after every layer (SAME padding: relu(bias) is not zero).
+#include "common.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int CH = 256;          // channels in = out (padded)
+constexpr int TM = 64;           // output frames per work-group
+constexpr int MAX_LAYERS = 8;
+constexpr int ACT_ROWS = 120;    // >= 16 * 7 + taps - 1
+constexpr int ACT_CHUNK = ACT_ROWS * 128;
+constexpr int ACT_BYTES = 4 * ACT_CHUNK;  // 61 440
+constexpr int WSLOT = CH * 128;           // 32 768
+constexpr int NSLOT = 3;
+constexpr int CHAIN_LDS = ACT_BYTES + NSLOT * WSLOT;  // 159 744 <= 160 KiB
+constexpr int MT_MAX = 7;
+
+struct ChainArgs {
+    const __bf16* x;                  // input of the first layer of the run
+    __bf16* y[MAX_LAYERS];            // outputs (forward: activations; dgrad: gradients), same geometry as x
+    const __bf16* w[MAX_LAYERS];      // packed weights [256][taps][256] (forward: w_fwd; dgrad: w_dgrad, taps flipped)
+    const float* bias[MAX_LAYERS];    // forward
+    const __bf16* mask[MAX_LAYERS];   // dgrad: the stored activation whose sign is the ReLU mask, same geometry
+    int n_layers, taps, pad;          // pad = rows of left context per layer (forward: pad_left; dgrad: pad_right)
+    int batch, t_out, t_tiles;
+    int row0, rs;                     // halo rows in front of frame 0, elements per row
+    long bs;                          // elements per utterance
+};
+
+__device__ __forceinline__ void chain_glds16(const __bf16* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const SL_GLOBAL void*)gsrc, (SL_LDS void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void chain_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int OFF>
+__device__ __forceinline__ void chain_ds_read128(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int I, int N>
+struct ChainReadRun {  // N reads, 16 rows (2048 bytes) apart
+    static __device__ __forceinline__ void go(bf16x8 (&f)[N], unsigned addr) {
+        chain_ds_read128<I * 2048>(f[I], addr);
+        ChainReadRun<I + 1, N>::go(f, addr);
+    }
+};
+template <int N>
+struct ChainReadRun<N, N> {
+    static __device__ __forceinline__ void go(bf16x8 (&)[N], unsigned) {}
+};
+// s_waitcnt lgkmcnt(CNT) that the MFMAs consuming these fragments cannot be hoisted above
+template <int MT>
+struct ChainWait;
+template <>
+struct ChainWait<4> {
+    template <int CNT>
+    static __device__ __forceinline__ void frags(bf16x8 (&w)[2], bf16x8 (&x)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(CNT));
+    }
+};
+template <>
+struct ChainWait<5> {
+    template <int CNT>
+    static __device__ __forceinline__ void frags(bf16x8 (&w)[2], bf16x8 (&x)[5]) {
+        asm volatile("s_waitcnt lgkmcnt(%7)"
+                     : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4])
+                     : "n"(CNT));
+    }
+};
+template <>
+struct ChainWait<6> {
+    template <int CNT>
+    static __device__ __forceinline__ void frags(bf16x8 (&w)[2], bf16x8 (&x)[6]) {
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5])
+                     : "n"(CNT));
+    }
+};
+template <>
+struct ChainWait<7> {
+    template <int CNT>
+    static __device__ __forceinline__ void frags(bf16x8 (&w)[2], bf16x8 (&x)[7]) {
+        asm volatile("s_waitcnt lgkmcnt(%9)"
+                     : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]),
+                       "+v"(x[6])
+                     : "n"(CNT));
+    }
+};
+
+template <bool DGRAD>
+__global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* act = smem;
+    char* wring = smem + ACT_BYTES;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int b = tile / a.t_tiles;
+    const int t0 = (tile - b * a.t_tiles) * TM;
+    const int n = a.n_layers;
+    const int taps = a.taps;
+    const int pad = a.pad;
+    const int halo = taps - 1;          // rows a layer consumes beyond its output rows
+    const int steps_per_layer = taps * 4;
+    const int total_steps = n * steps_per_layer;
+    const int w_rs = taps * CH;         // elements per output channel in the packed weights
+
+    // ---- weight stream: global step g = (layer, tap, 64-channel chunk); DMA instruction j copies weight rows
+    // [8j, 8j + 8): lane -> row 8j + lane / 8, physical 16-byte slot lane % 8 = logical slot ^ (row & 7)
+    const int wlane_off = (lane >> 3) * w_rs + (((lane & 7) ^ (lane >> 3)) << 3);
+    auto stage = [&](int g) {
+        const int l = g / steps_per_layer;
+        const int s = g - l * steps_per_layer;
+        const __bf16* src = a.w[l] + (long)s * 64 + wlane_off;  // (tap, chunk) pieces are consecutive: s * 64 elements
+        char* dst = wring + (g % NSLOT) * WSLOT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = wave * 4 + q;
+            chain_glds16(src + (long)(8 * j) * w_rs, dst + j * 1024);
+        }
+    };
+    stage(0);
+    if (total_steps > 1) stage(1);
+
+    // ---- input rows of the first layer: frames t0 - pad * n .. (64 + halo * n rows), zero outside [0, T')
+    {
+        const int rows_in = TM + halo * n;
+        const __bf16* xb = a.x + (long)b * a.bs;
+        for (int idx = tid; idx < rows_in * 32; idx += 512) {
+            const int r = idx >> 5, slot = idx & 31;
+            const int t = t0 - pad * n + r;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (t >= 0 && t < a.t_out) v = *(const u32x4*)(xb + (long)(a.row0 + t) * a.rs + slot * 8);
+            *(u32x4*)(act + (slot >> 3) * ACT_CHUNK + r * 128 + (((slot & 7) ^ (r & 7)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[MT_MAX][2];
+#pragma unroll
+    for (int m = 0; m < MT_MAX; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int lrow = lane & 15, lq = lane >> 4;
+    // weight fragment rows of this lane: channel 32 * wave + 16 * nt + lrow; byte offsets inside a ring slot per k-half
+    const int a_off0 = (32 * wave + lrow) * 128, a_key0 = (32 * wave + lrow) & 7;
+    const unsigned w_frag[2] = {(unsigned)(a_off0 + ((lq ^ a_key0) << 4)), (unsigned)(a_off0 + (((4 + lq) ^ a_key0) << 4))};
+
+    // one layer's steps with a compile-time count of 16-row tiles: straight-line code per step (a wave-uniform
+    // `if (m < mt)` around every tile made each tile its own basic block -- LDS read, wait, two MFMAs -- and the kernel
+    // 3.4x slower than its MFMAs: 1.26 us per step)
+    int g = 0;
+    auto run_steps = [&](auto mt_c) {
+        constexpr int MT = decltype(mt_c)::value;
+        for (int s = 0; s < steps_per_layer; ++s, ++g) {
+            // tile g has landed (the one or two younger ones stay in flight); everyone is past step g - 1
+            if (g + 1 < total_steps)
+                chain_wait_vmcnt<4>();
+            else
+                chain_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (g + 2 < total_steps) stage(g + 2);
+            const int tap = s >> 2, chunk = s & 3;
+            // Fragment reads through inline asm with hand-counted waits: through plain loads the compiler cannot prove that
+            // a read does not alias the LDS-DMA requests in flight and drains vmcnt(0) before the first read of every step --
+            // the prefetch of the tile two steps ahead then sits on the critical path of every step (measured: 1.26 us per
+            // step).  LDS returns in order: lgkmcnt(2 + MT) = the first k-half's fragments are there.
+            // addresses: the 16-row tiles of a fragment family differ by a constant (16 rows = 2048 bytes: the swizzle key
+            // (row & 7) does not change), which rides in the instruction's offset field -> two address computations per
+            // operand and step instead of one per read
+            const unsigned wslot = lds0 + ACT_BYTES + (g % NSLOT) * WSLOT;
+            const int rr = lrow + tap;
+            const unsigned arow = lds0 + chunk * ACT_CHUNK + rr * 128;
+            const int akey = rr & 7;
+            bf16x8 wa[2][2], xb[2][MT];
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const unsigned waddr = wslot + w_frag[kh];
+                chain_ds_read128<0>(wa[kh][0], waddr);
+                chain_ds_read128<16 * 128>(wa[kh][1], waddr);
+                const unsigned aaddr = arow + (((kh * 4 + lq) ^ akey) << 4);
+                ChainReadRun<0, MT>::go(xb[kh], aaddr);
+            }
+            ChainWait<MT>::template frags<2 + MT>(wa[0], xb[0]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][0], xb[0][m], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][1], xb[0][m], acc[m][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (keeps the second wait behind the first k-half's MFMAs)
+            ChainWait<MT>::template frags<0>(wa[1], xb[1]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][0], xb[1][m], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][1], xb[1][m], acc[m][1], 0, 0, 0);
+            }
+        }
+    };
+    for (int l = 0; l < n; ++l) {
+        const int rows_out = TM + halo * (n - 1 - l);
+        const int mt = (rows_out + 15) >> 4;
+        switch (mt) {
+            case 4: run_steps(std::integral_constant<int, 4>{}); break;
+            case 5: run_steps(std::integral_constant<int, 5>{}); break;
+            case 6: run_steps(std::integral_constant<int, 6>{}); break;
+            default: run_steps(std::integral_constant<int, 7>{}); break;
+        }
+        // ---- layer epilogue.  D^T tile: lane holds channels cb + 0..3 (cb = 32 * wave + 16 * nt + 4 * (lane >> 4)) of output
+        // row j = 16 * m + (lane & 15), i.e. frame t = t0 - pad' * (n - 1 - l) + j
+        __builtin_amdgcn_s_barrier();  // every wave has finished reading this layer's input rows
+        asm volatile("" ::: "memory");
+        const int t_first = t0 - pad * (n - 1 - l);
+        __bf16* yb = a.y[l] + (long)b * a.bs;
+#pragma unroll
+        for (int m = 0; m < MT_MAX; ++m) {
+            if (m < mt) {
+                const int j = 16 * m + lrow;
+                const int t = t_first + j;
+                const bool live = j < rows_out && t >= 0 && t < a.t_out;
+                const bool core = live && t >= t0 && t < t0 + TM;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int cb = 32 * wave + 16 * nt + 4 * lq;
+                    f32x4 v = acc[m][nt];
+                    acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const long gidx = (long)(a.row0 + t) * a.rs + cb;
+                    if (DGRAD) {
+                        u32x2 mk = {0u, 0u};
+                        if (live) mk = *(const u32x2*)(a.mask[l] + (long)b * a.bs + gidx);
+                        const unsigned m0 = mk[0] & 0xFFFFu, m1 = mk[0] >> 16, m2 = mk[1] & 0xFFFFu, m3 = mk[1] >> 16;
+                        v[0] = (m0 != 0 && m0 < 0x8000u) ? v[0] : 0.f;  // bf16 > 0: sign clear, magnitude non-zero
+                        v[1] = (m1 != 0 && m1 < 0x8000u) ? v[1] : 0.f;
+                        v[2] = (m2 != 0 && m2 < 0x8000u) ? v[2] : 0.f;
+                        v[3] = (m3 != 0 && m3 < 0x8000u) ? v[3] : 0.f;
+                    } else {
+                        const f32x4 bv = *(const f32x4*)(a.bias[l] + cb);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + bv[i], 0.f);
+                    }
+                    u32x2 p;
+                    p[0] = live ? pack_bf16x2(v[0], v[1]) : 0u;
+                    p[1] = live ? pack_bf16x2(v[2], v[3]) : 0u;
+                    // next layer's input row j, channels cb .. cb + 3: chunk cb / 64, slot (cb % 64) / 8 ^ (j & 7)
+                    *(u32x2*)(act + (cb >> 6) * ACT_CHUNK + j * 128 + (((((cb & 63) >> 3)) ^ (j & 7)) << 4) + ((cb & 7) << 1)) = p;
+                    if (core) *(u32x2*)(yb + gidx) = p;
+                }
+            }
+        }
+        __syncthreads();  // the rewritten rows are visible before the next layer reads them
+    }
+}
+
+}  // namespace
+
+// the run must fit the kernel's fixed shape: 256 padded channels in and out, odd taps <= 9, 2..8 layers, every tensor in
+// the same halo'd geometry
+bool conv_chain_bf16_supported(const sl_conv_geom* g, int n_layers) {
+    return g->cin == CH && g->cout == CH && g->taps >= 3 && g->taps <= 9 && (g->taps & 1) == 1 && n_layers >= 2 &&
+           n_layers <= MAX_LAYERS && 16 * MT_MAX >= TM + (g->taps - 1) * (n_layers - 1) &&
+           16 * MT_MAX + g->taps - 1 <= ACT_ROWS && g->x_row_stride == CH && g->y_row_stride == CH &&
+           g->x_batch_stride == g->y_batch_stride && g->x_row0 + g->taps / 2 == g->y_row0;
+}
+
+int conv_chain_bf16(const void* x, void* const* ys, const void* const* ws, const float* const* biases,
+                    const void* const* masks, const sl_conv_geom* g, int n_layers, int epilogue, hipStream_t s) {
+    ChainArgs a;
+    a.x = (const __bf16*)x;
+    for (int i = 0; i < n_layers; ++i) {
+        a.y[i] = (__bf16*)ys[i];
+        a.w[i] = (const __bf16*)ws[i];
+        a.bias[i] = biases ? biases[i] : nullptr;
+        a.mask[i] = masks ? (const __bf16*)masks[i] : nullptr;
+    }
+    a.n_layers = n_layers;
+    a.taps = g->taps;
+    a.pad = g->taps / 2;
+    a.batch = g->batch;
+    a.t_out = g->t_out;
+    a.t_tiles = (g->t_out + TM - 1) / TM;
+    a.row0 = g->y_row0;
+    a.rs = CH;
+    a.bs = g->y_batch_stride;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_chain_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  CHAIN_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_chain_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  CHAIN_LDS);
+        attr_set = true;
+    }
+    const dim3 grid(a.batch * a.t_tiles);
+    sl_prof_begin(s);
+    if (epilogue == SL_EPI_RELU_MASK)
+        hipLaunchKernelGGL(conv_chain_bf16_kernel<true>, grid, dim3(512), CHAIN_LDS, s, a);
+    else
+        hipLaunchKernelGGL(conv_chain_bf16_kernel<false>, grid, dim3(512), CHAIN_LDS, s, a);
+    sl_prof_end(s);
+    return sl_check_launch("sl_conv1d_chain");
+}

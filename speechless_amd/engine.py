@@ -384,6 +384,11 @@ class Engine:
         # (tensor views of the flat parameter buffers, data_ptr() calls, geometry look-ups: ~10 us per launch) was what
         # capped the host-fed loop below the rate of the resident step.  Geometries are passed by reference and
         # re-targeted in place (_Buffers.set_length), so one list serves every batch length of a buffer set.
+        # runs of identical layers (inner_conv_1..7) as ONE launch with the activations kept in LDS (sl_conv1d_chain).
+        # Correct and tested, but measured SLOWER than the seven single launches so far (forward 179 vs 7 x 24.4 = 171 us,
+        # input gradients 207 vs 185 us) -> opt-in
+        self.use_chain = os.environ.get("SL_CHAIN", "0") == "1"
+        self._chain_tables = {}
         self.use_launch_lists = os.environ.get("SL_LAUNCH_LISTS", "1") != "0"
         self._rec = None
         self._adam_tables = {}
@@ -555,6 +560,38 @@ class Engine:
         self._src_keepalive = src
         return buf
 
+    def _chain_table(self, kind, layers, buf):
+        """ctypes pointer tables of sl_conv1d_chain for the given layers (plan indices in launch order), cached per
+        (buffer set, kind).  kind 'fwd': ys = activations, ws = forward operands, biases; kind 'dgrad': layer i of the list
+        is the input gradient of plan i: ys = g[i - 1], ws = dgrad operands, masks = y[i - 1]."""
+        key = (kind, tuple(layers), id(buf))
+        hit = self._chain_tables.get(key)
+        if hit is not None and hit[0] is buf:
+            return hit[1]
+        n = len(layers)
+        arr = ctypes.c_void_p * n
+        if kind == "fwd":
+            ys = arr(*[buf.y[i].data_ptr() for i in layers])
+            ws = arr(*[self.w_fwd[i].data_ptr() for i in layers])
+            aux = arr(*[self.layer_param_views(self.params, self.plans[i])[1].data_ptr() for i in layers])
+        else:
+            ys = arr(*[buf.g[i - 1].data_ptr() for i in layers])
+            ws = arr(*[self.w_dgrad[i].data_ptr() for i in layers])
+            aux = arr(*[buf.y[i - 1].data_ptr() for i in layers])
+        if len(self._chain_tables) > 64:
+            self._chain_tables.clear()
+        self._chain_tables[key] = (buf, (ys, ws, aux))
+        return ys, ws, aux
+
+    def _chain_ok(self, buf, layers):
+        """the fused kernel takes a run of ReLU layers of the bf16 path whose geometry it supports"""
+        if not self.use_chain or self.dtype != "bf16" or len(layers) < 2:
+            return False
+        if any(self.specs[i].activation != "relu" for i in layers):
+            return False
+        return bool(self.lib.raw("sl_conv1d_chain_supported")(ctypes.byref(buf.fwd_geom[layers[0]]), len(layers),
+                                                              self.dtype_code))
+
     def _dropout_layers(self):
         """Indices of the layers with a Dropout in front of them (all but the last three, net.py:326-330)."""
         return range(0, max(len(self.plans) - 3, 0))
@@ -575,7 +612,8 @@ class Engine:
             ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size, self.dtype_code))
         # launch list (no dropout): everything below takes its frame count from the geometries, except the unfused
         # softmax, which gets it by value -> then the list is per length
-        key = None if rate else ("fwd", st, fuse_out, tuple(sorted(self.nt_cfg.items())), None if fuse_out else buf.t_out)
+        key = None if rate else ("fwd", st, fuse_out, self.use_chain, tuple(sorted(self.nt_cfg.items())),
+                                 None if fuse_out else buf.t_out)
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
             self._replay(ops)
@@ -604,8 +642,27 @@ class Engine:
             self._launch("dropout:input", "sl_dropout", buf.x0.data_ptr(), buf.x0_dropped.data_ptr(), buf.x0.numel(),
                          self.dtype_code, rate, seed0, st)
             x = buf.x0_dropped
+        chained = {}  # first layer of a run -> the run, when it goes through sl_conv1d_chain
+        if not rate:
+            for (s0, e0) in self.runs:
+                if e0 < n - 1 and self._chain_ok(buf, list(range(s0, e0 + 1))) and not any(
+                        ("fwd", self.specs[i].name) in self.nt_cfg for i in range(s0, e0 + 1)):
+                    chained[s0] = list(range(s0, e0 + 1))
+        skip_until = -1
         for p in self.plans:
             last = p.index == n - 1
+            if p.index <= skip_until:
+                x = buf.y[p.index]
+                continue
+            if p.index in chained:
+                layers = chained[p.index]
+                ys, ws, biases = self._chain_table("fwd", layers, buf)
+                self._launch("fwd:{}..{}".format(self.specs[layers[0]].name, self.specs[layers[-1]].name),
+                             "sl_conv1d_chain", x.data_ptr(), ys, ws, biases, None, ctypes.byref(buf.fwd_geom[p.index]),
+                             len(layers), _lib.EPI_BIAS_RELU, self.dtype_code, st)
+                skip_until = layers[-1]
+                x = buf.y[p.index]
+                continue
             y = buf.logits if last else buf.y[p.index]
             _, bias = self.layer_param_views(self.params, p)
             if last and fuse_out:  # output layer + softmax + log(p + eps) re-normalisation in one launch
@@ -723,7 +780,7 @@ class Engine:
         # launch list: the default schedule only (no dropout masks to rescale, no early Adam, no second wgrad stream)
         plain = not (early_adam or self.overlap_wgrad or buf.dropped or os.environ.get("SL_DEFER_BGRAD") == "skip")
         key = ("bwd", main.cuda_stream, on_bucket_ready is not None, self.defer_bias_grads, self.frozen_layer_count,
-               self.group_wgrad, tuple(sorted(self.nt_cfg.items()))) if plain else None
+               self.group_wgrad, self.use_chain, tuple(sorted(self.nt_cfg.items()))) if plain else None
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
             self._replay(ops, on_bucket_ready)
@@ -777,6 +834,19 @@ class Engine:
             else:
                 bucket_layers.extend(layers)
 
+        # input gradients of a run of identical ReLU layers in one launch (sl_conv1d_chain): keyed by the TOP layer
+        dchain, dchain_skip = {}, set()
+        if not buf.dropped:
+            for (s0, e0) in self.runs:
+                lo_d = max(s0, first + 1)
+                layers = list(range(e0, lo_d - 1, -1))
+                if len(layers) >= 2 and self.use_chain and self.dtype == "bf16" and \
+                        all(self.specs[i - 1].activation == "relu" for i in layers) and \
+                        not any(("dgrad", self.specs[i].name) in self.nt_cfg for i in layers) and \
+                        bool(self.lib.raw("sl_conv1d_chain_supported")(ctypes.byref(buf.dgrad_geom[e0]), len(layers),
+                                                                       self.dtype_code)):
+                    dchain[e0] = layers
+                    dchain_skip.update(layers[1:])
         # (those two need every layer's bias gradient at once; defer_bias_grads = False restores one hand-over per layer)
         defer = self.defer_bias_grads and not (early_adam or self.overlap_wgrad)
         pending, pending_bytes = [], 0  # layers whose bias-gradient launch is still owed to the side stream
@@ -830,7 +900,16 @@ class Engine:
                 if on_bucket_ready is not None and i == split:
                     join_side()
                     bucket_ready(0)
-            if i > first:
+            if i in dchain:
+                layers = dchain[i]
+                ys, ws, masks = self._chain_table("dgrad", layers, buf)
+                self._launch("dgrad:{}..{}".format(self.specs[layers[0]].name, self.specs[layers[-1]].name),
+                             "sl_conv1d_chain", buf.g[i].data_ptr(), ys, ws, None, masks,
+                             ctypes.byref(buf.dgrad_geom[i]), len(layers), _lib.EPI_RELU_MASK, self.dtype_code,
+                             main.cuda_stream)
+            elif i in dchain_skip:
+                pass
+            elif i > first:
                 elu = self.specs[i - 1].activation == "elu"
                 elu_dropped = elu and buf.dropped and i in self._dropout_layers()
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(),

@@ -667,3 +667,44 @@ def test_recorded_launch_lists_train_exactly_like_the_eager_path(dtype):
     for a, b in zip(results[0][0], results[1][0]):
         assert np.array_equal(a, b)
     assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+
+
+# ------------------------------------------------------------------------------------------ fused run of inner layers
+def test_fused_run_of_inner_layers_against_the_single_launches():
+    """sl_conv1d_chain (inner_conv_1..7 in one launch, activations handed from layer to layer through LDS, halo
+    recomputed per 64-frame tile) against the seven sl_conv1d_nt launches it replaces, forward and input-gradient
+    direction, on batches whose frame counts exercise partial tiles, a single tile and the utterance boundaries: every
+    stored activation / gradient agrees to bf16 round-off of the same fp32 sums in another order, the layout invariants
+    hold, and loss / gradients stay within the bf16 path's tolerances against the oracle's bf16 mirror."""
+    import torch
+    from speechless_amd.engine import HALO
+    for t in (300, 77, 1000):
+        case = make_case(b=3, t=t, seed=70 + t)
+        res = {}
+        for chain in (True, False):
+            eng = make_engine(case, "bf16")
+            eng.use_chain = chain
+            losses, grads = run_loss_and_grads(eng, case)
+            tags = [op[3] for ops in eng.cur.launch_lists.values() for op in ops if op[0] == 0]
+            assert (tags.count("sl_conv1d_chain") == 2) == chain and ("sl_conv1d_chain" in tags) == chain
+            res[chain] = (eng, losses, grads)
+        (ea, la, ga), (eb, lb, gb) = res[True], res[False]
+        t_out = ea.cur.t_out
+        for i in range(len(ea.plans) - 1):
+            ya, yb = ea.cur.y[i].float().cpu().numpy(), eb.cur.y[i].float().cpu().numpy()
+            c = ea.specs[i].cout
+            assert not ya[:, :HALO].any() and not ya[:, HALO + t_out:].any() and not ya[:, :, c:].any(), i
+            scale = max(np.abs(yb).max(), 1e-30)
+            assert np.abs(ya - yb).max() <= 2.0 ** -6 * scale, (t, "y", i, np.abs(ya - yb).max() / scale)
+            assert rel_l2(ya, yb) < 3e-3, (t, "y", i, rel_l2(ya, yb))
+        for i in range(len(ea.plans)):
+            ga_i, gb_i = ea.cur.g[i].float().cpu().numpy(), eb.cur.g[i].float().cpu().numpy()
+            assert not ga_i[:, :HALO].any() and not ga_i[:, HALO + t_out:].any(), i
+            assert rel_l2(ga_i, gb_i) < 3e-2, (t, "g", i, rel_l2(ga_i, gb_i))  # (ReLU-mask flips between the two orders)
+        np.testing.assert_allclose(la, lb, rtol=2e-3)
+        if t == 300:
+            mirror = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), case["labels"],
+                                          case["prediction_lengths"], case["label_lengths"], bf16_mirror=True)
+            np.testing.assert_allclose(la, mirror["losses"], rtol=1e-3)
+            for name, i in (("output_conv", 10), ("big_conv_2", 9), ("big_conv_1", 8)):
+                assert rel_l2(ga[i][0], mirror["grads"][i][0]) < 2e-2, name
