@@ -139,21 +139,33 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     const int w_rs = taps * CH;         // elements per output channel in the packed weights
 
     // ---- weight stream: global step g = (layer, tap, 64-channel chunk); DMA instruction j copies weight rows
-    // [8j, 8j + 8): lane -> row 8j + lane / 8, physical 16-byte slot lane % 8 = logical slot ^ (row & 7)
-    const int wlane_off = (lane >> 3) * w_rs + (((lane & 7) ^ (lane >> 3)) << 3);
-    auto stage = [&](int g) {
-        const int l = g / steps_per_layer;
-        const int s = g - l * steps_per_layer;
-        const __bf16* src = a.w[l] + (long)s * 64 + wlane_off;  // (tap, chunk) pieces are consecutive: s * 64 elements
-        char* dst = wring + (g % NSLOT) * WSLOT;
+    // [8j, 8j + 8): lane -> row 8j + lane / 8, physical 16-byte slot lane % 8 = logical slot ^ (row & 7).  The request
+    // stream advances by increments (a uniform base pointer + four loop-invariant per-lane offsets, ring slot rotated): the
+    // first version recomputed (layer, step) and the slot from g with integer divisions -- 73 scalar instructions per step
+    // and wave (PMC: SQ_INSTS_SALU), more issue slots than the step's 22 MFMAs + 32 LDS instructions together.
+    int voff[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = wave * 4 + q;
-            chain_glds16(src + (long)(8 * j) * w_rs, dst + j * 1024);
-        }
+    for (int q = 0; q < 4; ++q)
+        voff[q] = (8 * (wave * 4 + q) + (lane >> 3)) * w_rs + (((lane & 7) ^ (lane >> 3)) << 3);
+    // Branch-free: past the last tile the last one is requested again (into a slot nobody reads any more), which also keeps
+    // the vmcnt bookkeeping uniform -- one younger request of four instructions is outstanding at every wait.
+    const __bf16* st_src = a.w[0];  // (uniform) source of the next tile to request
+    int st_layer = 0, st_step = 0, st_slot = 0, st_left = total_steps;
+    auto stage_next = [&]() {
+        char* dst = wring + st_slot * WSLOT + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) chain_glds16(st_src + voff[q], dst + q * 1024);
+        st_slot = st_slot == NSLOT - 1 ? 0 : st_slot + 1;
+        const bool more = st_left > 1;
+        const bool wrap = more && st_step + 1 == steps_per_layer;
+        st_left -= more ? 1 : 0;
+        st_layer += wrap ? 1 : 0;
+        st_step = wrap ? 0 : st_step + (more ? 1 : 0);
+        const __bf16* layer_base = a.w[st_layer];
+        st_src = wrap ? layer_base : st_src + (more ? 64 : 0);  // (tap, chunk) pieces of a layer are consecutive
     };
-    stage(0);
-    if (total_steps > 1) stage(1);
+    stage_next();
+    stage_next();
 
     // ---- input rows of the first layer: frames t0 - pad * n .. (64 + halo * n rows), zero outside [0, T')
     {
@@ -186,24 +198,21 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     int g = 0;
     auto run_steps = [&](auto mt_c) {
         constexpr int MT = decltype(mt_c)::value;
+        int cur_slot = g % NSLOT;
         for (int s = 0; s < steps_per_layer; ++s, ++g) {
-            // tile g has landed (the one or two younger ones stay in flight); everyone is past step g - 1
-            if (g + 1 < total_steps)
-                chain_wait_vmcnt<4>();
-            else
-                chain_wait_vmcnt<0>();
+            // tile g has landed (the younger request stays in flight); everyone is past tile g - 1
+            chain_wait_vmcnt<4>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (g + 2 < total_steps) stage(g + 2);
+            stage_next();  // tile g + 2 into the slot tile g - 1 has left
             const int tap = s >> 2, chunk = s & 3;
-            // Fragment reads through inline asm with hand-counted waits: through plain loads the compiler cannot prove that
-            // a read does not alias the LDS-DMA requests in flight and drains vmcnt(0) before the first read of every step --
-            // the prefetch of the tile two steps ahead then sits on the critical path of every step (measured: 1.26 us per
-            // step).  LDS returns in order: lgkmcnt(2 + MT) = the first k-half's fragments are there.
-            // addresses: the 16-row tiles of a fragment family differ by a constant (16 rows = 2048 bytes: the swizzle key
-            // (row & 7) does not change), which rides in the instruction's offset field -> two address computations per
-            // operand and step instead of one per read
-            const unsigned wslot = lds0 + ACT_BYTES + (g % NSLOT) * WSLOT;
+            // fragment reads go through inline asm with hand-counted waits: through plain loads the compiler drains
+            // vmcnt(0) before the first read of every step (it cannot prove that a read does not alias the LDS-DMA requests
+            // in flight).  The 16-row tiles of a fragment family differ by a constant (16 rows = 2048 bytes: the swizzle key
+            // (row & 7) does not change), which rides in the instruction's offset field.  LDS returns in order:
+            // lgkmcnt(2 + MT) = the first k-half's fragments are there.
+            const unsigned wslot = lds0 + ACT_BYTES + cur_slot * WSLOT;
+            cur_slot = cur_slot == NSLOT - 1 ? 0 : cur_slot + 1;
             const int rr = lrow + tap;
             const unsigned arow = lds0 + chunk * ACT_CHUNK + rr * 128;
             const int akey = rr & 7;
@@ -213,8 +222,7 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
                 const unsigned waddr = wslot + w_frag[kh];
                 chain_ds_read128<0>(wa[kh][0], waddr);
                 chain_ds_read128<16 * 128>(wa[kh][1], waddr);
-                const unsigned aaddr = arow + (((kh * 4 + lq) ^ akey) << 4);
-                ChainReadRun<0, MT>::go(xb[kh], aaddr);
+                ChainReadRun<0, MT>::go(xb[kh], arow + (((kh * 4 + lq) ^ akey) << 4));
             }
             ChainWait<MT>::template frags<2 + MT>(wa[0], xb[0]);
 #pragma unroll
@@ -283,6 +291,7 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
         }
         __syncthreads();  // the rewritten rows are visible before the next layer reads them
     }
+    chain_wait_vmcnt<0>();  // (the surplus requests of the branch-free stream must not outlive the work-group's LDS)
 }
 
 }  // namespace
