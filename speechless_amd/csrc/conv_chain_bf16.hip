@@ -153,8 +153,12 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     int st_layer = 0, st_step = 0, st_slot = 0, st_left = total_steps;
     auto stage_next = [&]() {
         char* dst = wring + st_slot * WSLOT + wave * 4096;
+#if !defined(SL_CHAIN_PROBE_NO_DMA)  // SL_CHAIN_PROBE_*: timing probes, wrong results by construction
 #pragma unroll
         for (int q = 0; q < 4; ++q) chain_glds16(st_src + voff[q], dst + q * 1024);
+#else
+        (void)dst;
+#endif
         st_slot = st_slot == NSLOT - 1 ? 0 : st_slot + 1;
         const bool more = st_left > 1;
         const bool wrap = more && st_step + 1 == steps_per_layer;
@@ -195,14 +199,18 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     // one layer's steps with a compile-time count of 16-row tiles: straight-line code per step (a wave-uniform
     // `if (m < mt)` around every tile made each tile its own basic block -- LDS read, wait, two MFMAs -- and the kernel
     // 3.4x slower than its MFMAs: 1.26 us per step)
-    int g = 0;
+    int cur_slot = 0;
     auto run_steps = [&](auto mt_c) {
         constexpr int MT = decltype(mt_c)::value;
-        int cur_slot = g % NSLOT;
-        for (int s = 0; s < steps_per_layer; ++s, ++g) {
-            // tile g has landed (the younger request stays in flight); everyone is past tile g - 1
-            chain_wait_vmcnt<4>();
+        for (int s = 0; s < steps_per_layer; ++s) {
+            // A wave requests exactly the weight rows it reads itself (rows [32 wave, 32 wave + 32) of every tile), so the
+            // ring needs no barrier: the wave's own counted vmcnt orders its reads behind its requests, and the slot that is
+            // re-requested here was last read two steps ago (retired by that step's lgkmcnt(0)).  The eight waves drift
+            // apart inside a layer -- one wave's request / read phase runs under its SIMD partner's MFMAs.
+            chain_wait_vmcnt<4>();  // tile g has landed (the younger request stays in flight)
+#if defined(SL_CHAIN_PROBE_BARRIER)
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
             stage_next();  // tile g + 2 into the slot tile g - 1 has left
             const int tap = s >> 2, chunk = s & 3;
@@ -217,6 +225,15 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
             const unsigned arow = lds0 + chunk * ACT_CHUNK + rr * 128;
             const int akey = rr & 7;
             bf16x8 wa[2][2], xb[2][MT];
+#if defined(SL_CHAIN_PROBE_NO_READS)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                wa[kh][0] = wa[kh][1] = (bf16x8){};
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xb[kh][m] = (bf16x8){};
+            }
+            (void)wslot; (void)arow; (void)akey;
+#else
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
                 const unsigned waddr = wslot + w_frag[kh];
@@ -224,24 +241,42 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
                 chain_ds_read128<16 * 128>(wa[kh][1], waddr);
                 ChainReadRun<0, MT>::go(xb[kh], arow + (((kh * 4 + lq) ^ akey) << 4));
             }
+#endif
             ChainWait<MT>::template frags<2 + MT>(wa[0], xb[0]);
+#if !defined(SL_CHAIN_PROBE_NO_MFMA)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][0], xb[0][m], acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][1], xb[0][m], acc[m][1], 0, 0, 0);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);  // (keeps the second wait behind the first k-half's MFMAs)
             ChainWait<MT>::template frags<0>(wa[1], xb[1]);
+#if !defined(SL_CHAIN_PROBE_NO_MFMA)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][0], xb[1][m], acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][1], xb[1][m], acc[m][1], 0, 0, 0);
             }
+#endif
         }
     };
     for (int l = 0; l < n; ++l) {
         const int rows_out = TM + halo * (n - 1 - l);
         const int mt = (rows_out + 15) >> 4;
+        // this wave's bias values, requested before the layer's steps (a load in the epilogue is a full L2 round trip
+        // with every MFMA pipe idle)
+        f32x4 bv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        if (!DGRAD) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bv[nt] = *(const f32x4*)(a.bias[l] + 32 * wave + 16 * nt + 4 * lq);
+        }
+#if defined(SL_CHAIN_PROBE_NO_EPILOGUE)
+        if (l > 0 && a.batch > 0) {
+            run_steps(std::integral_constant<int, 5>{});
+            continue;
+        }
+#endif
         switch (mt) {
             case 4: run_steps(std::integral_constant<int, 4>{}); break;
             case 5: run_steps(std::integral_constant<int, 5>{}); break;
@@ -250,10 +285,25 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
         }
         // ---- layer epilogue.  D^T tile: lane holds channels cb + 0..3 (cb = 32 * wave + 16 * nt + 4 * (lane >> 4)) of output
         // row j = 16 * m + (lane & 15), i.e. frame t = t0 - pad' * (n - 1 - l) + j
-        __builtin_amdgcn_s_barrier();  // every wave has finished reading this layer's input rows
-        asm volatile("" ::: "memory");
         const int t_first = t0 - pad * (n - 1 - l);
         __bf16* yb = a.y[l] + (long)b * a.bs;
+        u32x2 mk[MT_MAX][2];
+        if (DGRAD) {  // the ReLU masks are requested before the barrier, not behind it
+#pragma unroll
+            for (int m = 0; m < MT_MAX; ++m) {
+                const int j = 16 * m + lrow;
+                const int t = t_first + j;
+                const bool live = m < mt && j < rows_out && t >= 0 && t < a.t_out;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    mk[m][nt] = (u32x2){0u, 0u};
+                    if (live)
+                        mk[m][nt] = *(const u32x2*)(a.mask[l] + (long)b * a.bs + (long)(a.row0 + t) * a.rs + 32 * wave + 16 * nt + 4 * lq);
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();  // every wave has finished reading this layer's input rows
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int m = 0; m < MT_MAX; ++m) {
             if (m < mt) {
@@ -268,17 +318,15 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
                     acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     const long gidx = (long)(a.row0 + t) * a.rs + cb;
                     if (DGRAD) {
-                        u32x2 mk = {0u, 0u};
-                        if (live) mk = *(const u32x2*)(a.mask[l] + (long)b * a.bs + gidx);
-                        const unsigned m0 = mk[0] & 0xFFFFu, m1 = mk[0] >> 16, m2 = mk[1] & 0xFFFFu, m3 = mk[1] >> 16;
+                        const unsigned m0 = mk[m][nt][0] & 0xFFFFu, m1 = mk[m][nt][0] >> 16, m2 = mk[m][nt][1] & 0xFFFFu,
+                                       m3 = mk[m][nt][1] >> 16;
                         v[0] = (m0 != 0 && m0 < 0x8000u) ? v[0] : 0.f;  // bf16 > 0: sign clear, magnitude non-zero
                         v[1] = (m1 != 0 && m1 < 0x8000u) ? v[1] : 0.f;
                         v[2] = (m2 != 0 && m2 < 0x8000u) ? v[2] : 0.f;
                         v[3] = (m3 != 0 && m3 < 0x8000u) ? v[3] : 0.f;
                     } else {
-                        const f32x4 bv = *(const f32x4*)(a.bias[l] + cb);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + bv[i], 0.f);
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + bv[nt][i], 0.f);
                     }
                     u32x2 p;
                     p[0] = live ? pack_bf16x2(v[0], v[1]) : 0u;
@@ -289,7 +337,11 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
                 }
             }
         }
-        __syncthreads();  // the rewritten rows are visible before the next layer reads them
+        // the rewritten rows are visible before the next layer reads them (not __syncthreads(): its fence would drain the
+        // weight requests in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     chain_wait_vmcnt<0>();  // (the surplus requests of the branch-free stream must not outlive the work-group's LDS)
 }
