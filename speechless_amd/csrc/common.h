@@ -51,6 +51,16 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
 }
+// the same rounding in one instruction (v_cvt_pk_bf16_f32, gfx950); differs from the software form only on NaN payloads
+typedef float sl_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 sl_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short sl_s16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short sl_u16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int pack_bf16x2_hw(float lo, float hi) {
+    const sl_f32x2_t v = {lo, hi};
+    const sl_bf16x2_t h = __builtin_convertvector(v, sl_bf16x2_t);
+    return __builtin_bit_cast(unsigned int, h);
+}
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
 
 // XCD-aware work-group remap: the dispatcher places block b on XCD b % 8 (speed only, never correctness).

@@ -118,6 +118,19 @@ struct ChainWait<7> {
     }
 };
 
+#if defined(SL_CHAIN_PROBE_TIMES)  // s_memtime stamps per wave: [work-group][wave][40]: begin, after the input rows, per layer
+                                   // {steps done, past barrier 1, epilogue done, past barrier 2}, end (tools/chain_stamps.py)
+__device__ unsigned long long chain_probe_times[1024 * 8 * 40];
+#define SL_CHAIN_STAMP(i)                                                        \
+    do {                                                                         \
+        unsigned long long t_;                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        if (lane == 0 && blockIdx.x < 1024) chain_probe_times[(blockIdx.x * 8 + wave) * 40 + (i)] = t_; \
+    } while (0)
+#else
+#define SL_CHAIN_STAMP(i)
+#endif
+
 template <bool DGRAD>
 __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -137,6 +150,7 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     const int steps_per_layer = taps * 4;
     const int total_steps = n * steps_per_layer;
     const int w_rs = taps * CH;         // elements per output channel in the packed weights
+    SL_CHAIN_STAMP(0);
 
     // ---- weight stream: global step g = (layer, tap, 64-channel chunk); DMA instruction j copies weight rows
     // [8j, 8j + 8): lane -> row 8j + lane / 8, physical 16-byte slot lane % 8 = logical slot ^ (row & 7).  The request
@@ -171,19 +185,23 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     stage_next();
     stage_next();
 
-    // ---- input rows of the first layer: frames t0 - pad * n .. (64 + halo * n rows), zero outside [0, T')
+    // ---- input rows of the first layer: frames t0 - pad * n .. (64 + halo * n rows), through LDS-DMA like the weights
+    // (piece = 8 rows of one 64-channel chunk = 1 KB; lane -> row 8 * group + lane / 8, physical slot lane % 8).  Frames
+    // outside the utterance come from a zero row of the tensor itself: [-row0, 0) and [T', T' + 1) are halo / padding rows.
     {
-        const int rows_in = TM + halo * n;
+        const int groups = (TM + halo * n + 7) >> 3;
         const __bf16* xb = a.x + (long)b * a.bs;
-        for (int idx = tid; idx < rows_in * 32; idx += 512) {
-            const int r = idx >> 5, slot = idx & 31;
-            const int t = t0 - pad * n + r;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (t >= 0 && t < a.t_out) v = *(const u32x4*)(xb + (long)(a.row0 + t) * a.rs + slot * 8);
-            *(u32x4*)(act + (slot >> 3) * ACT_CHUNK + r * 128 + (((slot & 7) ^ (r & 7)) << 4)) = v;
+        for (int pc = wave; pc < 4 * groups; pc += 8) {
+            const int c = pc & 3, rg = pc >> 2;
+            const int r = rg * 8 + (lane >> 3);
+            const int t = min(max(t0 - pad * n + r, -a.row0), a.t_out);
+            chain_glds16(xb + (long)(a.row0 + t) * a.rs + c * 64 + (((lane & 7) ^ (r & 7)) << 3),
+                         act + c * ACT_CHUNK + rg * 1024);
         }
+        chain_wait_vmcnt<0>();
     }
     __syncthreads();
+    SL_CHAIN_STAMP(1);
 
     f32x4 acc[MT_MAX][2];
 #pragma unroll
@@ -195,6 +213,14 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     // weight fragment rows of this lane: channel 32 * wave + 16 * nt + lrow; byte offsets inside a ring slot per k-half
     const int a_off0 = (32 * wave + lrow) * 128, a_key0 = (32 * wave + lrow) & 7;
     const unsigned w_frag[2] = {(unsigned)(a_off0 + ((lq ^ a_key0) << 4)), (unsigned)(a_off0 + (((4 + lq) ^ a_key0) << 4))};
+
+    // epilogue: LDS byte offset of (row lrow, channels cb .. cb + 3): chunk cb / 64, 16-byte slot (cb % 64) / 8 ^ (row & 7)
+    unsigned lds_w[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int cb = 32 * wave + 16 * nt + 4 * lq;
+        lds_w[nt] = (cb >> 6) * ACT_CHUNK + lrow * 128 + ((((cb & 63) >> 3) ^ (lrow & 7)) << 4) + ((cb & 7) << 1);
+    }
 
     // one layer's steps with a compile-time count of 16-row tiles: straight-line code per step (a wave-uniform
     // `if (m < mt)` around every tile made each tile its own basic block -- LDS read, wait, two MFMAs -- and the kernel
@@ -284,65 +310,123 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
             default: run_steps(std::integral_constant<int, 7>{}); break;
         }
         // ---- layer epilogue.  D^T tile: lane holds channels cb + 0..3 (cb = 32 * wave + 16 * nt + 4 * (lane >> 4)) of output
-        // row j = 16 * m + (lane & 15), i.e. frame t = t0 - pad' * (n - 1 - l) + j
+        // row j = 16 * m + (lane & 15), i.e. frame t = t_first + j.  The epilogue is VALU work with every MFMA pipe idle (two
+        // waves per SIMD share the VALU): its first version -- per-tile 64-bit addresses, software bf16 rounding, per-element
+        // liveness selects -- was 45 instructions per tile = 2.7 us per layer.  Now: addresses = per-lane bases + immediate
+        // offsets, v_cvt_pk_bf16_f32, and the zeroing of out-of-utterance rows only in work-groups that have such rows.
+        SL_CHAIN_STAMP(2 + 4 * l);
+        // ---- layer epilogue.  D^T tile: lane holds channels cb + 0..3 (cb = 32 * wave + 16 * nt + 4 * (lane >> 4)) of output
+        // row j = 16 * m + (lane & 15), i.e. frame t = t_first + j.  Everything here runs with the MFMA pipes idle, and the
+        // first version was 20 % of the kernel: (a) 45 VALU instructions per tile (64-bit addresses, software bf16 rounding,
+        // per-element selects; two waves share a SIMD's VALU) and (b) 8-byte-per-lane HBM stores and ReLU-mask loads in the
+        // tile layout: 16 different 128-byte lines per instruction, 1800 line transactions per layer and work-group, and
+        // their issue stalls (s_memtime stamps: 5000 cycles per layer forward, 11 000 backward).  Now the tiles only go to
+        // LDS (per-lane base addresses + immediate offsets, v_cvt_pk_bf16_f32), and the HBM side is row-contiguous from the
+        // LDS copy: 16 bytes per lane, every line written / read once.
         const int t_first = t0 - pad * (n - 1 - l);
         __bf16* yb = a.y[l] + (long)b * a.bs;
-        u32x2 mk[MT_MAX][2];
-        if (DGRAD) {  // the ReLU masks are requested before the barrier, not behind it
+        const int jc0 = t0 - t_first, jc_n = min(TM, a.t_out - t0);                 // core rows: j - jc0 in [0, jc_n)
+        const int jl0 = max(0, -t_first), jl_n = min(16 * mt, a.t_out - t_first) - jl0;  // rows inside the utterance
+        const bool edge = t_first < 0 || t_first + 16 * mt > a.t_out;
+        // piece i of the row-contiguous view: row 16 i + 2 wave + lane / 32, 16-byte slot lane % 32 of the row's 512 bytes
+        const int prow = 2 * wave + (lane >> 5), pslot = lane & 31;
+        const unsigned plds = lds0 + (pslot >> 3) * ACT_CHUNK + prow * 128 + (((pslot & 7) ^ (prow & 7)) << 4);  // + 2048 i
+        u32x4 mk[MT_MAX];
+        if (DGRAD) {  // ReLU masks (the stored forward activations) of all rows, requested before the barrier; rows outside
+                      // the utterance read a zero halo / padding row, which also zeroes their gradient
+            const __bf16* mb = a.mask[l] + (long)b * a.bs;  // (uniform base + 32-bit lane offset: one VGPR per address)
 #pragma unroll
-            for (int m = 0; m < MT_MAX; ++m) {
-                const int j = 16 * m + lrow;
-                const int t = t_first + j;
-                const bool live = m < mt && j < rows_out && t >= 0 && t < a.t_out;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    mk[m][nt] = (u32x2){0u, 0u};
-                    if (live)
-                        mk[m][nt] = *(const u32x2*)(a.mask[l] + (long)b * a.bs + (long)(a.row0 + t) * a.rs + 32 * wave + 16 * nt + 4 * lq);
-                }
+            for (int i = 0; i < MT_MAX; ++i) {  // (all seven pieces whatever mt is: straight-line code, rows stay in bounds)
+                const int t = min(max(t_first + 16 * i + prow, -a.row0), a.t_out);
+                mk[i] = *(const u32x4*)(mb + (unsigned)((a.row0 + t) * CH + pslot * 8));
             }
         }
         __builtin_amdgcn_s_barrier();  // every wave has finished reading this layer's input rows
         asm volatile("" ::: "memory");
+        SL_CHAIN_STAMP(3 + 4 * l);
+        auto epilogue = [&](auto edge_c) {
+            constexpr bool EDGE = decltype(edge_c)::value;
 #pragma unroll
-        for (int m = 0; m < MT_MAX; ++m) {
-            if (m < mt) {
-                const int j = 16 * m + lrow;
-                const int t = t_first + j;
-                const bool live = j < rows_out && t >= 0 && t < a.t_out;
-                const bool core = live && t >= t0 && t < t0 + TM;
+            for (int m = 0; m < MT_MAX; ++m) {
+                if (m < mt) {
+                    const bool live = !EDGE || (unsigned)(16 * m + lrow - jl0) < (unsigned)jl_n;
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int cb = 32 * wave + 16 * nt + 4 * lq;
-                    f32x4 v = acc[m][nt];
-                    acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    const long gidx = (long)(a.row0 + t) * a.rs + cb;
-                    if (DGRAD) {
-                        const unsigned m0 = mk[m][nt][0] & 0xFFFFu, m1 = mk[m][nt][0] >> 16, m2 = mk[m][nt][1] & 0xFFFFu,
-                                       m3 = mk[m][nt][1] >> 16;
-                        v[0] = (m0 != 0 && m0 < 0x8000u) ? v[0] : 0.f;  // bf16 > 0: sign clear, magnitude non-zero
-                        v[1] = (m1 != 0 && m1 < 0x8000u) ? v[1] : 0.f;
-                        v[2] = (m2 != 0 && m2 < 0x8000u) ? v[2] : 0.f;
-                        v[3] = (m3 != 0 && m3 < 0x8000u) ? v[3] : 0.f;
-                    } else {
+                    for (int nt = 0; nt < 2; ++nt) {
+                        f32x4 v = acc[m][nt];
+                        acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (!DGRAD) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + bv[nt][i], 0.f);
+                            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] + bv[nt][i], 0.f);
+                        }
+                        u32x2 pk;
+                        pk[0] = pack_bf16x2_hw(v[0], v[1]);
+                        pk[1] = pack_bf16x2_hw(v[2], v[3]);
+                        if (EDGE && !DGRAD) {  // SAME padding: relu(bias) is not zero
+                            pk[0] = live ? pk[0] : 0u;
+                            pk[1] = live ? pk[1] : 0u;
+                        }
+                        // next layer's input row j, channels cb .. cb + 3 (16 rows on = 2048 bytes, same swizzle key)
+                        *(u32x2*)(act + lds_w[nt] + m * 2048) = pk;
                     }
-                    u32x2 p;
-                    p[0] = live ? pack_bf16x2(v[0], v[1]) : 0u;
-                    p[1] = live ? pack_bf16x2(v[2], v[3]) : 0u;
-                    // next layer's input row j, channels cb .. cb + 3: chunk cb / 64, slot (cb % 64) / 8 ^ (j & 7)
-                    *(u32x2*)(act + (cb >> 6) * ACT_CHUNK + j * 128 + (((((cb & 63) >> 3)) ^ (j & 7)) << 4) + ((cb & 7) << 1)) = p;
-                    if (core) *(u32x2*)(yb + gidx) = p;
                 }
             }
-        }
-        // the rewritten rows are visible before the next layer reads them (not __syncthreads(): its fence would drain the
-        // weight requests in flight)
+        };
+        if (edge && !DGRAD)
+            epilogue(std::true_type{});
+        else
+            epilogue(std::false_type{});
+        SL_CHAIN_STAMP(4 + 4 * l);
+        // the rewritten rows are visible (not __syncthreads(): its fence would drain the weight requests in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (DGRAD) {
+            // masking pass over ALL rows (the next layer consumes the halo rows too), HBM store of the core rows
+            u32x4 gq[MT_MAX];
+#pragma unroll
+            for (int i = 0; i < MT_MAX; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(gq[i]) : "v"(plds), "n"(i * 2048));
+            // (the registers are operands of the wait: no use of them can be scheduled above it)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(gq[0]), "+v"(gq[1]), "+v"(gq[2]), "+v"(gq[3]), "+v"(gq[4]), "+v"(gq[5]), "+v"(gq[6])
+                         :
+                         : "memory");
+            static_assert(MT_MAX == 7, "the wait above names seven registers");
+#pragma unroll
+            for (int i = 0; i < MT_MAX; ++i) {
+                {
+                    // per bf16: forward activation > 0 ? g : 0  ==  g * min(max(bits as int16, 0), 1)
+                    const sl_s16x8_t k = __builtin_bit_cast(sl_s16x8_t, mk[i]);
+                    const sl_s16x8_t keep = __builtin_elementwise_min(__builtin_elementwise_max(k, (sl_s16x8_t)(0)), (sl_s16x8_t)(1));
+                    const sl_u16x8_t prod = __builtin_bit_cast(sl_u16x8_t, gq[i]) * __builtin_bit_cast(sl_u16x8_t, keep);
+                    const u32x4 o = __builtin_bit_cast(u32x4, prod);
+                    const int j = 16 * i + prow;
+                    *(u32x4*)(act + (plds - lds0) + i * 2048) = o;
+                    if ((unsigned)(j - jc0) < (unsigned)jc_n)
+                        *(u32x4*)(yb + (unsigned)((a.row0 + t_first + j) * CH + pslot * 8)) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            // HBM store of the core rows from the LDS copy (4 pieces per wave)
+            const int crow = jc0 + prow;
+            const unsigned clds = lds0 + (pslot >> 3) * ACT_CHUNK + crow * 128 + (((pslot & 7) ^ (crow & 7)) << 4);
+            u32x4 cq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cq[i]) : "v"(clds), "n"(i * 2048));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]) : : "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 o = cq[i];
+                const int j = 16 * i + prow;  // (relative to the first core row)
+                if (j < jc_n) *(u32x4*)(yb + (unsigned)((a.row0 + t0 + j) * CH + pslot * 8)) = o;
+            }
+        }
+        SL_CHAIN_STAMP(5 + 4 * l);
     }
+    SL_CHAIN_STAMP(38);
     chain_wait_vmcnt<0>();  // (the surplus requests of the branch-free stream must not outlive the work-group's LDS)
 }
 
@@ -356,6 +440,12 @@ bool conv_chain_bf16_supported(const sl_conv_geom* g, int n_layers) {
            16 * MT_MAX + g->taps - 1 <= ACT_ROWS && g->x_row_stride == CH && g->y_row_stride == CH &&
            g->x_batch_stride == g->y_batch_stride && g->x_row0 + g->taps / 2 == g->y_row0;
 }
+
+#if defined(SL_CHAIN_PROBE_TIMES)
+extern "C" int sl_chain_probe_read(void* host_dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(chain_probe_times), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 int conv_chain_bf16(const void* x, void* const* ys, const void* const* ws, const float* const* biases,
                     const void* const* masks, const sl_conv_geom* g, int n_layers, int epilogue, hipStream_t s) {
