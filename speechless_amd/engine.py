@@ -384,10 +384,10 @@ class Engine:
         # (tensor views of the flat parameter buffers, data_ptr() calls, geometry look-ups: ~10 us per launch) was what
         # capped the host-fed loop below the rate of the resident step.  Geometries are passed by reference and
         # re-targeted in place (_Buffers.set_length), so one list serves every batch length of a buffer set.
-        # runs of identical layers (inner_conv_1..7) as ONE launch with the activations kept in LDS (sl_conv1d_chain).
-        # Correct and tested, but measured SLOWER than the seven single launches so far (forward 179 vs 7 x 24.4 = 171 us,
-        # input gradients 207 vs 185 us) -> opt-in
-        self.use_chain = os.environ.get("SL_CHAIN", "0") == "1"
+        # runs of identical layers (inner_conv_1..7) as ONE launch with the activations kept in LDS (sl_conv1d_chain):
+        # forward 124 us against 7 x 23.6 = 165 us of single launches, input gradients 126 against 185 (config 3;
+        # DESIGN.md section 3.1).  SL_CHAIN=0 restores the single launches (A/B measurements).
+        self.use_chain = os.environ.get("SL_CHAIN", "1") == "1"
         self._chain_tables = {}
         self.use_launch_lists = os.environ.get("SL_LAUNCH_LISTS", "1") != "0"
         self._rec = None
