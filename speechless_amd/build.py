@@ -41,9 +41,14 @@ def _scratch_users(remarks):
     return bad
 
 
+# ctc.hip: the probability-domain lattice is a lone wave's dependent chain of scalar fp32 operations; packed fp32 VALU
+# (v_pk_mul_f32 out of the SLP vectorizer) costs such a wave more than the two scalar instructions it replaces
+FILE_FLAGS = {"ctc.hip": ["-fno-slp-vectorize"]}
+
+
 def _compile(src):
     obj = CSRC / (src.replace(".hip", ".o"))
-    cmd = [HIPCC] + FLAGS + ["-c", str(CSRC / src), "-o", str(obj)]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", str(CSRC / src), "-o", str(obj)]
     if src in NO_SCRATCH:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)

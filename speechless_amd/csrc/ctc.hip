@@ -19,6 +19,8 @@
 //   greedy_decode_kernel: one work-group per utterance: argmax (first max wins), merge repeats, drop blank, compact.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 // The lattice lives in LOG2 units: v_exp_f32 / v_log_f32 are base-2 natively, so a 3-way log-sum-exp is 3 + 1 raw
@@ -231,7 +233,7 @@ __device__ __forceinline__ float log2_of_double(double x) {
 // u = p + eps instead of q) and is brought to log2 units on the fly; the sum of a frame's state posteriors must then be
 // 1 -- if the linear lattice lost mass to underflow it is not, and the utterance is flagged for the log-domain repair
 // pass.  only_flagged: this launch IS the repair pass (log-domain lattice): utterances that are not flagged are skipped.
-template <int NJ, bool LIN>
+template <int NJ, int LIN>  // LIN: 0 = log-domain rows; 1 = linear rows in doubles (exponent blocks of 16); 2 = in floats (of 8)
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ probs, const float* __restrict__ logq,
                                                        const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ label_len,
@@ -291,31 +293,36 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                 float av[NJ], bv[NJ];  // LIN: av = fractional part (log2 of the two mantissas), bv unused, ai = integer part
                 int ai[NJ];
                 if (LIN) {
-                    const double* al = (const double*)alpha_v + fidx * sp;
-                    const double* be = (const double*)beta_v + fidx * sp;
-                    double ad[NJ], bd[NJ];
+                    typedef typename std::conditional<LIN == 2, float, double>::type RT;
+                    RT ad[NJ], bd[NJ];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {  // only the live part of the row was written: s < S rounded up to 8
                         const bool in = lane + 64 * j < ((S + 7) & ~7);
-                        ad[j] = in ? al[lane + 64 * j] : 0.0;
-                        bd[j] = in ? be[lane + 64 * j] : 0.0;
+                        if (LIN == 1) {
+                            ad[j] = in ? (RT)((const double*)alpha_v)[fidx * sp + lane + 64 * j] : (RT)0;
+                            bd[j] = in ? (RT)((const double*)beta_v)[fidx * sp + lane + 64 * j] : (RT)0;
+                        } else {
+                            ad[j] = in ? (RT)((const float*)alpha_v)[fidx * sp + lane + 64 * j] : (RT)0;
+                            bd[j] = in ? (RT)((const float*)beta_v)[fidx * sp + lane + 64 * j] : (RT)0;
+                        }
                     }
                     // exponents: one per block of 16 steps of the respective direction (alpha: step = t, beta: T-1-t)
                     // Exponents add up to tens of thousands over a long utterance while the posterior needs the FRACTION of
                     // the log2 to 1e-3: integer parts (block exponents, frexp exponents, the integer part of log2 Z) are
                     // summed exactly, only the mantissa logarithms go through fp32.
                     // (one exponent per lattice lane = 8 states and block of 16 steps of the respective direction)
-                    const int32_t* eap = ea + ((long)b * (t_out / 16 + 1) + (t >> 4)) * 64;
-                    const int32_t* ebp = eb + ((long)b * (t_out / 16 + 1) + ((T - 1 - t) >> 4)) * 64;
+                    constexpr int RBS = LIN == 2 ? 3 : 4;  // log2 of the frames per exponent block
+                    const int32_t* eap = ea + ((long)b * ((t_out >> RBS) + 1) + (t >> RBS)) * 64;
+                    const int32_t* ebp = eb + ((long)b * ((t_out >> RBS) + 1) + ((T - 1 - t) >> RBS)) * 64;
                     const int zi = zint[b];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const int wl = (lane + 64 * j) >> 3;
                         const int eab = eap[wl] + ebp[wl] - zi;
                         // a state the other direction cannot reach has posterior 0 whatever this direction holds
-                        const bool dead = ad[j] == 0.0 || bd[j] == 0.0;
+                        const bool dead = !(ad[j] > (RT)0 && bd[j] > (RT)0 && ad[j] < (RT)INFINITY && bd[j] < (RT)INFINITY);
                         int xa, xb;
-                        const double ma = frexp(dead ? 1.0 : ad[j], &xa), mb = frexp(dead ? 1.0 : bd[j], &xb);
+                        const RT ma = frexp(dead ? (RT)1 : ad[j], &xa), mb = frexp(dead ? (RT)1 : bd[j], &xb);
                         av[j] = dead ? -INFINITY : __builtin_amdgcn_logf((float)ma) + __builtin_amdgcn_logf((float)mb);
                         ai[j] = eab + xa + xb;
                         bv[j] = 0.f;
@@ -405,8 +412,25 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 // underflows; whether that lost anything is checked by the gradient kernel (sum of a frame's posteriors = 1), and a
 // flagged utterance is redone by the log-domain kernels (repair pass, normally two empty launches).
 constexpr int WNS = 8;         // states per lane
-constexpr int WTARGET = 500;   // exponent the relevant maximum is rescaled to
-constexpr int WRESCALE = 16;   // frames between rescales (two prefetch chunks)
+
+// Number type of the lattice.  double: 2^+-1022 of range, rescale every 16 frames to 2^500 -- the parity (fp32) path.
+// float: the arithmetic of a frame is 20 operations per lane and they run at twice the rate (and the row stores are half as
+// wide), but the range has to be budgeted: rescale every 8 frames to 2^8.  Above: a lane's values grow by at most 3x per
+// frame by their own sums (2^12.7 per block) and by mass arriving from the lane below, which in 8 frames has crossed at
+// most 8 states = 4 labels, each worth at least u >= eps = 2^-26.6 of what the lane already held (2^106) -> 2^127 is
+// not reached; below: 126 + 8 binades + denormals, where a lane spans at most 4 labels x 26.6.  Whatever still escapes
+// (inf / NaN or lost mass) fails the gradient kernel's sum-of-posteriors check and is redone by the repair pass.
+template <typename R>
+struct WaveReal;
+template <>
+struct WaveReal<double> {
+    static constexpr int TARGET = 500, RESCALE = 16, SHIFT_MAX = 400;
+};
+template <>
+struct WaveReal<float> {
+    static constexpr int TARGET = 8, RESCALE = 8, SHIFT_MAX = 100;
+};
+constexpr int WRESCALE = 16;   // frames of one straight-line block (two prefetch chunks)
 
 __device__ __forceinline__ double dpp_from_lower_lane(double v) {  // lane l <- lane l-1, lane 0 <- 0
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -420,6 +444,26 @@ __device__ __forceinline__ double dpp_from_upper_lane(double v) {  // lane l <- 
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float dpp_from_lower_lane(float v) {
+#if defined(SL_PROBE_CTC_NODPP)  // timing probe (wrong results): no cross-lane shift
+    return v * 0.5f;
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+#endif
+}
+__device__ __forceinline__ float dpp_from_upper_lane(float v) {
+#if defined(SL_PROBE_CTC_NODPP)
+    return v * 0.5f;
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+#endif
+}
+__device__ __forceinline__ int wave_frexp_exp(double v) { return __builtin_amdgcn_frexp_exp(v); }
+__device__ __forceinline__ int wave_frexp_exp(float v) { return __builtin_amdgcn_frexp_expf(v); }
+__device__ __forceinline__ double wave_ldexp(double v, int e) { return ldexp(v, e); }
+__device__ __forceinline__ float wave_ldexp(float v, int e) { return ldexpf(v, e); }
+__device__ __forceinline__ double wave_max2(double x, double y) { return fmax(x, y); }
+__device__ __forceinline__ float wave_max2(float x, float y) { return fmaxf(x, y); }
 
 __device__ __forceinline__ int dpp_int_from_lower_lane(int v, int lane0_value) {
     return __builtin_amdgcn_update_dpp(lane0_value, v, 0x138, 0xf, 0xf, false);
@@ -431,74 +475,80 @@ __device__ __forceinline__ int dpp_int_from_upper_lane(int v, int lane63_value) 
 // The recursion of one direction (compile-time DIR: 0 = alpha, forwards; 1 = beta, backwards).  Every store is
 // unconditional (dead lanes write their row slice to a dump row with stride 0, every lane writes the frame's exponent to
 // the same word): an exec-masked store between a prefetch load and its use would force s_waitcnt vmcnt(0) per frame.
-template <int DIR>
+template <int DIR, typename R>
 __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, const int32_t* __restrict__ lab,
-                                                 double* __restrict__ rows, double* __restrict__ dump,
+                                                 R* __restrict__ rows, R* __restrict__ dump,
                                                  int32_t* __restrict__ eout, int lane, int L, int S, int T, int k,
-                                                 int blank, float eps, double* a, int* e_final) {
+                                                 int blank, float eps, R* a, int* e_final) {
+    constexpr int RB = WaveReal<R>::RESCALE;  // frames between rescales = frames per stored exponent
+    constexpr int ZERO_SLOT = 63;             // emission slot of the dead label positions (k <= 63)
     // label slots of this lane: position 4 * lane + i sits in state 8 * lane + 2 * i + 1
     int col[4];
-    bool slot_live[4];
-    double sk[4];
+    R sk[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pos = 4 * lane + i;
-        slot_live[i] = pos < L;
-        const int me = slot_live[i] ? lab[pos] : blank;
-        col[i] = me;
+        const bool slot_live = pos < L;
+        const int me = slot_live ? lab[pos] : blank;
+        col[i] = slot_live ? me : ZERO_SLOT;  // dead label slots: u = 0
         bool skip;
         if (DIR == 0)
-            skip = slot_live[i] && pos >= 1 && lab[pos - 1] != me;
+            skip = slot_live && pos >= 1 && lab[pos - 1] != me;
         else
             skip = pos + 1 < L && lab[pos + 1] != me;
-        sk[i] = skip ? 1.0 : 0.0;
-    }
-    float livef[4], epsf[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        livef[i] = slot_live[i] ? 1.f : 0.f;
-        epsf[i] = slot_live[i] ? eps : 0.f;
+        sk[i] = skip ? (R)1 : (R)0;
     }
     const int tstart = DIR == 0 ? 0 : T - 1;
     const int tstep = DIR == 0 ? 1 : -1;
     const bool lane_live = WNS * lane < S;
-    double* rowp = lane_live ? rows + (long)tstart * (64 * WNS) + WNS * lane : dump + WNS * lane;
+    R* rowp = lane_live ? rows + (long)tstart * (64 * WNS) + WNS * lane : dump + WNS * lane;
     const long row_inc = lane_live ? (long)tstep * (64 * WNS) : 0;
 
     // Emissions: the raw probabilities of an 8-frame chunk are ONE contiguous span of 8 * k floats; it is fetched one
     // chunk ahead with four coalesced loads per lane and handed out through LDS (a lone wave executes its LDS operations
     // in order, so the read after the write needs no barrier).  Per-lane gathers straight from global memory would put
     // ten vector-memory operations per frame behind the 6-bit vmcnt counter, whose 63 slots divided by the store round
-    // trip (~1.5 us) is what paced the first version of this kernel (0.235 us per frame).
-    __shared__ float emis[2][8 * 64];
+    // trip (~1.5 us) is what paced the first version of this kernel (0.235 us per frame).  The LDS copy holds u = p + eps
+    // already in the lattice's number type (the conversions and the five adds per frame were a third of a frame's time:
+    // s_memtime probe, 473 -> 324 ticks without them) and a zero in slot 63 for the dead label positions.
+    __shared__ R emis[2][8 * 64 + 64];  // (+ 64: where the lanes beyond 8 * k of a chunk put their value)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        emis[0][j * 64 + lane] = (R)0;
+        emis[1][j * 64 + lane] = (R)0;
+    }
+    // per-lane constants of the chunk transfer (k is not a compile-time constant: no division inside the loop); frames
+    // past the end of the utterance re-read its last frame (their results are never used)
+    int st_idx[4], ld_jf[4], ld_c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = lane + 64 * r;
+        const int jf = idx / k;
+        ld_c[r] = idx - jf * k;
+        ld_jf[r] = jf < 8 ? jf : 7;
+        st_idx[r] = jf < 8 ? jf * 64 + ld_c[r] : 8 * 64 + lane;
+    }
+    const float* chunk0 = pr + (long)tstart * k;
+    const int kstep = tstep * k;
     auto fetch_chunk = [&](int base, float* e4) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = lane + 64 * r;
-            const int jf = idx / k, c = idx - jf * k;
-            const int step = base + (jf < 8 ? jf : 7);
-            const int st = step < T ? step : T - 1;
-            e4[r] = pr[(long)(tstart + tstep * st) * k + c];
-        }
+        for (int r = 0; r < 4; ++r) e4[r] = chunk0[min(base + ld_jf[r], T - 1) * kstep + ld_c[r]];
     };
     auto stage_chunk = [&](int buf, const float* e4) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = lane + 64 * r;
-            const int jf = idx / k, c = idx - jf * k;
-            if (jf < 8) emis[buf][jf * 64 + c] = e4[r];
-        }
+        for (int r = 0; r < 4; ++r) emis[buf][st_idx[r]] = (R)(e4[r] + eps);
     };
     float e4[4];
     fetch_chunk(0, e4);
     stage_chunk(0, e4);
 #pragma unroll
-    for (int j = 0; j < WNS; ++j) a[j] = 0.0;
+    for (int j = 0; j < WNS; ++j) a[j] = (R)0;
     int E = 0;              // this lane's exponent: true value = stored value * 2^E
-    bool lane_zero = true;  // nothing has reached this lane's states yet
+    bool lane_zero = true;  // nothing has reached this lane's states yet (as of the last rescale)
+    R fscale = (R)1;        // 2^(neighbour's exponent - E), fixed between rescales
 
     // Block floating point PER LANE: lane l's eight states share the exponent E (true value = stored * 2^E), brought
-    // back to 2^WTARGET every WRESCALE steps with no cross-lane reduction; the one value (beta: two) that crosses a lane
+    // back to 2^TARGET every RB steps with no cross-lane reduction; the one value (beta: two) that crosses a lane
     // boundary per frame is rescaled by the exponent difference on the way (frame()).  A single exponent per ROW is not
     // enough: early in training the net says "blank" with p ~ 1 and every label with p ~ eps, so each label a state has
     // consumed costs 2^-26 and the states of one row span thousands of binades -- per lane (four labels) they span a
@@ -510,45 +560,39 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
         const int hi_edge = DIR == 0 ? S : 2 * tp + 1;        // beta: states above are unreachable from the start
         // the exponent the block that ends here was stored under (a lane may have taken over its neighbour's exponent
         // in the middle of the block; its rows before that are zeros, which any exponent describes)
-        eout[max(base / WRESCALE - 1, 0) * 64 + lane] = E;
-        double m = 0.0;
+        eout[max(base / RB - 1, 0) * 64 + lane] = E;
+        R m = (R)0;
 #pragma unroll
         for (int j = 0; j < WNS; ++j) {
             const int st = WNS * lane + j;
-            a[j] = (st < lo_edge || st > hi_edge) ? 0.0 : a[j];
-            m = fmax(m, a[j]);
+            a[j] = (st < lo_edge || st > hi_edge) ? (R)0 : a[j];
+            m = wave_max2(m, a[j]);
         }
-        lane_zero = !(m > 0.0);
-        const int shift = lane_zero ? 0 : WTARGET - __builtin_amdgcn_frexp_exp(m);
+        lane_zero = !(m > (R)0);
+        const int shift = lane_zero ? 0 : WaveReal<R>::TARGET - wave_frexp_exp(m);
 #pragma unroll
-        for (int j = 0; j < WNS; ++j) a[j] = ldexp(a[j], shift);
+        for (int j = 0; j < WNS; ++j) a[j] = wave_ldexp(a[j], shift);
         E -= shift;
+        // A lane that holds nothing yet takes over the exponent of the neighbour its first mass will come from -- here, once
+        // per block, not per frame: in RB frames mass moves at most 2 RB states = RB / 4 lanes (skip transitions), so RB / 4
+        // + 1 rounds of "empty lane <- neighbour" cover every lane that can be reached before the next rescale.  The factor
+        // that brings the neighbour's boundary value(s) to this lane's exponent is then fixed for the block.
+#pragma unroll
+        for (int round = 0; round < RB / 4 + 1; ++round) {
+            const int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
+            E = lane_zero ? en : E;
+        }
+        const int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
+        fscale = wave_ldexp((R)1, max(min(en - E, WaveReal<R>::SHIFT_MAX), -WaveReal<R>::SHIFT_MAX * 4));
     };
     // one frame: emissions from LDS, three phases of mutually independent operations (a lone wave hides no latency by
     // itself: the eight two-term sums, the four skip terms, the eight products; the empty asm statements pin the phase
     // order), store of the row.
-    auto frame = [&](bool first, const float* erow) {
-#if defined(SL_PROBE_CTC_NOEMIS)  // timing probe (wrong results): no emission reads
-        const double ub = 0.03;
-        double uq[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) uq[i] = 0.03 * livef[i];
-#else
-        const double ub = (double)(erow[blank] + eps);
-        double uq[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) uq[i] = (double)fmaf(erow[col[i]], livef[i], epsf[i]);  // dead label slots: 0
-#endif
-        double n[WNS];
+    auto frame_core = [&](bool first, const R ub, const R (&uq)[4]) {
+        R n[WNS];
         if (DIR == 0) {
-            // state 8l - 1 (a label state) of the lane below, brought to this lane's exponent; a lane that holds nothing
-            // yet takes over its neighbour's exponent when the first mass arrives
-            const double below_raw = dpp_from_lower_lane(a[7]);
-            const int e_below = dpp_int_from_lower_lane(E, E);
-            const bool adopt = lane_zero && below_raw != 0.0;
-            E = adopt ? e_below : E;
-            lane_zero = lane_zero && !adopt;
-            const double below = ldexp(below_raw, min(e_below - E, 400));
+            // state 8l - 1 (a label state) of the lane below, brought to this lane's exponent
+            const R below = dpp_from_lower_lane(a[7]) * fscale;
             n[0] = a[0] + below;
 #pragma unroll
             for (int i = 1; i < WNS; ++i) n[i] = a[i] + a[i - 1];
@@ -558,14 +602,8 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
             n[5] = fma(sk[2], a[3], n[5]);
             n[7] = fma(sk[3], a[5], n[7]);
         } else {
-            const double up0_raw = dpp_from_upper_lane(a[0]);  // state 8l + 8 (blank)
-            const double up1_raw = dpp_from_upper_lane(a[1]);  // state 8l + 9 (label)
-            const int e_up = dpp_int_from_upper_lane(E, E);
-            const bool adopt = lane_zero && (up0_raw != 0.0 || up1_raw != 0.0);
-            E = adopt ? e_up : E;
-            lane_zero = lane_zero && !adopt;
-            const int de = min(e_up - E, 400);
-            const double up0 = ldexp(up0_raw, de), up1 = ldexp(up1_raw, de);
+            const R up0 = dpp_from_upper_lane(a[0]) * fscale;  // state 8l + 8 (blank)
+            const R up1 = dpp_from_upper_lane(a[1]) * fscale;  // state 8l + 9 (label)
             n[7] = a[7] + up0;
 #pragma unroll
             for (int i = 0; i < WNS - 1; ++i) n[i] = a[i] + a[i + 1];
@@ -592,22 +630,42 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
                     blank_entry = WNS * lane + 2 * i == S - 1;               // state S - 1
                     label_entry = L > 0 && WNS * lane + 2 * i + 1 == S - 2;  // state S - 2
                 }
-                n[2 * i] = blank_entry ? ub : 0.0;
-                n[2 * i + 1] = label_entry ? uq[i] : 0.0;
-                lane_zero = lane_zero && !(blank_entry || label_entry);
+                n[2 * i] = blank_entry ? ub : (R)0;
+                n[2 * i + 1] = label_entry ? uq[i] : (R)0;
             }
         }
         // dead blank states (s >= S, even) only ever see zeros: their label neighbours have u = 0
 #pragma unroll
         for (int i = 0; i < WNS; ++i) a[i] = n[i];
 #if !defined(SL_PROBE_CTC_NOSTORE)  // (timing probe: no lattice stores)
+        if (sizeof(R) == 8) {
 #pragma unroll
-        for (int i = 0; i < WNS; i += 2) *(double2*)(rowp + i) = make_double2(a[i], a[i + 1]);
+            for (int i = 0; i < WNS; i += 2) *(double2*)((double*)rowp + i) = make_double2((double)a[i], (double)a[i + 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < WNS; i += 4)
+                *(float4*)((float*)rowp + i) = make_float4((float)a[i], (float)a[i + 1], (float)a[i + 2], (float)a[i + 3]);
+        }
 #endif
         rowp += row_inc;
     };
+    // (Issuing a frame's LDS reads one frame ahead -- inline-asm reads, hand-placed wait -- was measured and changed
+    // nothing: the reads are not what a frame waits for.  A frame is 47 instructions of a lone wave, ~7 cycles each.)
+    auto frame = [&](bool first, const R* erow) {
+        R uq[4];
+#if defined(SL_PROBE_CTC_NOEMIS)  // timing probe (wrong results): no emission reads
+        const R ub = (R)0.03;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uq[i] = (R)0.03;
+#else
+        const R ub = erow[blank];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uq[i] = erow[col[i]];
+#endif
+        frame_core(first, ub, uq);
+    };
 
-    // Full blocks of WRESCALE = 16 steps run as straight-line code: the waitcnt pass can then count the stores that are
+    // Full blocks of 16 steps run as straight-line code: the waitcnt pass can then count the stores that are
     // younger than a chunk's prefetch loads exactly (with a branch per frame it assumed none and waited for the stores'
     // round trip once per chunk).
     int base = 0;
@@ -619,6 +677,7 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
         for (int j = 1; j < 8; ++j) frame(false, &emis[0][j * 64]);
         stage_chunk(1, e4);
         fetch_chunk(16, e4);
+        if (RB == 8) rescale(8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) frame(false, &emis[1][j * 64]);
         stage_chunk(0, e4);
@@ -631,6 +690,7 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
         for (int j = 0; j < 8; ++j) frame(false, &emis[0][j * 64]);
         stage_chunk(1, e4);
         fetch_chunk(base + 16, e4);
+        if (RB == 8) rescale(base + 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) frame(false, &emis[1][j * 64]);
         stage_chunk(0, e4);
@@ -641,21 +701,23 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
         fetch_chunk(base + 8, e4);
         for (int j = 0; j < 8 && base + j < T; ++j) frame(base + j == 0, &emis[0][j * 64]);
         stage_chunk(1, e4);
+        if (RB == 8 && base + 8 < T) rescale(base + 8);
         for (int j = 0; j < 8 && base + 8 + j < T; ++j) frame(false, &emis[1][j * 64]);
     }
-    eout[((T - 1) / WRESCALE) * 64 + lane] = E;  // the last (possibly partial) block
+    eout[((T - 1) / RB) * 64 + lane] = E;  // the last (possibly partial) block
     *e_final = E;
 }
 
-// workspace: alpha, beta double[B][T][512] (+ one dump row per utterance and direction); ea, eb int32[B][T/16+1][64];
-// logz2 float[B]; cls as for the log-domain kernel
+// workspace: alpha, beta R[B][T][512] (+ one dump row per utterance and direction); ea, eb int32[B][T/RB+1][64], RB =
+// WaveReal<R>::RESCALE; logz2 float[B]; cls as for the log-domain kernel
+template <typename R>
 __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __restrict__ probs,
                                                               const float* __restrict__ logq,
                                                               const int32_t* __restrict__ labels,
                                                               const int32_t* __restrict__ label_len,
                                                               const int32_t* __restrict__ input_len,
-                                                              double* __restrict__ alpha, double* __restrict__ beta,
-                                                              double* __restrict__ dump, int32_t* __restrict__ ea,
+                                                              R* __restrict__ alpha, R* __restrict__ beta,
+                                                              R* __restrict__ dump, int32_t* __restrict__ ea,
                                                               int32_t* __restrict__ eb, float* __restrict__ logz2,
                                                               int32_t* __restrict__ zint, float* __restrict__ loss,
                                                               int32_t* __restrict__ cls,
@@ -707,7 +769,8 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
     }
     const int32_t* lab = labels + (long)b * l_max;
     const float* pr = probs + (long)b * t_out * k;
-    double a[WNS];
+    constexpr int RB = WaveReal<R>::RESCALE;
+    R a[WNS];
     int E;
     if (dir == 0) {
         // sum over the scored frames of ln c_t, c_t = 1 / sum_j (p_j + eps) = q_blank / (p_blank + eps): what separates
@@ -719,19 +782,19 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
 #if defined(SL_PROBE_CTC_CLOCK)
         const long long probe_t0 = clock64();
 #endif
-        wave_lattice_run<0>(pr, lab, alpha + (long)b * t_out * (64 * WNS), dump + (long)(2 * b) * (64 * WNS),
-                            ea + (long)b * (t_out / WRESCALE + 1) * 64, lane, L, S, T, k, blank, eps, a, &E);
+        wave_lattice_run<0, R>(pr, lab, alpha + (long)b * t_out * (64 * WNS), dump + (long)(2 * b) * (64 * WNS),
+                               ea + (long)b * (t_out / RB + 1) * 64, lane, L, S, T, k, blank, eps, a, &E);
         // Z_u = alpha_{T-1}(S-1) + alpha_{T-1}(S-2)
         double* fin = (double*)wl_lds;
         int* fin_e = (int*)(fin + 2);
 #pragma unroll
         for (int i = 0; i < WNS; ++i) {
             if (WNS * lane + i == S - 1) {
-                fin[0] = a[i];
+                fin[0] = (double)a[i];
                 fin_e[0] = E;
             }
             if (WNS * lane + i == S - 2) {
-                fin[1] = a[i];
+                fin[1] = (double)a[i];
                 fin_e[1] = E;
             }
         }
@@ -750,14 +813,14 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
             // -ln Z_u in double: the integer part is in the tens of thousands for a long utterance
             loss[b] = z > 0.0 ? (float)(-((double)(xz + ez) + (double)frac) * 0.6931471805599453 - (double)csum) : INFINITY;
             // no alignment at all, or every one of them underflowed: the log-domain repair pass tells which
-            flags[b] = z > 0.0 ? 0 : 1;
+            flags[b] = (z > 0.0 && z < INFINITY) ? 0 : 1;  // (NaN / inf: the float lattice overflowed)
 #if defined(SL_PROBE_CTC_CLOCK)  // timing probe: s_memtime ticks per frame of the alpha recursion instead of the loss
             loss[b] = (float)(clock64() - probe_t0) / (float)T;
 #endif
         }
     } else {
-        wave_lattice_run<1>(pr, lab, beta + (long)b * t_out * (64 * WNS), dump + (long)(2 * b + 1) * (64 * WNS),
-                            eb + (long)b * (t_out / WRESCALE + 1) * 64, lane, L, S, T, k, blank, eps, a, &E);
+        wave_lattice_run<1, R>(pr, lab, beta + (long)b * t_out * (64 * WNS), dump + (long)(2 * b + 1) * (64 * WNS),
+                               eb + (long)b * (t_out / RB + 1) * 64, lane, L, S, T, k, blank, eps, a, &E);
     }
 }
 
@@ -853,7 +916,7 @@ __host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
     w.lin_alpha = take(wave ? rows * 64 * WNS * sizeof(double) : 0);
     w.lin_beta = take(wave ? rows * 64 * WNS * sizeof(double) : 0);
     w.dump = take(wave ? (size_t)2 * batch * 64 * WNS * sizeof(double) : 0);
-    const size_t eblocks = (size_t)batch * (t_out / WRESCALE + 1) * 64;  // one exponent per lane and block of 16 steps
+    const size_t eblocks = (size_t)batch * (t_out / 8 + 1) * 64;  // one exponent per lane and block of 16 (double) / 8 (float) steps
     w.ea = take(wave ? eblocks * sizeof(int32_t) : 0);
     w.eb = take(wave ? eblocks * sizeof(int32_t) : 0);
     w.logz2 = take((size_t)batch * sizeof(float));
@@ -866,7 +929,7 @@ __host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
 }  // namespace
 
 extern "C" int sl_ctc_select(int variant) {
-    SL_CHECK_ARG(variant >= 0 && variant <= 4, "sl_ctc_select: variant %d outside 0..4", variant);
+    SL_CHECK_ARG(variant >= 0 && variant <= 7, "sl_ctc_select: variant %d outside 0..7", variant);
     g_ctc_variant = variant;
     return SL_OK;
 }
@@ -910,35 +973,53 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
     float* beta = (float*)(base + w.log_beta);
     int32_t* cls = (int32_t*)(base + w.cls);
     int32_t* flags = (int32_t*)(base + w.flags);
-    const bool wave = g_ctc_variant != 1 && 2 * l_max + 1 <= 64 * WNS && (g_ctc_variant != 0 || t_out >= WAVE_MIN_FRAMES);
-    const bool repair = wave && g_ctc_variant != 2;
+    // which lattice: see sl_ctc_select
+    const bool fits = 2 * l_max + 1 <= 64 * WNS && k <= 63;
+    int v = g_ctc_variant;
+    if (v == 0) v = !fits ? 1 : (dtype == SL_F32 ? (t_out >= WAVE_MIN_FRAMES ? 4 : 1) : 5);
+    if (v != 1 && !fits) v = 1;
+    const bool wave = v != 1;
+    const bool wave_f32 = v >= 5;
+    const bool repair = wave && v != 2 && v != 6;
+    const bool force_repair = v == 3 || v == 7;
     const int frames_per_wg = 8;  // two frames per wave: 16000 frames -> 8000 waves in flight
     const size_t lds2 = (size_t)(2 * l_max + (k + 1)) * sizeof(int) + (size_t)(4 * 64 + 4 * l_max) * sizeof(float);
     const dim3 grid((t_out + frames_per_wg - 1) / frames_per_wg, batch);
     const int out_f32 = dtype == SL_F32 ? 1 : 0;
     int rc;
     if (wave) {
-        double* la = (double*)(base + w.lin_alpha);
-        double* lb = (double*)(base + w.lin_beta);
+        void* la = base + w.lin_alpha;
+        void* lb = base + w.lin_beta;
         int32_t* ea = (int32_t*)(base + w.ea);
         int32_t* eb = (int32_t*)(base + w.eb);
         float* logz2 = (float*)(base + w.logz2);
         int32_t* zint = (int32_t*)(base + w.zint);
         size_t lds = (size_t)(l_max + k + 1) * sizeof(int);
         if (lds < 2 * sizeof(double) + 2 * sizeof(int)) lds = 2 * sizeof(double) + 2 * sizeof(int);
-        hipLaunchKernelGGL(ctc_lattice_wave_kernel, dim3(batch, 3), dim3(64), lds, s, probs, logq, labels, label_len,
-                           input_len, la, lb, (double*)(base + w.dump), ea, eb, logz2, zint, loss, cls, flags, t_out, k,
-                           l_max, k - 1, eps);
+        if (wave_f32)
+            hipLaunchKernelGGL(ctc_lattice_wave_kernel<float>, dim3(batch, 3), dim3(64), lds, s, probs, logq, labels,
+                               label_len, input_len, (float*)la, (float*)lb, (float*)(base + w.dump), ea, eb, logz2, zint,
+                               loss, cls, flags, t_out, k, l_max, k - 1, eps);
+        else
+            hipLaunchKernelGGL(ctc_lattice_wave_kernel<double>, dim3(batch, 3), dim3(64), lds, s, probs, logq, labels,
+                               label_len, input_len, (double*)la, (double*)lb, (double*)(base + w.dump), ea, eb, logz2, zint,
+                               loss, cls, flags, t_out, k, l_max, k - 1, eps);
         rc = sl_check_launch("sl_ctc_loss_grad(wave lattice)");
         if (rc != SL_OK) return rc;
-        // rows are 512 doubles wide; the kernel reads 8 columns per lane
-        hipLaunchKernelGGL((ctc_grad_kernel<8, true>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
-                           input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
-                           l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32, eps,
-                           grad_scale, g_ctc_variant == 3 ? nullptr : flags, nullptr);
+        // rows are 512 values wide; the kernel reads 8 columns per lane
+        if (wave_f32)
+            hipLaunchKernelGGL((ctc_grad_kernel<8, 2>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
+                               input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
+                               l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
+                               eps, grad_scale, force_repair ? nullptr : flags, nullptr);
+        else
+            hipLaunchKernelGGL((ctc_grad_kernel<8, 1>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
+                               input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
+                               l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
+                               eps, grad_scale, force_repair ? nullptr : flags, nullptr);
         rc = sl_check_launch("sl_ctc_loss_grad(grad)");
         if (rc != SL_OK || !repair) return rc;
-        if (g_ctc_variant == 3) {  // tests: redo everything
+        if (force_repair) {  // tests: redo everything
             rc = (int)hipMemsetAsync(flags, 1, (size_t)batch * sizeof(int32_t), s);
             if (rc != 0) return SL_ERR_LAUNCH_FAILED;
         }
@@ -953,7 +1034,7 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
     rc = sl_check_launch("sl_ctc_loss_grad(lattice)");
     if (rc != SL_OK) return rc;
 #define SL_CTC_GRAD(NJ_)                                                                                              \
-    hipLaunchKernelGGL((ctc_grad_kernel<NJ_, false>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,        \
+    hipLaunchKernelGGL((ctc_grad_kernel<NJ_, 0>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,        \
                        input_len, (const void*)alpha, (const void*)beta, nullptr, nullptr, nullptr, nullptr, loss, cls,   \
                        dlogits,                                                                                        \
                        t_out, k, l_max, sp, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,  \

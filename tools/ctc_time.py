@@ -39,7 +39,10 @@ def main():
     lib.call("sl_softmax_logq", logits.data_ptr(), probs.data_ptr(), logq.data_ptr(), b, t, k, k, t * k, 1e-8, st)
     need = lib.raw("sl_ctc_workspace_bytes")(b, t, args.lmax)
     ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-    for variant, name in ((1, "log-domain lattice"), (2, "wave lattice, no repair launches"), (0, "wave lattice + repair launches")):
+    ref = None
+    for variant, name in ((1, "log-domain lattice"), (2, "wave lattice (double), no repair launches"),
+                          (4, "wave lattice (double) + repair launches"), (6, "wave lattice (float), no repair launches"),
+                          (5, "wave lattice (float) + repair launches"), (0, "automatic (bf16 output)")):
         lib.call("sl_ctc_select", variant)
 
         def run():
@@ -55,8 +58,13 @@ def main():
             run()
         e1.record()
         torch.cuda.synchronize()
-        print("{:40s} {:8.1f} us per call   (mean loss {:.3f})".format(name, e0.elapsed_time(e1) / args.reps * 1e3,
-                                                                     float(loss.mean())))
+        g = dl.float().cpu().numpy()
+        if ref is None:
+            ref = (loss.cpu().numpy().copy(), g)
+        print("{:44s} {:8.1f} us per call   (mean loss {:.4f}; vs log-domain: loss {:.2e}, gradient rel-L2 {:.2e})".format(
+            name, e0.elapsed_time(e1) / args.reps * 1e3, float(loss.mean()),
+            float(np.abs(loss.cpu().numpy() - ref[0]).max() / np.abs(ref[0]).max()),
+            float(np.linalg.norm(g - ref[1]) / np.linalg.norm(ref[1]))))
     lib.call("sl_ctc_select", 0)
 
 
