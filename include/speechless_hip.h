@@ -193,11 +193,12 @@ int sl_output_softmax(const void* x, const void* w, const float* bias, float* pr
  *          halo'd tensor described by (g_row0, g_row_stride, g_batch_stride), dtype `dtype`; frames >=
  *          input_len[b] get zeros.  grad_scale = 1/B realises Keras' mean over the batch (net.py:389).
  * workspace: sl_ctc_workspace_bytes(...) bytes (alpha/beta lattices).
- * Two lattice kernels: the log-domain one (one thread per lattice state, LDS row exchange + barrier per frame), and for
- * long utterances (t_out >= 1024) with labels of up to 255 graphemes a probability-domain one (doubles with an exponent
- * per 16 frames, one wave per utterance and direction, no transcendental and no barrier on the T'-long sequential path);
- * there the gradient kernel checks every frame's posteriors against 1 and an utterance that lost mass to underflow is
- * redone by the log-domain kernels.  Results agree to fp32 round-off either way.
+ * Two lattice kernels: with labels of up to 255 graphemes and k <= 63 a probability-domain one (one wave per utterance
+ * and direction, eight lattice states per lane, block floating point with one exponent per lane and 8 / 16 frames, no
+ * transcendental, no LDS exchange and no barrier on the T'-long sequential path) in doubles; the gradient kernel then
+ * checks every frame's posteriors against 1, and an utterance that lost mass to underflow is redone by the second kernel:
+ * the log-domain one (one thread per lattice state, LDS row exchange + barrier per frame), which also serves longer
+ * labels.  Results agree to fp32 round-off.
  */
 size_t sl_ctc_workspace_bytes(int batch, int t_out, int l_max);
 int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* labels, const int32_t* label_len,
@@ -206,9 +207,9 @@ int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* label
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Measurement / test hook: which lattice sl_ctc_loss_grad runs.  0 (default) = as described above, 1 = log-domain lattice
- * only, 2 = probability-domain lattice without the repair launches, 3 = probability-domain lattice and then EVERY
- * utterance redone by the repair pass, 4 = probability-domain lattice + repair whenever the labels fit, whatever the
- * length.  Process-wide; not for concurrent use with sl_ctc_loss_grad. */
+ * only; probability-domain lattice in doubles: 2 = without the repair launches, 3 = and then EVERY utterance redone by the
+ * repair pass, 4 = + repair; in floats (faster, but the repair pass is needed in some regimes: ctc.hip:WaveReal): 6 / 7 / 5
+ * likewise.  Process-wide; not for concurrent use with sl_ctc_loss_grad. */
 int sl_ctc_select(int variant);
 
 /* ---- greedy decode (net.py:452-454 tf.nn.ctc_greedy_decoder, merge_repeated=True; numpy twin

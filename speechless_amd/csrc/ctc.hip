@@ -413,13 +413,16 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 // flagged utterance is redone by the log-domain kernels (repair pass, normally two empty launches).
 constexpr int WNS = 8;         // states per lane
 
-// Number type of the lattice.  double: 2^+-1022 of range, rescale every 16 frames to 2^500 -- the parity (fp32) path.
-// float: the arithmetic of a frame is 20 operations per lane and they run at twice the rate (and the row stores are half as
-// wide), but the range has to be budgeted: rescale every 8 frames to 2^8.  Above: a lane's values grow by at most 3x per
-// frame by their own sums (2^12.7 per block) and by mass arriving from the lane below, which in 8 frames has crossed at
-// most 8 states = 4 labels, each worth at least u >= eps = 2^-26.6 of what the lane already held (2^106) -> 2^127 is
-// not reached; below: 126 + 8 binades + denormals, where a lane spans at most 4 labels x 26.6.  Whatever still escapes
-// (inf / NaN or lost mass) fails the gradient kernel's sum-of-posteriors check and is redone by the repair pass.
+// Number type of the lattice.  double (the default): 2^+-1022 of range, rescale every 16 frames to 2^500.
+// float (sl_ctc_select 5..7, measurement): a frame's 20 operations run at twice the rate and the row stores are half as
+// wide -- 83 instead of 106 us per call at 32 x 500 frames -- but 2^-134 .. 2^119 around a lane's maximum is not enough
+// everywhere: (a) a lane that holds a few early paths when the bulk of the mass arrives within a block grows by more
+// than 2^119 (blank logit + 5 .. 10 over the labels: overflow at the lattice front); a floor on the exponent from the
+// source lane's maximum (E >= E_source - 100) cures that, but (b) with every label at the 1e-8 floor a lane's own states
+// are 2^-106 per lane below the source lane's and ARE what reaches the end of the utterance -- the floor flushes them.
+// No per-lane exponent serves both without knowing the emission costs in between; a per-frame overflow check would
+// cost what the float arithmetic saves.  Either failure is caught (sum of posteriors / non-finite Z) and repaired by the
+// log-domain pass, at three times the price -- hence doubles by default.
 template <typename R>
 struct WaveReal;
 template <>
@@ -428,7 +431,7 @@ struct WaveReal<double> {
 };
 template <>
 struct WaveReal<float> {
-    static constexpr int TARGET = 8, RESCALE = 8, SHIFT_MAX = 100;
+    static constexpr int TARGET = 8, RESCALE = 8, SHIFT_MAX = 126;
 };
 constexpr int WRESCALE = 16;   // frames of one straight-line block (two prefetch chunks)
 
@@ -573,17 +576,16 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
 #pragma unroll
         for (int j = 0; j < WNS; ++j) a[j] = wave_ldexp(a[j], shift);
         E -= shift;
-        // A lane that holds nothing yet takes over the exponent of the neighbour its first mass will come from -- here, once
-        // per block, not per frame: in RB frames mass moves at most 2 RB states = RB / 4 lanes (skip transitions), so RB / 4
-        // + 1 rounds of "empty lane <- neighbour" cover every lane that can be reached before the next rescale.  The factor
-        // that brings the neighbour's boundary value(s) to this lane's exponent is then fixed for the block.
+        // A lane that holds nothing yet takes over the exponent of the neighbour its first mass will come from -- once
+        // per block, not per frame: in RB frames mass moves at most 2 RB states = RB / 4 lanes (skip transitions), so
+        // RB / 4 + 1 rounds of "empty lane <- neighbour" cover every lane that can be reached before the next rescale.
 #pragma unroll
         for (int round = 0; round < RB / 4 + 1; ++round) {
             const int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
             E = lane_zero ? en : E;
         }
         const int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
-        fscale = wave_ldexp((R)1, max(min(en - E, WaveReal<R>::SHIFT_MAX), -WaveReal<R>::SHIFT_MAX * 4));
+        fscale = wave_ldexp((R)1, max(min(en - E, WaveReal<R>::SHIFT_MAX), -4 * WaveReal<R>::SHIFT_MAX));
     };
     // one frame: emissions from LDS, three phases of mutually independent operations (a lone wave hides no latency by
     // itself: the eight two-term sums, the four skip terms, the eight products; the empty asm statements pin the phase
@@ -888,14 +890,13 @@ __global__ __launch_bounds__(256) void greedy_decode_kernel(const float* __restr
 
 __host__ int lattice_sp(int l_max) { return ((2 * l_max + 1) + 63) / 64 * 64; }
 
-// which lattice sl_ctc_loss_grad runs (sl_ctc_select): 0 = automatic -- the probability-domain wave lattice with the
-// log-domain repair pass for LONG utterances (t_out >= 1024 and 2 * l_max + 1 <= 512: measured 807 vs 915 us per call at
-// 8 x 4000 frames), the log-domain lattice otherwise (at 32 x 500 frames the two are level, 130 vs 132 us, and the wave
-// path pays two more launches); 1 = log-domain lattice only; 2 = wave lattice without the repair launches
-// (measurement); 3 = wave lattice, then every utterance redone by the repair pass (tests); 4 = wave lattice + repair
-// whenever the labels fit (tests)
+// which lattice sl_ctc_loss_grad runs (sl_ctc_select): 0 = automatic -- when the labels fit (2 * l_max + 1 <= 512, k <= 63)
+// the probability-domain wave lattice in doubles with the log-domain repair pass behind it, otherwise the log-domain
+// lattice (per call at 32 x 500 frames: 108 vs 132 us; at 8 x 4000 frames 556 vs 912); 1 = log-domain lattice only; 2 =
+// double wave lattice without the repair launches (measurement); 3 = double wave lattice, then every utterance redone by
+// the repair pass (tests); 4 = double wave lattice + repair; 5 / 6 / 7 = the FLOAT wave lattice with repair / without /
+// with forced repair (measurement: 87 / 463 us, but see WaveReal)
 int g_ctc_variant = 0;
-constexpr int WAVE_MIN_FRAMES = 1024;
 
 struct CtcLayout {
     size_t log_alpha, log_beta, cls, lin_alpha, lin_beta, dump, ea, eb, logz2, zint, flags, total;
@@ -976,7 +977,7 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
     // which lattice: see sl_ctc_select
     const bool fits = 2 * l_max + 1 <= 64 * WNS && k <= 63;
     int v = g_ctc_variant;
-    if (v == 0) v = !fits ? 1 : (dtype == SL_F32 ? (t_out >= WAVE_MIN_FRAMES ? 4 : 1) : 5);
+    if (v == 0) v = fits ? 4 : 1;
     if (v != 1 && !fits) v = 1;
     const bool wave = v != 1;
     const bool wave_f32 = v >= 5;

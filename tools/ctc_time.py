@@ -16,6 +16,11 @@ def main():
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--lmax", type=int, default=200)
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--logit-scale", type=float, default=1.0, help="std of the random logits (0.01: the near-uniform softmax "
+                    "of a freshly initialised net)")
+    ap.add_argument("--blank-bias", type=float, default=0.0, help="added to the blank logit (25: the 'blank collapse' every "
+                    "CTC training run passes through early on)")
+    ap.add_argument("--ragged", action="store_true", help="input lengths U{frames/4 .. frames} instead of all = frames")
     args = ap.parse_args()
     import torch
     from speechless_amd import _lib
@@ -23,7 +28,9 @@ def main():
     b, t, k = args.batch, args.frames, 29
     rng = np.random.RandomState(0)
     dev = "cuda:0"
-    logits = torch.tensor(rng.randn(b, t, k).astype(np.float32), device=dev)
+    lg = (rng.randn(b, t, k) * args.logit_scale).astype(np.float32)
+    lg[:, :, k - 1] += args.blank_bias
+    logits = torch.tensor(lg, device=dev)
     probs = torch.zeros((b, t, k), dtype=torch.float32, device=dev)
     logq = torch.zeros_like(probs)
     lab_len = rng.randint(20, args.lmax + 1, size=b).astype(np.int32)
@@ -33,6 +40,8 @@ def main():
     lab = torch.tensor(labels, device=dev)
     ll = torch.tensor(lab_len, device=dev)
     il = torch.full((b,), t, dtype=torch.int32, device=dev)
+    if args.ragged:
+        il = torch.tensor(rng.randint(t // 4, t + 1, size=b).astype(np.int32), device=dev)
     loss = torch.zeros((b,), dtype=torch.float32, device=dev)
     dl = torch.zeros((b, t, 128), dtype=torch.bfloat16, device=dev)
     st = torch.cuda.current_stream().cuda_stream
