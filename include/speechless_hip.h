@@ -232,6 +232,23 @@ typedef struct {
 int sl_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers, int n_layers,
                         int dtype, int step, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* ---- Bias gradients out of the weight-gradient GEMM ("ones channel") ------------------------------------------------
+ * The channel padding of an activation tensor (250 -> 256, 2000 -> 2048) is multiplied through every GEMM anyway.  When the
+ * LAST padded output channel of layer i-1 carries the constant 1 on every valid frame (bias 1, zero weights; the host side
+ * sets that up), row cin_pad - 1 of layer i's weight gradient is  dW[k][cin_pad-1][co] = sum over the frames whose tap-k
+ * input frame is valid of g[frame][co]  -- for the tap that reads the frame itself (k = pad_left) exactly the bias gradient
+ * of layer i (BiasAddGrad, net.py:389 autodiff), computed by sl_conv1d_wgrad at no extra cost instead of by sl_bias_grad's
+ * extra pass over g.  This call moves it to the bias-gradient slot and zeroes the row for all taps, so that the padded
+ * weights stay zero under the optimizer.  grads: the flat fp32 gradient buffer; per layer the element offsets of dW
+ * ([k][cin_pad][cout_pad]) and db ([cout_pad]); copy = 0: zero the row only (e.g. dropout was applied to the ones).
+ */
+#define SL_BGW_MAX_LAYERS 16
+typedef struct sl_bgw_layer {
+    int64_t w_off, b_off;
+    int32_t k, cin_pad, cout_pad, tap;
+} sl_bgw_layer;
+int sl_bias_grad_from_wgrad(float* grads, const sl_bgw_layer* layers, int n_layers, int copy, void* stream);
+
 /* ---- Dropout (net.py:301-303: a Keras Dropout(rate) layer in front of every conv except the last three; training
  * phase only, `dropout=None` in every reference configuration) ------------------------------------------------------
  * sl_dropout: dst[i] = keep_i ? src[i] / (1 - rate) : 0 over n elements (dst may be src), keep_i a pure function of

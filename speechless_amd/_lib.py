@@ -31,6 +31,12 @@ class AdamLayer(ctypes.Structure):
                 ("cout_pad", c_int32)]
 
 
+class BgwLayer(ctypes.Structure):
+    """Mirror of sl_bgw_layer (include/speechless_hip.h)."""
+    _fields_ = [("w_off", c_int64), ("b_off", c_int64), ("k", c_int32), ("cin_pad", c_int32), ("cout_pad", c_int32),
+                ("tap", c_int32)]
+
+
 class ConvGeom(ctypes.Structure):
     """Mirror of sl_conv_geom (include/speechless_hip.h)."""
     _fields_ = [
@@ -93,6 +99,7 @@ SIGNATURES = {
     "sl_z_normalize_workspace_bytes": (c_size_t, [c_int]),
     "sl_z_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t,
                                c_void_p]),
+    "sl_bias_grad_from_wgrad": (c_int, [c_void_p, POINTER(BgwLayer), c_int, c_int, c_void_p]),
     "sl_adam_pack_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AdamLayer), c_int, c_int, c_int,
                                     c_float, c_float, c_float, c_float, c_void_p]),
 }

@@ -259,6 +259,39 @@ extern "C" int sl_adam_pack_layers(float* param, const float* grad, float* m, fl
     return sl_check_launch("sl_adam_pack_layers");
 }
 
+namespace {
+struct BgwTable {
+    sl_bgw_layer l[SL_BGW_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void bias_grad_from_wgrad_kernel(float* __restrict__ grads, BgwTable t, int copy) {
+    const sl_bgw_layer L = t.l[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= L.cout_pad) return;
+    float* row = grads + L.w_off + (long)(L.cin_pad - 1) * L.cout_pad + c;  // tap 0; a tap further = cin_pad * cout_pad
+    const long tap_stride = (long)L.cin_pad * L.cout_pad;
+    if (copy) grads[L.b_off + c] = row[(long)L.tap * tap_stride];
+    for (int k = 0; k < L.k; ++k) row[(long)k * tap_stride] = 0.f;
+}
+}  // namespace
+
+extern "C" int sl_bias_grad_from_wgrad(float* grads, const sl_bgw_layer* layers, int n_layers, int copy, void* stream) {
+    SL_CHECK_ARG(grads != nullptr && layers != nullptr, "sl_bias_grad_from_wgrad: null pointer");
+    SL_CHECK_ARG(n_layers >= 1 && n_layers <= SL_BGW_MAX_LAYERS, "sl_bias_grad_from_wgrad: 1..%d layers per call",
+                 SL_BGW_MAX_LAYERS);
+    BgwTable t;
+    int widest = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        SL_CHECK_ARG(layers[i].k >= 1 && layers[i].tap >= 0 && layers[i].tap < layers[i].k && layers[i].cin_pad >= 1 &&
+                         layers[i].cout_pad >= 1,
+                     "sl_bias_grad_from_wgrad: bad layer %d", i);
+        t.l[i] = layers[i];
+        if (layers[i].cout_pad > widest) widest = layers[i].cout_pad;
+    }
+    hipLaunchKernelGGL(bias_grad_from_wgrad_kernel, dim3((widest + 255) / 256, n_layers), dim3(256), 0,
+                       (hipStream_t)stream, grads, t, copy);
+    return sl_check_launch("sl_bias_grad_from_wgrad");
+}
+
 extern "C" int sl_adam_pack_layer(float* param, const float* grad, float* m, float* v, void* w_fwd, void* w_dgrad, int k,
                                   int cin_pad, int cout_pad, int dtype, int step, float lr, float beta1, float beta2,
                                   float eps, void* stream) {

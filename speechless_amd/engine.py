@@ -370,6 +370,13 @@ class Engine:
         self._side_stream = None
         self.overlap_wgrad = False
         self.defer_bias_grads = os.environ.get("SL_DEFER_BGRAD", "1") != "0"  # A/B knob, see backward()
+        # "ones channel": the last padded output channel of every hidden layer carries the constant 1 (bias 1, zero weights),
+        # so the next layer's weight-gradient GEMM -- which multiplies the padding through anyway -- leaves that layer's
+        # BIAS gradient in row cin_pad - 1 of dW (sl_bias_grad_from_wgrad, include/speechless_hip.h): ten of the eleven
+        # sl_bias_grad passes over g (two launches each, on the side stream, 0.07 ms of the config-3 step by taking
+        # bandwidth and power from the GEMMs beside them) become one small launch.  SL_ONES_CHANNEL=0: the old passes.
+        self.ones_channel = os.environ.get("SL_ONES_CHANNEL", "1") == "1"
+        self._bgw_tables = {}
         # forward + CTC + backward of a resident step replayed from a hipGraph (one graph per batch geometry): the ~60
         # launches and 4 cross-stream hand-overs of the step cost the host ~0.7 ms of Python / ctypes per step otherwise
         self.use_graph = os.environ.get("SL_USE_GRAPH", "0") == "1"
@@ -495,7 +502,34 @@ class Engine:
             wv, bv = self.layer_param_views(self.params, p)
             wv[:, :s.cin, :s.cout] = torch.as_tensor(np.ascontiguousarray(w, dtype=np.float32)).to(self.device)
             bv[:s.cout] = torch.as_tensor(np.ascontiguousarray(b, dtype=np.float32)).to(self.device)
+            if self._has_ones_output(p):
+                bv[p.cout_pad - 1] = 1.0  # relu(0 * x + 1) = elu(1) = 1: the ones channel (see self.ones_channel)
         self._packed_dirty = True
+
+    def _has_ones_output(self, plan):
+        """hidden layer whose output has channel padding: its last padded channel is the constant 1"""
+        return self.ones_channel and plan.index < len(self.plans) - 1 and plan.cout_pad > plan.spec.cout
+
+    def _ones_input_layers(self, first):
+        """trainable layers whose input carries a ones channel: their bias gradient is row cin_pad - 1 of dW"""
+        return [i for i in range(max(first, 1), len(self.plans)) if self._has_ones_output(self.plans[i - 1])]
+
+    def _bias_grads_from_wgrad(self, layers, copy, stream):
+        """One sl_bias_grad_from_wgrad launch for `layers` (their weight gradients are complete on `stream`)."""
+        layers = list(layers)
+        for lo in range(0, len(layers), 16):
+            chunk = tuple(layers[lo:lo + 16])
+            table = self._bgw_tables.get(chunk)
+            if table is None:
+                table = (_lib.BgwLayer * len(chunk))()
+                for entry, i in zip(table, chunk):
+                    q = self.plans[i]
+                    entry.w_off, entry.b_off = q.w_off, q.b_off
+                    entry.k, entry.cin_pad, entry.cout_pad, entry.tap = q.spec.kernel_size, q.cin_pad, q.cout_pad, q.pad_left
+                self._bgw_tables[chunk] = table
+            self._launch("bgrad_from_wgrad:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name),
+                         "sl_bias_grad_from_wgrad", self.grads.data_ptr(), table, len(chunk), 1 if copy else 0,
+                         stream.cuda_stream)
 
     def _unpad(self, tensor):
         out = []
@@ -779,7 +813,8 @@ class Engine:
         side = self._side_stream
         # launch list: the default schedule only (no dropout masks to rescale, no early Adam, no second wgrad stream)
         plain = not (early_adam or self.overlap_wgrad or buf.dropped or os.environ.get("SL_DEFER_BGRAD") == "skip")
-        key = ("bwd", main.cuda_stream, on_bucket_ready is not None, self.defer_bias_grads, self.frozen_layer_count,
+        key = ("bwd", main.cuda_stream, on_bucket_ready is not None, self.defer_bias_grads, self.ones_channel,
+               self.frozen_layer_count,
                self.group_wgrad, self.use_chain, tuple(sorted(self.nt_cfg.items()))) if plain else None
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
@@ -847,6 +882,11 @@ class Engine:
                                                                        self.dtype_code)):
                     dchain[e0] = layers
                     dchain_skip.update(layers[1:])
+        # bias gradients out of the weight-gradient GEMM (self.ones_channel): which layers, and whether the row holds the
+        # bias gradient (the ones were not touched by dropout) or only has to be zeroed before the optimizer sees it
+        ones_in = self._ones_input_layers(first)
+        simple = not (early_adam or self.overlap_wgrad)
+        ones_db = set(ones_in) if (simple and not buf.dropped and self.dtype == "bf16") else set()
         # (those two need every layer's bias gradient at once; defer_bias_grads = False restores one hand-over per layer)
         defer = self.defer_bias_grads and not (early_adam or self.overlap_wgrad)
         pending, pending_bytes = [], 0  # layers whose bias-gradient launch is still owed to the side stream
@@ -858,9 +898,9 @@ class Engine:
             # Every hand-over is an event record on MAIN, and the record costs MAIN ~6 us of pipeline drain
             # (profiles/r01j: 11 records = the only gaps in the step's timeline); g[i] stays intact until the next step,
             # so the small layers' bias gradients can wait for a common hand-over.
-            if os.environ.get("SL_DEFER_BGRAD") != "skip":  # ("skip": timing experiment only, no bias gradients)
+            if os.environ.get("SL_DEFER_BGRAD") != "skip" and i not in ones_db:  # ("skip": timing experiment only)
                 pending.append(i)
-            pending_bytes += buf.g[i].numel() * buf.g[i].element_size()
+                pending_bytes += buf.g[i].numel() * buf.g[i].element_size()
             if pending and (not defer or pending_bytes >= (128 << 20) or i <= first + 1 or
                             (on_bucket_ready is not None and i == split)):
                 # g[j], j in pending (CTC gradient or a previous dgrad) are complete at this point of MAIN
@@ -872,6 +912,8 @@ class Engine:
                                      dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
                                      self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
                                      buf.wgrad_ws.numel(), wgrad_stream.cuda_stream)
+                        if i in ones_in:
+                            self._bias_grads_from_wgrad([i], False, wgrad_stream)
                     for j in pending:
                         _, db_j = self.layer_param_views(self.grads, self.plans[j])
                         self._launch("bgrad:" + self.plans[j].spec.name, "sl_bias_grad", buf.g[j].data_ptr(),
@@ -892,12 +934,18 @@ class Engine:
                                  dw_lo.data_ptr(), ctypes.byref(buf.wgrad_geom[lo]), hi - lo + 1, stride_elems,
                                  stride_elems, plo.w_numel + plo.cout_pad, 0, buf.wgrad_ws.data_ptr(),
                                  buf.wgrad_ws.numel(), main.cuda_stream)
+                    if not simple:
+                        self._bias_grads_from_wgrad([j for j in range(lo, hi + 1) if j in ones_in], False, main)
             elif not self.overlap_wgrad:
                 self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
                              dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
                              self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
                              buf.wgrad_ws.numel(), main.cuda_stream)
+                if not simple and i in ones_in:
+                    self._bias_grads_from_wgrad([i], False, main)
                 if on_bucket_ready is not None and i == split:
+                    if simple:
+                        self._bias_grads_from_wgrad([j for j in ones_in if j >= split], bool(ones_db), main)
                     join_side()
                     bucket_ready(0)
             if i in dchain:
@@ -944,6 +992,10 @@ class Engine:
                     bucket_ready(1)
             join_side()
         else:
+            if simple:
+                rest = [j for j in ones_in if on_bucket_ready is None or j < split]
+                if rest:
+                    self._bias_grads_from_wgrad(rest, bool(ones_db), main)
             join_side()
             if on_bucket_ready is not None and split > first:
                 bucket_ready(1)

@@ -87,9 +87,14 @@ def test_forward_f32_layer_by_layer(t):
         want = np.maximum(zs[i], 0)
         err = np.abs(got - want).max() / np.abs(want).max()
         assert err < 1e-4, "layer {} ({}) activation error {}".format(i, case["specs"][i].name, err)
-        # layout invariants: halo rows, rows past the valid time and padded channels stay zero
+        # layout invariants: halo rows, rows past the valid time and padded channels stay zero -- except the last padded
+        # channel of a hidden layer, which carries the constant 1 on every valid frame (Engine.ones_channel)
         assert not raw[:, :HALO].any() and not raw[:, HALO + buf.t_out:].any()
-        assert not raw[:, :, case["specs"][i].cout:].any()
+        padding = raw[:, :, case["specs"][i].cout:]
+        if eng.ones_channel and padding.shape[2]:
+            assert (padding[:, HALO:HALO + buf.t_out, -1] == 1).all()
+            padding = padding[:, :, :-1]
+        assert not padding.any()
     assert np.abs(probs - ref_probs).max() < 1e-5
     np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
 
@@ -624,6 +629,8 @@ def test_single_layer_kernels_with_exact_operands(dtype, layer):
         x_in = np.maximum(_bf16_exact(rng, (3, t_out, s.cin)), 0)
         xt = torch.zeros_like(buf.y[layer - 1])
         xt[:, HALO:HALO + t_out, :s.cin] = torch.tensor(x_in).to(td)
+        if eng._has_ones_output(eng.plans[layer - 1]):
+            xt[:, HALO:HALO + t_out, -1] = 1  # the ones channel a forward pass would have put there
         buf.y[layer - 1].copy_(xt)
     g = _bf16_exact(rng, (3, t_out, s.cout), 0.01)
     gt = torch.zeros_like(buf.g[layer])
@@ -652,7 +659,14 @@ def test_single_layer_kernels_with_exact_operands(dtype, layer):
     assert rel_l2(dw, dw_ref) < 2e-6, ("wgrad", dtype, layer, rel_l2(dw, dw_ref))
     assert rel_l2(db, db_ref) < 2e-6, ("bias grad", dtype, layer, rel_l2(db, db_ref))
     full = dw_v.cpu().numpy()
-    assert not full[:, s.cin:, :].any() and not full[:, :, s.cout:].any()  # padded lanes stay zero
+    assert not full[:, :, s.cout:].any()  # padded lanes stay zero ...
+    p = eng.plans[layer]
+    if layer > 0 and eng._has_ones_output(eng.plans[layer - 1]):
+        # ... except the row of the input's ones channel: at the tap that reads the frame itself it IS the bias gradient
+        assert not full[:, s.cin:p.cin_pad - 1, :].any()
+        assert rel_l2(full[p.pad_left, p.cin_pad - 1, :s.cout], db_ref) < 2e-6
+    else:
+        assert not full[:, s.cin:, :].any()
     # ---- dgrad (with the ReLU mask of the layer input)
     if layer > 0:
         eng.lib.call("sl_conv1d_nt", buf.g[layer].data_ptr(), eng.w_dgrad[layer].data_ptr(), None,

@@ -504,11 +504,17 @@ def test_fp32_mfma_kernels_against_the_valu_kernels_and_float64():
         yb, _ = layer_activation(eb, eb.cur, i)
         assert np.abs(ya - yb).max() <= 2e-5 * max(np.abs(yb).max(), 1e-30), i
     # layout invariants of the MFMA kernels' masked stores: halo rows, rows beyond T' and padded channels stay zero
+    # (but for the ones channel of the activations, Engine.ones_channel)
     for tensors in (ea.cur.y, ea.cur.g[:-1]):
         for i, t in enumerate(tensors):
-            raw = t.cpu().numpy()
+            raw = t.float().cpu().numpy()
             c = ea.specs[i].cout
-            assert not raw[:, :HALO].any() and not raw[:, HALO + ea.cur.t_out:].any() and not raw[:, :, c:].any(), i
+            assert not raw[:, :HALO].any() and not raw[:, HALO + ea.cur.t_out:].any(), i
+            padding = raw[:, :, c:]
+            if tensors is ea.cur.y and ea.ones_channel and i < len(ea.plans) - 1 and padding.shape[2]:
+                assert (padding[:, HALO:HALO + ea.cur.t_out, -1] == 1).all(), i
+                padding = padding[:, :, :-1]
+            assert not padding.any(), i
 
 
 def test_config2_greedy_decode_bit_exact_at_batch_32():
@@ -708,7 +714,8 @@ def test_fused_run_of_inner_layers_against_the_single_launches():
         for i in range(len(ea.plans) - 1):
             ya, yb = ea.cur.y[i].float().cpu().numpy(), eb.cur.y[i].float().cpu().numpy()
             c = ea.specs[i].cout
-            assert not ya[:, :HALO].any() and not ya[:, HALO + t_out:].any() and not ya[:, :, c:].any(), i
+            assert not ya[:, :HALO].any() and not ya[:, HALO + t_out:].any() and not ya[:, :, c:-1].any(), i
+            assert (ya[:, HALO:HALO + t_out, -1] == 1).all() and (yb[:, HALO:HALO + t_out, -1] == 1).all(), i  # ones channel
             scale = max(np.abs(yb).max(), 1e-30)
             assert np.abs(ya - yb).max() <= 2.0 ** -6 * scale, (t, "y", i, np.abs(ya - yb).max() / scale)
             assert rel_l2(ya, yb) < 3e-3, (t, "y", i, rel_l2(ya, yb))
@@ -723,3 +730,53 @@ def test_fused_run_of_inner_layers_against_the_single_launches():
             np.testing.assert_allclose(la, mirror["losses"], rtol=1e-3)
             for name, i in (("output_conv", 10), ("big_conv_2", 9), ("big_conv_1", 8)):
                 assert rel_l2(ga[i][0], mirror["grads"][i][0]) < 2e-2, name
+
+
+# ------------------------------------------------------------------------------------------ bias gradients out of the wgrad GEMM
+@pytest.mark.parametrize("dropout", [None, 0.3])
+def test_bias_gradients_from_the_ones_channel(dropout):
+    """Engine.ones_channel: the last padded output channel of every hidden layer is the constant 1, so the next layer's
+    weight-gradient GEMM leaves that layer's bias gradient in row cin_pad - 1 of dW (sl_bias_grad_from_wgrad) and the ten
+    sl_bias_grad passes over g are not launched.  Same bias gradients as those passes (fp32 sums of the same bf16 values in
+    another order) and as the oracle's bf16 mirror; the padded weights stay exactly zero and the ones stay ones through
+    optimisation steps -- also when dropout hits the ones (then the passes are used and the row is only zeroed)."""
+    import torch
+    case = make_case(b=3, t=300, seed=91)
+    res = {}
+    for ones in (True, False):
+        eng = make_engine(case, "bf16", lr=1e-3)
+        assert eng.ones_channel
+        if not ones:
+            eng.ones_channel = False
+            eng.set_weights(eng.get_weights())  # (rebuilds the parameter buffer without the ones biases)
+        if dropout:
+            eng.dropout_rate, eng.dropout_seed = dropout, 5
+        eng.load_input(case["x"])
+        eng.set_labels(case["labels"], case["label_lengths"], case["prediction_lengths"])
+        eng.forward(training=True)
+        losses = eng.ctc().cpu().numpy()
+        eng.backward()
+        torch.cuda.synchronize()
+        grads = eng.get_gradients()
+        tags = [op[3] for ops in eng.cur.launch_lists.values() for op in ops if op[0] == 0] if not dropout else []
+        if not dropout:
+            assert tags.count("sl_bias_grad") == (1 if ones else len(eng.plans))
+            assert tags.count("sl_bias_grad_from_wgrad") == (1 if ones else 0)
+        res[ones] = (eng, losses, grads)
+    (ea, la, ga), (eb, lb, gb) = res[True], res[False]
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    for i in range(len(ea.plans)):
+        assert rel_l2(ga[i][0], gb[i][0]) < 1e-6, i      # weight gradients: the same kernels on the same data
+        assert rel_l2(ga[i][1], gb[i][1]) < 1e-5, (i, rel_l2(ga[i][1], gb[i][1]))  # bias gradients: GEMM row vs pass over g
+    # optimisation steps: padded weights stay zero, the ones stay ones, both engines stay together
+    for eng in (ea, eb):
+        for _ in range(3):
+            eng.train_step(case["x"], case["labels"], np.array(case["label_lengths"]), np.array(case["prediction_lengths"]))
+    for p in ea.plans:
+        wv, bv = ea.layer_param_views(ea.params, p)
+        wv, bv = wv.cpu().numpy(), bv.cpu().numpy()
+        assert not wv[:, p.spec.cin:, :].any() and not wv[:, :, p.spec.cout:].any(), p.spec.name
+        assert not bv[p.spec.cout:p.cout_pad - 1].any() and bv[p.cout_pad - 1] == (1.0 if ea._has_ones_output(p) else 0.0)
+    if not dropout:
+        for (wa, ba), (wb, bb) in zip(ea.get_weights(), eb.get_weights()):
+            assert rel_l2(wa, wb) < 1e-4 and np.abs(ba - bb).max() < 1e-4 * max(np.abs(bb).max(), 1e-6) + 1e-6
