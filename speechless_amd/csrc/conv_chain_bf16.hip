@@ -16,14 +16,10 @@
 //   * eight waves = two per SIMD; wave w owns output channels [32w, 32w + 32) for all rows: per step 2 weight fragments
 //     + up to 7 activation fragments per k-half feed up to 28 MFMAs (v_mfma_f32_16x16x32_bf16), D^T orientation (MFMA rows
 //     = channels) so that a lane ends with 4 consecutive channels of one time row: 8-byte LDS / HBM stores.
-// STATUS (round 2): parity-tested (tests/test_gpu_round2.py::test_fused_run_of_inner_layers_against_the_single_launches)
-// but not yet faster than the launches it replaces -- forward 179 us against 7 x 24.4 us, input gradients 207 against 185 --
-// so the engine keeps it opt-in (Engine.use_chain / SL_CHAIN=1).  A step takes 0.91 us against 0.45 us of MFMA issue time:
-// the LDS array is busy ~1000 cycles per step (144 KB of fragment reads at 256 B/clk + the 32 KB DMA write) and, with all
-// eight waves in lockstep behind one barrier per step, that time does not overlap the MFMA phase.  History: a
-// wave-uniform `if (m < mt)` around every tile 1.26 us per step; compiler-visible LDS reads (vmcnt(0) before the first read
-// of every step) 0.96; per-read address arithmetic 0.91.  Next: reads of step g + 1 under the MFMAs of step g (barrier in
-// the middle of a step) and a 2 x 4 wave layout (-17 % fragment bytes).
+//   * a wave requests exactly the weight rows it reads itself, so the ring needs NO barrier: the waves drift apart inside a
+//     layer and one wave's request / read phase runs under its SIMD partner's MFMAs; barriers only at the layer ends.
+// Measured (config 3, tools/chain_time.py, tools/chain_stamps.py; history in DESIGN.md section 3.1a): forward 124 us against
+// 7 x 23.6 = 165 us of single launches, input gradients 126 against 185 us.  A step is 930 cycles against 713 of MFMA issue.
 // LDS: activations 4 chunk-slabs x 120 rows x 128 B = 60 KB (row r, 16-byte slot s stored at slot s ^ (r & 7): a fragment
 // read at any tap offset stays conflict-free, as in the slab kernel of conv_nt_bf16.hip) + 3 x 32 KB weight slots.
 // Rows outside [0, T') are forced to zero after every layer (SAME padding: relu(bias) is not zero).

@@ -37,10 +37,9 @@ def main():
     rc = raw.sl_chain_probe_read(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(out.nbytes))
     assert rc == 0, rc
     t = out.reshape(256, 8, 40).astype(np.int64)
-    t = t[:250]
     base = t[:, :, 0].min(axis=1, keepdims=True)[:, :, None]
     rel = t - base
-    print("direction", direction, "; cycles of the s_memtime counter, mean over 250 work-groups x 8 waves")
+    print("direction", direction, "; cycles of the s_memtime counter, mean over 256 work-groups x 8 waves (backward: 'barrier-2 wait' includes the ReLU-mask pass)")
     print("begin -> input rows in LDS: {:.0f}".format((rel[:, :, 1]).mean()))
     prev = rel[:, :, 1]
     tot = dict(steps=0., wait1=0., epi=0., wait2=0.)
@@ -56,9 +55,7 @@ def main():
     end = rel[:, :, 38]
     print("total {:.0f} cycles; steps {:.0f}, barrier-1 {:.0f}, epilogue {:.0f}, barrier-2 {:.0f}".format(
         end.mean(), tot["steps"], tot["wait1"], tot["epi"], tot["wait2"]))
-    print("work-group start spread (max - min of begin over work-groups): {:.0f}; end spread {:.0f}".format(
-        float(t[:, :, 0].min(axis=1).max() - t[:, :, 0].min()), float(t[:, :, 38].max(axis=1).max() - t[:, :, 38].max(axis=1).min())))
-    print("whole launch (first begin -> last end): {:.0f}".format(float(t[:, :, 38].max() - t[:, :, 0].min())))
+    print("whole launch (first begin -> last end): {:.0f} cycles".format(float(t[:, :, 38].max() - t[:, :, 0].min())))
 
 
 if __name__ == "__main__":
