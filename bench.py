@@ -447,7 +447,10 @@ def main():
                             "kernel's launches per step",
             "duration_note": "HIP events recorded by the library immediately around the kernel on its launch stream "
                              "(sl_profile_next_kernel) in otherwise un-instrumented steps; compare with the average "
-                             "of wgrad_tn_ilv_kernel in profiles/r02j_kernel_stats.csv",
+                             "of wgrad_tn_ilv_kernel in profiles/r02k_kernel_stats.csv -- that average is SHORTER (177.6 us "
+                             "= 0.55 of peak): the chip is power-limited under this step (1.2 kW, tools/power_probe.py) "
+                             "and the profiler's gaps between kernels let every kernel run at a higher clock than in the "
+                             "un-instrumented step measured here (DESIGN.md section 4)",
             "flops_per_launch": dom_flops, "avg_launch_ms": dom_ms}
     if args.config in (2, 3):
         nt_flops = fl[names.index("big_conv_1")] * BATCH_PER_GPU
