@@ -15,7 +15,8 @@
 //     (global_load_lds, counted vmcnt), two steps ahead and across layer boundaries;
 //   * eight waves = two per SIMD; wave w owns output channels [32w, 32w + 32) for all rows: per step 2 weight fragments
 //     + up to 7 activation fragments per k-half feed up to 28 MFMAs (v_mfma_f32_16x16x32_bf16), D^T orientation (MFMA rows
-//     = channels) so that a lane ends with 4 consecutive channels of one time row: 8-byte LDS / HBM stores.
+//     = channels) so that a lane ends with 4 consecutive channels of one time row (8-byte LDS stores; the HBM side is
+//     row-contiguous from the LDS copy, 16 bytes per lane).
 //   * a wave requests exactly the weight rows it reads itself, so the ring needs NO barrier: the waves drift apart inside a
 //     layer and one wave's request / read phase runs under its SIMD partner's MFMAs; barriers only at the layer ends.
 // Measured (config 3, tools/chain_time.py, tools/chain_stamps.py; history in DESIGN.md section 3.1a): forward 124 us against
