@@ -886,7 +886,7 @@ class Engine:
         # bias gradient (the ones were not touched by dropout) or only has to be zeroed before the optimizer sees it
         ones_in = self._ones_input_layers(first)
         simple = not (early_adam or self.overlap_wgrad)
-        ones_db = set(ones_in) if (simple and not buf.dropped and self.dtype == "bf16") else set()
+        ones_db = set(ones_in) if (simple and not buf.dropped) else set()
         # (those two need every layer's bias gradient at once; defer_bias_grads = False restores one hand-over per layer)
         defer = self.defer_bias_grads and not (early_adam or self.overlap_wgrad)
         pending, pending_bytes = [], 0  # layers whose bias-gradient launch is still owed to the side stream

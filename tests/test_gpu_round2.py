@@ -733,8 +733,9 @@ def test_fused_run_of_inner_layers_against_the_single_launches():
 
 
 # ------------------------------------------------------------------------------------------ bias gradients out of the wgrad GEMM
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("dropout", [None, 0.3])
-def test_bias_gradients_from_the_ones_channel(dropout):
+def test_bias_gradients_from_the_ones_channel(dropout, dtype):
     """Engine.ones_channel: the last padded output channel of every hidden layer is the constant 1, so the next layer's
     weight-gradient GEMM leaves that layer's bias gradient in row cin_pad - 1 of dW (sl_bias_grad_from_wgrad) and the ten
     sl_bias_grad passes over g are not launched.  Same bias gradients as those passes (fp32 sums of the same bf16 values in
@@ -744,7 +745,7 @@ def test_bias_gradients_from_the_ones_channel(dropout):
     case = make_case(b=3, t=300, seed=91)
     res = {}
     for ones in (True, False):
-        eng = make_engine(case, "bf16", lr=1e-3)
+        eng = make_engine(case, dtype, lr=1e-3)
         assert eng.ones_channel
         if not ones:
             eng.ones_channel = False
