@@ -85,6 +85,37 @@ def main():
         t1 = time.perf_counter()
         phases.append((name, t0, t1, n))
 
+    # single launches of the step on their real operands (energy per launch = power x time; algorithmic GFLOP beside it)
+    import ctypes
+    from speechless_amd import _lib
+    eng = engines[True]
+    buf = eng.cur
+    st = torch.cuda.current_stream().cuda_stream
+    i = [q.index for q in eng.plans if q.spec.name == "big_conv_1"][0]
+    p = eng.plans[i]
+    _, bias = eng.layer_param_views(eng.params, p)
+    dw, _ = eng.layer_param_views(eng.grads, p)
+
+    def fwd_big1():
+        eng.lib.call("sl_conv1d_nt", buf.y[i - 1].data_ptr(), eng.w_fwd[i].data_ptr(), bias.data_ptr(), None,
+                     buf.y[i].data_ptr(), ctypes.byref(buf.fwd_geom[i]), _lib.EPI_BIAS_RELU, eng.dtype_code, 0, 0,
+                     buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+
+    def dgrad_big1():
+        eng.lib.call("sl_conv1d_nt", buf.g[i].data_ptr(), eng.w_dgrad[i].data_ptr(), None, buf.y[i - 1].data_ptr(),
+                     buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_RELU_MASK, eng.dtype_code, 0, 0,
+                     buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+
+    def wgrad_big1():
+        eng.lib.call("sl_conv1d_wgrad", buf.y[i - 1].data_ptr(), buf.g[i].data_ptr(), dw.data_ptr(),
+                     ctypes.byref(buf.wgrad_geom[i]), eng.dtype_code, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+    a1 = torch.randn(16384, 8192, device="cuda", dtype=torch.bfloat16)
+    b1 = torch.randn(8192, 2048, device="cuda", dtype=torch.bfloat16)
+    phase("idle", lambda: time.sleep(0.01), 1.0)
+    phase("big_conv_1 forward alone (512 GF)", fwd_big1, 3.0)
+    phase("big_conv_1 input gradient alone (512 GF)", dgrad_big1, 3.0)
+    phase("big_conv_1 weight gradient alone (512 GF)", wgrad_big1, 3.0)
+    phase("vendor GEMM 16384x8192x2048 (550 GF)", lambda: torch.matmul(a1, b1), 3.0)
     phase("idle", lambda: time.sleep(0.01), 1.0)
     phase("step, fused inner layers", engines[True].train_step_resident, 4.0)
     phase("idle", lambda: time.sleep(0.01), 1.0)
