@@ -31,8 +31,8 @@ def run(cfg):
 run(0); ref = eng.grads.clone()
 flops = 2.0 * B * buf.t_out * 7 * 250 * 250 * (hi - lo + 1)
 res = []
-for (wm, wn, stg) in [(2, 2, 2), (2, 2, 3), (4, 2, 2), (2, 4, 2), (4, 4, 2)]:
-    for sp in (1, 2, 3, 4, 6, 8, 16):
+for (wm, wn, stg) in [(2, 2, 2), (2, 2, 3), (4, 2, 2), (2, 4, 2), (4, 4, 2), (4, 4, 10)]:
+    for sp in (1, 2, 3, 4, 5, 6, 8, 16):
         cfg = cfg_word(wm, wn, stg, sp)
         try:
             run(cfg); torch.cuda.synchronize()
@@ -45,4 +45,4 @@ for (wm, wn, stg) in [(2, 2, 2), (2, 2, 3), (4, 2, 2), (2, 4, 2), (4, 4, 2)]:
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 5
         res.append((ms, wm, wn, stg, sp, err))
-for r in sorted(res)[:8]: print("%.4f ms  %4.0f TFLOP/s  cfg(wm,wn,stages,splits)=%s err=%.1e" % (r[0], flops / r[0] / 1e9, r[1:5], r[5]))
+for r in sorted(res)[:12]: print("%.4f ms  %4.0f TFLOP/s  cfg(wm,wn,stages,splits)=%s err=%.1e" % (r[0], flops / r[0] / 1e9, r[1:5], r[5]))
