@@ -781,3 +781,37 @@ def test_bias_gradients_from_the_ones_channel(dropout, dtype):
     if not dropout:
         for (wa, ba), (wb, bb) in zip(ea.get_weights(), eb.get_weights()):
             assert rel_l2(wa, wb) < 1e-4 and np.abs(ba - bb).max() < 1e-4 * max(np.abs(bb).max(), 1e-6) + 1e-6
+
+
+# ------------------------------------------------------------------------------------------ the round's fast paths over odd shapes
+@pytest.mark.parametrize("b,t", [(1, 33), (2, 127), (5, 129), (3, 255), (7, 641), (4, 1031)])
+def test_fast_paths_against_the_plain_launches_over_odd_shapes(b, t):
+    """Fused inner-layer launches + bias gradients out of the weight-gradient GEMM + wave CTC lattice (the defaults) against
+    single launches + sl_bias_grad passes + log-domain lattice on batches whose sizes hit the corners of the tilings: one
+    utterance, fewer frames than a 64-frame tile, one frame more than a tile / than a 256-row time tile, ragged
+    prediction lengths.  Same loss; gradients as close as two summation orders of the same bf16 data allow."""
+    import torch
+    from speechless_amd import _lib
+    case = make_case(b=b, t=t, seed=200 + t)
+    res = {}
+    try:
+        for fast in (True, False):
+            eng = make_engine(case, "bf16")
+            if not fast:
+                eng.use_chain = False
+                eng.ones_channel = False
+                eng.set_weights(eng.get_weights())
+            _lib.lib().call("sl_ctc_select", 0 if fast else 1)
+            losses, grads = run_loss_and_grads(eng, case)
+            res[fast] = (losses, grads, eng)
+    finally:
+        _lib.lib().call("sl_ctc_select", 0)
+    (la, ga, ea), (lb, gb, _) = res[True], res[False]
+    tags = [op[3] for ops in ea.cur.launch_lists.values() for op in ops if op[0] == 0]
+    assert "sl_conv1d_chain" in tags and "sl_bias_grad_from_wgrad" in tags
+    np.testing.assert_allclose(la, lb, rtol=2e-3)  # (bf16 activations through two different accumulation orders)
+    for i in range(len(ga)):
+        assert rel_l2(ga[i][0], gb[i][0]) < 5e-2, (i, rel_l2(ga[i][0], gb[i][0]))  # ReLU-mask flips between the orders
+        assert rel_l2(ga[i][1], gb[i][1]) < 5e-2, (i, rel_l2(ga[i][1], gb[i][1]))
+    for i in (8, 9, 10):  # above the fused run the two paths see the same activations up to those flips' echo
+        assert rel_l2(ga[i][0], gb[i][0]) < 2e-2, i
