@@ -815,3 +815,21 @@ def test_fast_paths_against_the_plain_launches_over_odd_shapes(b, t):
         assert rel_l2(ga[i][1], gb[i][1]) < 5e-2, (i, rel_l2(ga[i][1], gb[i][1]))
     for i in (8, 9, 10):  # above the fused run the two paths see the same activations up to those flips' echo
         assert rel_l2(ga[i][0], gb[i][0]) < 2e-2, i
+
+
+def test_ctc_falls_back_to_the_log_domain_lattice_where_the_wave_lattice_does_not_fit(hip_lib):
+    """The wave lattice holds 2 * 255 + 1 states and 63 classes; beyond that sl_ctc_loss_grad must pick the log-domain
+    lattice by itself (it was the default before, so long labels used to be covered implicitly): labels of 300 graphemes
+    over 700 frames, and 64 classes, against the float64 oracle."""
+    from test_gpu_parity import run_ctc_kernel
+    rng = np.random.RandomState(17)
+    for k, n, t in ((29, 300, 700), (64, 40, 120)):
+        lab_len = [n, n // 3]
+        labels = o.pack_label_batch([list(rng.randint(0, k - 1, size=m)) for m in lab_len])
+        logits = rng.randn(2, t, k).astype(np.float32)
+        input_len = [t, t - 7]
+        _, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
+        ref_p = o.softmax(logits.astype(np.float64))
+        ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
+        np.testing.assert_allclose(loss, ref_loss, rtol=2e-5)
+        assert rel_l2(dl, o.softmax_backward(ref_p, ref_dp)) < 2e-3, (k, n)
