@@ -231,6 +231,10 @@ typedef struct {
 } sl_adam_layer;
 int sl_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers, int n_layers,
                         int dtype, int step, float lr, float beta1, float beta2, float eps, void* stream);
+/* The operand rewrite alone (sl_pack_weights for several layers in one launch, same table): used when the masters were
+ * updated elsewhere -- the data-parallel step with a sharded optimizer runs sl_adam_step on this rank's slice of the flat
+ * buffers and all-gathers the masters (speechless_amd/parallel.py; the reference has no counterpart, main.py:14-24). */
+int sl_pack_layers(const float* param, const sl_adam_layer* layers, int n_layers, int dtype, void* stream);
 
 /* ---- Bias gradients out of the weight-gradient GEMM ("ones channel") ------------------------------------------------
  * The channel padding of an activation tensor (250 -> 256, 2000 -> 2048) is multiplied through every GEMM anyway.  When the

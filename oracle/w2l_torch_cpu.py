@@ -69,24 +69,53 @@ def loss_and_gradients(specs, weights, input_batch, labels, prediction_lengths, 
                 grads=grads)
 
 
+def keras_adam_update(params, state, step, lr=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8):
+    """Keras-2.0 Adam (keras/optimizers.py of the 2.0.x line the reference pins nothing tighter than; net.py:132):
+    lr_t = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t);  m, v as usual;  p -= lr_t * m / (sqrt(v) + epsilon)
+    -- epsilon OUTSIDE the bias correction, unlike torch.optim.Adam.  In place on the leaf tensors `params`
+    (their .grad read), state = (list of m, list of v)."""
+    ms, vs = state
+    lr_t = lr * np.sqrt(1.0 - beta_2 ** step) / (1.0 - beta_1 ** step)
+    with torch.no_grad():
+        grads = [p.grad for p in params]
+        torch._foreach_mul_(ms, beta_1)
+        torch._foreach_add_(ms, grads, alpha=1.0 - beta_1)
+        torch._foreach_mul_(vs, beta_2)
+        torch._foreach_addcmul_(vs, grads, grads, value=1.0 - beta_2)
+        denom = torch._foreach_sqrt(vs)
+        torch._foreach_add_(denom, epsilon)
+        torch._foreach_addcdiv_(params, ms, denom, value=-lr_t)
+
+
 def timed_training_steps(specs, weights, input_batch, labels, prediction_lengths, label_lengths, steps=1,
-                         warmup=0, eps=1e-8, lr=1e-4):
-    """fwd + CTC + bwd + Adam on the host cores; returns seconds per step (list).  Used by bench.py's
-    cpu_baseline leg only."""
+                         warmup=0, eps=1e-8, lr=1e-4, record_first=False):
+    """fwd + CTC + bwd + Keras-form Adam on the host cores; returns seconds per step (list).  Used by bench.py's
+    cpu_baseline leg.  record_first=True: also returns what the FIRST step (the one from `weights`) computed --
+    per-utterance losses, probabilities, gradients (Keras layout) and the weights after its update -- so that the
+    same leg doubles as the parity checker at the benchmark's own batch size (bench.py `parity`)."""
     import time
     tweights = to_torch_weights(weights)
     params = [p for wb in tweights for p in wb]
-    opt = torch.optim.Adam(params, lr=lr, eps=1e-8)
+    state = ([torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params])
     x = torch.tensor(np.asarray(input_batch), dtype=torch.float32)
     times = []
+    record = None
     for it in range(warmup + steps):
         t0 = time.perf_counter()
-        opt.zero_grad(set_to_none=True)
+        for p in params:
+            p.grad = None
         probs = forward_probs(specs, tweights, x)
-        loss = per_utterance_ctc(probs, labels, prediction_lengths, label_lengths, eps).mean()
-        loss.backward()
-        opt.step()
+        losses = per_utterance_ctc(probs, labels, prediction_lengths, label_lengths, eps)
+        losses.mean().backward()
+        if record_first and it == 0:
+            record = dict(losses=losses.detach().numpy().copy(), probs=probs.detach().numpy().copy(),
+                          grads=[(np.ascontiguousarray(np.transpose(w.grad.numpy(), (2, 1, 0))), b.grad.numpy().copy())
+                                 for (w, b) in tweights])
+        keras_adam_update(params, state, it + 1, lr=lr)
+        if record_first and it == 0:
+            record["weights_after"] = [(np.ascontiguousarray(np.transpose(w.detach().numpy(), (2, 1, 0))),
+                                        b.detach().numpy().copy()) for (w, b) in tweights]
         dt = time.perf_counter() - t0
         if it >= warmup:
             times.append(dt)
-    return times
+    return (times, record) if record_first else times

@@ -102,6 +102,7 @@ SIGNATURES = {
     "sl_bias_grad_from_wgrad": (c_int, [c_void_p, POINTER(BgwLayer), c_int, c_int, c_void_p]),
     "sl_adam_pack_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AdamLayer), c_int, c_int, c_int,
                                     c_float, c_float, c_float, c_float, c_void_p]),
+    "sl_pack_layers": (c_int, [c_void_p, POINTER(AdamLayer), c_int, c_int, c_void_p]),
 }
 
 

@@ -68,7 +68,7 @@ def _compile(src):
 
 
 def build_host(force=False):
-    newest = max(f.stat().st_mtime for f in HOST_SOURCES)
+    newest = max(f.stat().st_mtime for f in HOST_SOURCES + [PACKAGE_DIR.parent / "include" / "speechless_host.h"])
     if not force and HOST_LIB_PATH.exists() and HOST_LIB_PATH.stat().st_mtime >= newest:
         return HOST_LIB_PATH
     cmd = [CXX, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-o", str(HOST_LIB_PATH)] + \

@@ -949,7 +949,16 @@ extern "C" size_t sl_ctc_workspace_bytes(int batch, int t_out, int l_max) {
     if (batch <= 0 || t_out <= 0 || l_max < 0) return 0;
     // log-domain alpha + beta lattices and the class position lists (pos[l_max] | start[k + 1], k <= 64) per utterance;
     // when the labels fit the wave lattice: its double lattices, per-frame exponents, log2 Z and repair flags as well
-    return ctc_layout(batch, t_out, l_max).total;
+    // MONOTONIC in l_max: labels beyond the wave lattice's 255 graphemes drop its double lattices from the layout, so the
+    // largest need below l_max is that of the longest label the wave lattice still takes -- a workspace sized for l_max
+    // serves every batch with shorter labels (a buffer set sees both in ordinary variable-length training)
+    size_t total = ctc_layout(batch, t_out, l_max).total;
+    const int wave_max = (64 * WNS - 1) / 2;
+    if (l_max > wave_max) {
+        const size_t t2 = ctc_layout(batch, t_out, wave_max).total;
+        if (t2 > total) total = t2;
+    }
+    return total;
 }
 
 extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* labels, const int32_t* label_len,

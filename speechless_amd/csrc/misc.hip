@@ -127,7 +127,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 //   w_fwd [cout][k][cin]   (32x64 tile transposed through LDS)   and   w_dgrad[cin][k-1-tap][cout]
 // 4 fp32 reads + 3 fp32 writes + 2 narrow writes per parameter instead of Adam (4r+3w) followed by pack (1r+2w).
 // grid (cout/64, cin/32, k + 1): z == k is the bias block (only y == 0 works there).
-template <typename T>
+template <typename T, bool ADAM = true>
 __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __restrict__ p, const float* __restrict__ g,
                                                 float* __restrict__ m, float* __restrict__ v, T* __restrict__ wf,
                                                 T* __restrict__ wd, int k, int cin, int cout, float lr_t, float b1,
@@ -136,6 +136,7 @@ __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __
     const int co0 = bx * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     auto adam4 = [&](long idx) {
+        if (!ADAM) return *(const f32x4*)(p + idx);  // pack only: the masters are already up to date
         const f32x4 gv = *(const f32x4*)(g + idx);
         f32x4 mv = *(f32x4*)(m + idx), vv = *(f32x4*)(v + idx), pv = *(f32x4*)(p + idx);
 #pragma unroll
@@ -206,7 +207,7 @@ struct AdamTable {
     int k[SL_ADAM_MAX_LAYERS], cin[SL_ADAM_MAX_LAYERS], cout[SL_ADAM_MAX_LAYERS];
 };
 
-template <typename T>
+template <typename T, bool ADAM = true>
 __global__ __launch_bounds__(256) void adam_pack_multi_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ m, float* __restrict__ v, AdamTable t,
                                                               float lr_t, float b1, float b2, float eps) {
@@ -218,11 +219,34 @@ __global__ __launch_bounds__(256) void adam_pack_multi_kernel(float* __restrict_
     const int nx = cout / 64, ny = cin / 32;
     const int bx = local % nx, by = (local / nx) % ny, bz = local / (nx * ny);
     const long off = t.offset[layer];
-    adam_pack_block<T>(tile, p + off, g + off, m + off, v + off, (T*)t.wf[layer], (T*)t.wd[layer], k, cin, cout, lr_t, b1,
-                       b2, eps, bx, by, bz);
+    if (!ADAM && bz == k) return;  // (the bias block has no operand copy)
+    adam_pack_block<T, ADAM>(tile, p + off, ADAM ? g + off : nullptr, ADAM ? m + off : nullptr, ADAM ? v + off : nullptr,
+                             (T*)t.wf[layer], (T*)t.wd[layer], k, cin, cout, lr_t, b1, b2, eps, bx, by, bz);
 }
 
 }  // namespace
+
+static int adam_table_from(const sl_adam_layer* layers, int n_layers, const char* who, AdamTable* t, int* blocks_out) {
+    t->n = n_layers;
+    int blocks = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const sl_adam_layer& L = layers[i];
+        SL_CHECK_ARG(L.w_fwd && L.k > 0 && L.cin_pad > 0 && L.cout_pad > 0 && L.cin_pad % 32 == 0 && L.cout_pad % 64 == 0 &&
+                         L.offset >= 0 && L.offset % 4 == 0,
+                     "%s: layer %d: need w_fwd, cin_pad %% 32 == 0, cout_pad %% 64 == 0, offset %% 4 == 0", who, i);
+        t->block_begin[i] = blocks;
+        t->offset[i] = L.offset;
+        t->wf[i] = L.w_fwd;
+        t->wd[i] = L.w_dgrad;
+        t->k[i] = L.k;
+        t->cin[i] = L.cin_pad;
+        t->cout[i] = L.cout_pad;
+        blocks += (L.cout_pad / 64) * (L.cin_pad / 32) * (L.k + 1);
+    }
+    t->block_begin[n_layers] = blocks;
+    *blocks_out = blocks;
+    return SL_OK;
+}
 
 extern "C" int sl_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers,
                                    int n_layers, int dtype, int step, float lr, float beta1, float beta2, float eps,
@@ -232,23 +256,9 @@ extern "C" int sl_adam_pack_layers(float* param, const float* grad, float* m, fl
                  SL_ADAM_MAX_LAYERS);
     SL_CHECK_ARG(step >= 1 && (dtype == SL_BF16 || dtype == SL_F32), "sl_adam_pack_layers: bad step or dtype");
     AdamTable t;
-    t.n = n_layers;
     int blocks = 0;
-    for (int i = 0; i < n_layers; ++i) {
-        const sl_adam_layer& L = layers[i];
-        SL_CHECK_ARG(L.w_fwd && L.k > 0 && L.cin_pad > 0 && L.cout_pad > 0 && L.cin_pad % 32 == 0 && L.cout_pad % 64 == 0 &&
-                         L.offset >= 0 && L.offset % 4 == 0,
-                     "sl_adam_pack_layers: layer %d: need w_fwd, cin_pad %% 32 == 0, cout_pad %% 64 == 0, offset %% 4 == 0", i);
-        t.block_begin[i] = blocks;
-        t.offset[i] = L.offset;
-        t.wf[i] = L.w_fwd;
-        t.wd[i] = L.w_dgrad;
-        t.k[i] = L.k;
-        t.cin[i] = L.cin_pad;
-        t.cout[i] = L.cout_pad;
-        blocks += (L.cout_pad / 64) * (L.cin_pad / 32) * (L.k + 1);
-    }
-    t.block_begin[n_layers] = blocks;
+    const int rc = adam_table_from(layers, n_layers, "sl_adam_pack_layers", &t, &blocks);
+    if (rc != SL_OK) return rc;
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
     if (dtype == SL_BF16)
         hipLaunchKernelGGL((adam_pack_multi_kernel<unsigned short>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, param,
@@ -257,6 +267,25 @@ extern "C" int sl_adam_pack_layers(float* param, const float* grad, float* m, fl
         hipLaunchKernelGGL((adam_pack_multi_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m,
                            v, t, (float)lr_t, beta1, beta2, eps);
     return sl_check_launch("sl_adam_pack_layers");
+}
+
+extern "C" int sl_pack_layers(const float* param, const sl_adam_layer* layers, int n_layers, int dtype, void* stream) {
+    SL_CHECK_ARG(param && layers, "sl_pack_layers: null pointer");
+    SL_CHECK_ARG(n_layers >= 1 && n_layers <= SL_ADAM_MAX_LAYERS, "sl_pack_layers: 1..%d layers per call",
+                 SL_ADAM_MAX_LAYERS);
+    SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32, "sl_pack_layers: bad dtype");
+    AdamTable t;
+    int blocks = 0;
+    const int rc = adam_table_from(layers, n_layers, "sl_pack_layers", &t, &blocks);
+    if (rc != SL_OK) return rc;
+    float* p = const_cast<float*>(param);  // (read only in the pack-only instantiation)
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL((adam_pack_multi_kernel<unsigned short, false>), dim3(blocks), dim3(256), 0,
+                           (hipStream_t)stream, p, nullptr, nullptr, nullptr, t, 0.f, 0.f, 0.f, 0.f);
+    else
+        hipLaunchKernelGGL((adam_pack_multi_kernel<float, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p,
+                           nullptr, nullptr, nullptr, t, 0.f, 0.f, 0.f, 0.f);
+    return sl_check_launch("sl_pack_layers");
 }
 
 namespace {

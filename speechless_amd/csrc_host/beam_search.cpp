@@ -20,6 +20,8 @@
 //   * the language model is read from an ARPA file (KenLM's binary format needs KenLM itself) and queried with
 //     standard back-off -- what KenLM's FullScore().prob returns.
 // Plain C++ (graph search on the host, not roofline work); utterances of a batch are decoded on separate threads.
+#include "../../include/speechless_host.h"  // the C-ABI this file implements (checked by the compiler)
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

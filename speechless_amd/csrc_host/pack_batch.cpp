@@ -5,6 +5,8 @@
 // into one (B, Tmax, F) staging buffer.  Plain C++ with a few std::threads; called through ctypes, which releases the
 // GIL for the duration of the call -- the Python version of this loop fought the training thread for the GIL and capped
 // the end-to-end rate at ~11 k utt/s with a 13 k utt/s GPU step.
+#include "../../include/speechless_host.h"  // the C-ABI this file implements (checked by the compiler)
+
 #include <algorithm>
 #include <cstdint>
 #include <cstring>

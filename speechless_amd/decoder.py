@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .pipeline import host_lib
+from ._host_lib import host_lib
 
 # net.py:447-450
 KENLM_WEIGHT = .8
@@ -21,23 +21,7 @@ DEFAULT_BEAM_WIDTH = 100  # tf.nn.ctc_beam_search_decoder's default
 
 
 def _lib():
-    lib = host_lib()
-    if not getattr(lib, "_beam_bound", False):
-        lib.sl_host_lm_load_arpa.restype = ctypes.c_void_p
-        lib.sl_host_lm_load_arpa.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
-        lib.sl_host_lm_free.argtypes = [ctypes.c_void_p]
-        lib.sl_host_lm_order.argtypes = [ctypes.c_void_p]
-        lib.sl_host_lm_score_sentence.restype = ctypes.c_double
-        lib.sl_host_lm_score_sentence.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
-        lib.sl_host_scorer_create.restype = ctypes.c_void_p
-        lib.sl_host_scorer_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
-                                              ctypes.c_float, ctypes.c_float]
-        lib.sl_host_scorer_free.argtypes = [ctypes.c_void_p]
-        lib.sl_host_ctc_beam_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
-                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-        lib._beam_bound = True
-    return lib
+    return host_lib()
 
 
 class NGramLanguageModel:

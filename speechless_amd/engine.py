@@ -161,7 +161,9 @@ class _Buffers:
         self.nt_ws = None
         self.wgrad_ws = None
         self.launch_lists = {}   # recorded launch lists (Engine._replay); dropped whenever a pointer they hold changes
-        self._ws_sized = set()   # output lengths whose workspace needs have been checked
+        self.chain_tables = {}   # sl_conv1d_chain pointer tables of this buffer set (Engine._chain_table)
+        self._ws_sized_fwd = set()   # output lengths whose forward / backward workspace needs have been checked
+        self._ws_sized_bwd = set()   # (a length first seen by predict() and trained on later still gets its dgrad sizing)
         self._clean_in = 0       # input frames / output rows up to which stale data may sit in the buffers
         self._clean_out = 0
 
@@ -191,11 +193,11 @@ class _Buffers:
             for g in geoms:
                 if g is not None:
                     g.t_out = t_out
-        if t_out not in self._ws_sized:  # split counts (hence workspace sizes) depend on the number of time tiles
-            self._ws_sized.add(t_out)
+        if t_out not in self._ws_sized_fwd:  # split counts (hence workspace sizes) depend on the number of time tiles
+            self._ws_sized_fwd.add(t_out)
             self.size_nt_workspace(eng, self.fwd_geom, "fwd")
-            if self.bwd_ready:
-                self.size_backward_workspaces(eng)
+        if self.bwd_ready and t_out not in self._ws_sized_bwd:
+            self.size_backward_workspaces(eng)
 
     def size_nt_workspace(self, eng, geoms, kind):
         need = 16
@@ -248,7 +250,6 @@ class _Buffers:
                 self.dgrad_geom[p.index] = dg
         self.bias_ws = None
         self.ctc_ws = None
-        self.ctc_ws_lmax = -1
         self.labels = None
         self.label_len = torch.zeros((self.batch,), dtype=torch.int32, device=dev)
         self.bwd_ready = True
@@ -256,6 +257,7 @@ class _Buffers:
 
     def size_backward_workspaces(self, eng):
         L = lib()
+        self._ws_sized_bwd.add(self.t_out)
         first = eng.frozen_layer_count
         ws_bytes = 0
         bias_ws = 0
@@ -279,12 +281,14 @@ class _Buffers:
             self.launch_lists = {}
 
     def ensure_ctc(self, eng, l_max):
-        if self.ctc_ws is not None and l_max <= self.ctc_ws_lmax:
-            return
+        """CTC workspace for label rows of up to l_max graphemes: sized in BYTES and never shrunk (the library's need
+        is monotonic in l_max since round 3, but a buffer set that has served long labels keeps its allocation)."""
         need = lib().raw("sl_ctc_workspace_bytes")(self.batch, self.tt_pad, l_max)  # covers every length
-        self.ctc_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=eng.device)
-        self.ctc_ws_lmax = l_max
-        self.labels = torch.zeros((self.batch, l_max), dtype=torch.int32, device=eng.device)
+        if self.ctc_ws is None or self.ctc_ws.numel() < need:
+            self.ctc_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=eng.device)
+            self.launch_lists = {}
+        if self.labels is None or self.labels.shape[1] < l_max:
+            self.labels = torch.zeros((self.batch, l_max), dtype=torch.int32, device=eng.device)
 
 
 class Engine:
@@ -368,8 +372,6 @@ class Engine:
         self.timeline = None
         self.kernel_timeline = None  # (set of tags, list of (tag, start, stop)): see _launch
         self._side_stream = None
-        self.overlap_wgrad = False
-        self.defer_bias_grads = os.environ.get("SL_DEFER_BGRAD", "1") != "0"  # A/B knob, see backward()
         # "ones channel": the last padded output channel of every hidden layer carries the constant 1 (bias 1, zero weights),
         # so the next layer's weight-gradient GEMM -- which multiplies the padding through anyway -- leaves that layer's
         # BIAS gradient in row cin_pad - 1 of dW (sl_bias_grad_from_wgrad, include/speechless_hip.h): ten of the eleven
@@ -377,14 +379,7 @@ class Engine:
         # bandwidth and power from the GEMMs beside them) become one small launch.  SL_ONES_CHANNEL=0: the old passes.
         self.ones_channel = os.environ.get("SL_ONES_CHANNEL", "1") == "1"
         self._bgw_tables = {}
-        # forward + CTC + backward of a resident step replayed from a hipGraph (one graph per batch geometry): the ~60
-        # launches and 4 cross-stream hand-overs of the step cost the host ~0.7 ms of Python / ctypes per step otherwise
-        self.use_graph = os.environ.get("SL_USE_GRAPH", "0") == "1"
         self.fuse_output_softmax = os.environ.get("SL_FUSE_OUTPUT", "1") != "0"  # A/B knob: sl_output_softmax
-        # train_step_resident: Adam of a layer runs under the rest of backward (see backward()).  Measured on MI355X
-        # (tools/step_ab.py): 2.546 ms/step either way -- the HBM-bound update slows the MFMA kernels it overlaps by as
-        # much as it costs alone -- so it is off by default, which also keeps per-kernel timings clean.
-        self.early_adam = False
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
         # Launch lists: the ~60 C-ABI calls and 4 stream hand-overs of a step are recorded the first time a buffer set
         # runs them and replayed afterwards with their arguments already marshalled -- the Python around each launch
@@ -395,7 +390,6 @@ class Engine:
         # forward 124 us against 7 x 23.6 = 165 us of single launches, input gradients 126 against 185 (config 3;
         # DESIGN.md section 3.1).  SL_CHAIN=0 restores the single launches (A/B measurements).
         self.use_chain = os.environ.get("SL_CHAIN", "1") == "1"
-        self._chain_tables = {}
         self.use_launch_lists = os.environ.get("SL_LAUNCH_LISTS", "1") != "0"
         self._rec = None
         self._adam_tables = {}
@@ -480,15 +474,41 @@ class Engine:
         b = tensor[plan.b_off: plan.b_off + plan.cout_pad]
         return w, b
 
-    def bucket_ranges(self):
-        """Flat-gradient ranges in the order they become ready during backward: the three output layers first
-        (81 % of the bytes), then the rest."""
+    def bucket_plan(self):
+        """Gradient buckets of the data-parallel exchange in the order backward() completes them: a list of
+        (layer indices, (lo, hi)) with [lo, hi) the bucket's contiguous range of the flat gradient buffer.
+        {output_conv, big_conv_2} (17 % of the bytes, complete after the second weight gradient of the step), {big_conv_1}
+        (64 %, its exchange runs under big_conv_1's input gradient and the whole inner run), the run of identical inner layers
+        (one grouped weight-gradient launch at the very end of backward), then what is left (striding_conv, whose weight
+        gradient is the last kernel of backward: the only exchange nothing covers).  Frozen layers are in no bucket."""
         n = len(self.plans)
-        split = max(n - 3, self.frozen_layer_count)
-        ranges = [(self.plans[split].w_off, self.param_numel)]
-        if split > self.frozen_layer_count:
-            ranges.append((self.plans[self.frozen_layer_count].w_off, self.plans[split].w_off))
-        return ranges, split
+        first = self.frozen_layer_count
+        groups = []
+        if n >= 3:
+            groups.append(list(range(max(n - 2, first), n)))
+            groups.append(list(range(max(n - 3, first), n - 2)))
+        else:
+            groups.append(list(range(first, n)))
+        rest_hi = max(n - 3, first) if n >= 3 else first
+        for (s0, e0) in reversed(self.runs):  # runs inside the remaining layers become buckets of their own
+            lo = max(s0, first)
+            if e0 < rest_hi and e0 >= lo:
+                if e0 + 1 < rest_hi:
+                    groups.append(list(range(e0 + 1, rest_hi)))
+                groups.append(list(range(lo, e0 + 1)))
+                rest_hi = lo
+        if rest_hi > first:
+            groups.append(list(range(first, rest_hi)))
+        plan = []
+        for layers in groups:
+            if layers:
+                hi_layer = self.plans[layers[-1]]
+                plan.append((layers, (self.plans[layers[0]].w_off, hi_layer.b_off + hi_layer.cout_pad)))
+        return plan
+
+    def bucket_ranges(self):
+        """Flat-gradient ranges of bucket_plan(), in completion order (what GradBucketReducer takes)."""
+        return [r for _, r in self.bucket_plan()]
 
     # ------------------------------------------------------------------ weights
     def set_weights(self, weights):
@@ -595,13 +615,13 @@ class Engine:
         return buf
 
     def _chain_table(self, kind, layers, buf):
-        """ctypes pointer tables of sl_conv1d_chain for the given layers (plan indices in launch order), cached per
-        (buffer set, kind).  kind 'fwd': ys = activations, ws = forward operands, biases; kind 'dgrad': layer i of the list
+        """ctypes pointer tables of sl_conv1d_chain for the given layers (plan indices in launch order), cached on the
+        buffer set (freed with it).  kind 'fwd': ys = activations, ws = forward operands, biases; kind 'dgrad': layer i of the list
         is the input gradient of plan i: ys = g[i - 1], ws = dgrad operands, masks = y[i - 1]."""
-        key = (kind, tuple(layers), id(buf))
-        hit = self._chain_tables.get(key)
-        if hit is not None and hit[0] is buf:
-            return hit[1]
+        key = (kind, tuple(layers))
+        hit = buf.chain_tables.get(key)
+        if hit is not None:
+            return hit
         n = len(layers)
         arr = ctypes.c_void_p * n
         if kind == "fwd":
@@ -612,9 +632,7 @@ class Engine:
             ys = arr(*[buf.g[i - 1].data_ptr() for i in layers])
             ws = arr(*[self.w_dgrad[i].data_ptr() for i in layers])
             aux = arr(*[buf.y[i - 1].data_ptr() for i in layers])
-        if len(self._chain_tables) > 64:
-            self._chain_tables.clear()
-        self._chain_tables[key] = (buf, (ys, ws, aux))
+        buf.chain_tables[key] = (ys, ws, aux)
         return ys, ws, aux
 
     def _chain_ok(self, buf, layers):
@@ -791,31 +809,26 @@ class Engine:
                       buf.ctc_ws.data_ptr(), buf.ctc_ws.numel(), self._stream())
         return buf.loss
 
-    def backward(self, on_bucket_ready=None, early_adam=False, reducer=None):
+    def backward(self, on_bucket_ready=None):
         """wgrad / bias-grad / dgrad for every trainable layer, output layer first.
 
-        early_adam: the fused Adam + operand repack of a layer (HBM-bound, 0.2 ms per step in total, 0.13 ms of it in
-        the three output layers whose gradients are complete FIRST) is enqueued as soon as that layer's wgrad, bias
-        grad and dgrad are: on the side stream (single GPU), or on the reducer's communication stream behind the
-        all-reduce of the layer's gradient bucket (data parallel).  It then runs underneath the MFMA-bound kernels of
-        the layers below instead of after them.  Results are identical to backward() followed by adam_step().
-
-        The HBM-bound bias gradients (they only stream g[i] once) run on a SIDE stream underneath the MFMA-bound
-        wgrad/dgrad kernels instead of in front of them.  With self.overlap_wgrad the weight gradients move to the side
-        stream as well, under the critical dgrad chain of the MAIN stream (they only need g[i] and the saved
-        activation; the short layers put at most one work-group on a CU, so kernels of different layers co-reside).
-        That is worth +1.3 % at B=32 but makes per-kernel event/rocprof durations overlap, so it is off by default.
-        on_bucket_ready(i) is called once the launches that complete gradient bucket i (bucket_ranges) are enqueued."""
+        Bias gradients: layers whose input carries the ones channel get theirs out of the weight-gradient GEMM
+        (_bias_grads_from_wgrad); the others (striding_conv; every layer when dropout touched the ones) by an HBM-bound
+        sl_bias_grad pass over g[i] on a SIDE stream underneath the MFMA-bound wgrad / dgrad kernels.  Every hand-over to
+        the side stream is an event record on the main stream and drains it for ~6 us (profiles/r01j: the only gaps of the
+        step's timeline), and g[i] stays intact until the next step, so passes are collected until >= 128 MB of gradient
+        are owed (or a bucket / the end of backward needs them).
+        on_bucket_ready(b) is called once every launch that writes gradient bucket b (bucket_plan) is enqueued on the main
+        stream -- the data-parallel reducer starts that bucket's exchange there."""
         buf = self.cur
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)  # (ROCm offers no priority below the default)
         side = self._side_stream
-        # launch list: the default schedule only (no dropout masks to rescale, no early Adam, no second wgrad stream)
-        plain = not (early_adam or self.overlap_wgrad or buf.dropped or os.environ.get("SL_DEFER_BGRAD") == "skip")
-        key = ("bwd", main.cuda_stream, on_bucket_ready is not None, self.defer_bias_grads, self.ones_channel,
-               self.frozen_layer_count,
-               self.group_wgrad, self.use_chain, tuple(sorted(self.nt_cfg.items()))) if plain else None
+        # launch list: not with dropout (its scale passes take the rate by value)
+        key = None if buf.dropped else ("bwd", main.cuda_stream, on_bucket_ready is not None, self.ones_channel,
+                                        self.frozen_layer_count, self.group_wgrad, self.use_chain,
+                                        tuple(sorted(self.nt_cfg.items())))
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
             self._replay(ops, on_bucket_ready)
@@ -823,131 +836,138 @@ class Engine:
         record = key is not None and self.use_launch_lists and self.timeline is None and \
             self.kernel_timeline is None and self._rec is None
         if not record:
-            self._backward_eager(buf, main, side, on_bucket_ready, early_adam, reducer)
+            self._backward_eager(buf, main, side, on_bucket_ready)
             return
         self._rec = []
         try:
-            self._backward_eager(buf, main, side, on_bucket_ready, early_adam, reducer)
+            self._backward_eager(buf, main, side, on_bucket_ready)
             buf.launch_lists[key] = self._rec
         finally:
             self._rec = None
 
-    def _backward_eager(self, buf, main, side, on_bucket_ready, early_adam, reducer):
-        first = self.frozen_layer_count
-        _, split = self.bucket_ranges()
-        grouped = {}  # layer index -> (lo, hi) of the run whose weight gradients are computed in one grouped launch
-        if self.group_wgrad and self.dtype == "bf16" and not self.overlap_wgrad:
+    def _grouped_wgrad_runs(self, first):
+        """layer index -> (lo, hi) of the run whose weight gradients are one grouped launch (bf16 path)"""
+        grouped = {}
+        if self.group_wgrad and self.dtype == "bf16":
             for (s0, e0) in self.runs:
                 lo = max(s0, first)
-                if e0 > lo and not (lo <= split <= e0):  # keep the bucket boundary simple
+                if e0 > lo:
                     for q in range(lo, e0 + 1):
                         grouped[q] = (lo, e0)
+        return grouped
 
-        def join_side():
-            self._hand_over(side, main)
+    def _dgrad_chains(self, buf, first):
+        """input gradients of a run of identical ReLU layers in one launch (sl_conv1d_chain): {top layer: layers, top
+        first}, and the set of layers such a launch covers besides its top layer"""
+        dchain, skip = {}, set()
+        if buf.dropped or not self.use_chain or self.dtype != "bf16":
+            return dchain, skip
+        for (s0, e0) in self.runs:
+            layers = list(range(e0, max(s0, first + 1) - 1, -1))
+            if len(layers) >= 2 and all(self.specs[i - 1].activation == "relu" for i in layers) and \
+                    not any(("dgrad", self.specs[i].name) in self.nt_cfg for i in layers) and \
+                    bool(self.lib.raw("sl_conv1d_chain_supported")(ctypes.byref(buf.dgrad_geom[e0]), len(layers),
+                                                                   self.dtype_code)):
+                dchain[e0] = layers
+                skip.update(layers[1:])
+        return dchain, skip
 
-        def bucket_ready(index):
-            on_bucket_ready(index)
-            if self._rec is not None:
-                self._rec.append((2, index))
+    def _launch_wgrad(self, buf, i, grouped, st):
+        """weight gradient of layer i -- or, at the lowest layer of a grouped run, of the whole run"""
+        p = self.plans[i]
+        if i in grouped:
+            lo, hi = grouped[i]
+            if i != lo:
+                return  # every g[lo..hi] is complete only at the lowest layer: one launch for the run there
+            plo = self.plans[lo]
+            dw_lo, _ = self.layer_param_views(self.grads, plo)
+            stride_elems = buf.batch * buf.rows * plo.cin_pad
+            self._launch("wgrad:{}..{}".format(plo.spec.name, self.plans[hi].spec.name), "sl_conv1d_wgrad_grouped",
+                         buf.y[lo - 1].data_ptr(), buf.g[lo].data_ptr(), dw_lo.data_ptr(),
+                         ctypes.byref(buf.wgrad_geom[lo]), hi - lo + 1, stride_elems, stride_elems,
+                         plo.w_numel + plo.cout_pad, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+            return
+        x = (buf.x0_dropped if buf.dropped else buf.x0) if i == 0 else buf.y[i - 1]
+        dw, _ = self.layer_param_views(self.grads, p)
+        self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), dw.data_ptr(),
+                     ctypes.byref(buf.wgrad_geom[i]), self.dtype_code, self.nt_cfg.get(("wgrad", p.spec.name), 0),
+                     buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
 
-        if early_adam:
-            if self._packed_dirty:
-                self.repack_weights()
-            self.adam_iterations += 1
-        dp = reducer is not None and (reducer.world_size > 1 or reducer.force)
-        bucket_layers = []  # data parallel: layers of the gradient bucket being completed
+    def _launch_dgrad(self, buf, i, st):
+        """input gradient of layer i into g[i - 1], through the activation of layer i - 1 (and its dropout)"""
+        p = self.plans[i]
+        elu = self.specs[i - 1].activation == "elu"
+        elu_dropped = elu and buf.dropped and i in self._dropout_layers()
+        self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(),
+                     None, None if elu_dropped else buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(),
+                     ctypes.byref(buf.dgrad_geom[i]),
+                     _lib.EPI_NONE if elu_dropped else (_lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK),
+                     self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
+                     buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+        if elu_dropped:
+            # a stored zero is ambiguous behind an ELU (dropped, or elu(z) == 0): both factors of the chain rule
+            # in one elementwise pass that recomputes the keep decisions from the step's seed
+            self._launch("dropout_elu_bwd:" + p.spec.name, "sl_elu_dropout_backward", buf.g[i - 1].data_ptr(),
+                         buf.y[i - 1].data_ptr(), buf.g[i - 1].numel(), self.dtype_code, self.dropout_rate,
+                         buf.dropout_seed0 + i, st)
+        elif buf.dropped and i in self._dropout_layers():
+            # the dgrad epilogue's mask (stored activation > 0) already applied the keep mask: the stored
+            # activation is post-dropout; what is left of d dropout / dx is the 1 / (1 - rate) factor
+            self._launch("dropout_scale:" + p.spec.name, "sl_scale", buf.g[i - 1].data_ptr(), buf.g[i - 1].numel(),
+                         self.dtype_code, 1.0 / (1.0 - self.dropout_rate), st)
 
-        def adam_after_this_layer(layers):
-            """layers: their wgrad / dgrad launches are all enqueued on MAIN (and their bias grads on SIDE)."""
-            issued = torch.cuda.Event()
-            issued.record(main)
-            if not dp:
-                with torch.cuda.stream(side):
-                    side.wait_event(issued)
-                    self._adam_layers(layers, side.cuda_stream)
-            else:
-                bucket_layers.extend(layers)
-
-        # input gradients of a run of identical ReLU layers in one launch (sl_conv1d_chain): keyed by the TOP layer
-        dchain, dchain_skip = {}, set()
-        if not buf.dropped:
-            for (s0, e0) in self.runs:
-                lo_d = max(s0, first + 1)
-                layers = list(range(e0, lo_d - 1, -1))
-                if len(layers) >= 2 and self.use_chain and self.dtype == "bf16" and \
-                        all(self.specs[i - 1].activation == "relu" for i in layers) and \
-                        not any(("dgrad", self.specs[i].name) in self.nt_cfg for i in layers) and \
-                        bool(self.lib.raw("sl_conv1d_chain_supported")(ctypes.byref(buf.dgrad_geom[e0]), len(layers),
-                                                                       self.dtype_code)):
-                    dchain[e0] = layers
-                    dchain_skip.update(layers[1:])
+    def _backward_eager(self, buf, main, side, on_bucket_ready):
+        first = self.frozen_layer_count
+        grouped = self._grouped_wgrad_runs(first)
+        dchain, dchain_skip = self._dgrad_chains(buf, first)
         # bias gradients out of the weight-gradient GEMM (self.ones_channel): which layers, and whether the row holds the
         # bias gradient (the ones were not touched by dropout) or only has to be zeroed before the optimizer sees it
         ones_in = self._ones_input_layers(first)
-        simple = not (early_adam or self.overlap_wgrad)
-        ones_db = set(ones_in) if (simple and not buf.dropped) else set()
-        # (those two need every layer's bias gradient at once; defer_bias_grads = False restores one hand-over per layer)
-        defer = self.defer_bias_grads and not (early_adam or self.overlap_wgrad)
-        pending, pending_bytes = [], 0  # layers whose bias-gradient launch is still owed to the side stream
+        ones_db = set() if buf.dropped else set(ones_in)
+        # data parallel: bucket b is complete once the weight gradient of its LOWEST layer is enqueued
+        bucket_at = {}
+        if on_bucket_ready is not None:
+            for b, (layers, _) in enumerate(self.bucket_plan()):
+                bucket_at[layers[0]] = (b, layers)
+        side_busy = [False]
+
+        def flush_bias_passes(pending):
+            """sl_bias_grad passes of the layers in `pending` (their g is complete at this point of MAIN) on SIDE"""
+            self._hand_over(main, side)
+            with torch.cuda.stream(side):
+                for j in pending:
+                    _, db_j = self.layer_param_views(self.grads, self.plans[j])
+                    self._launch("bgrad:" + self.plans[j].spec.name, "sl_bias_grad", buf.g[j].data_ptr(),
+                                 db_j.data_ptr(), ctypes.byref(buf.wgrad_geom[j]), self.dtype_code,
+                                 buf.bias_ws.data_ptr(), buf.bias_ws.numel(), side.cuda_stream)
+            side_busy[0] = True
+            del pending[:]
+
+        def join_side():
+            if side_busy[0]:
+                self._hand_over(side, main)
+                side_busy[0] = False
+
+        pending, pending_bytes = [], 0  # layers whose bias-gradient pass is still owed to the side stream
         for p in reversed(self.plans[first:]):
             i = p.index
-            x = (buf.x0_dropped if buf.dropped else buf.x0) if i == 0 else buf.y[i - 1]
-            dw, db = self.layer_param_views(self.grads, p)
-            # bias gradient of layer i: deferred until enough work has piled up for one hand-over to the side stream.
-            # Every hand-over is an event record on MAIN, and the record costs MAIN ~6 us of pipeline drain
-            # (profiles/r01j: 11 records = the only gaps in the step's timeline); g[i] stays intact until the next step,
-            # so the small layers' bias gradients can wait for a common hand-over.
-            if os.environ.get("SL_DEFER_BGRAD") != "skip" and i not in ones_db:  # ("skip": timing experiment only)
+            if i not in ones_db:
                 pending.append(i)
                 pending_bytes += buf.g[i].numel() * buf.g[i].element_size()
-            if pending and (not defer or pending_bytes >= (128 << 20) or i <= first + 1 or
-                            (on_bucket_ready is not None and i == split)):
-                # g[j], j in pending (CTC gradient or a previous dgrad) are complete at this point of MAIN
-                self._hand_over(main, side)
-                wgrad_stream = side if self.overlap_wgrad else main
-                with torch.cuda.stream(side):
-                    if self.overlap_wgrad:
-                        self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
-                                     dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
-                                     self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
-                                     buf.wgrad_ws.numel(), wgrad_stream.cuda_stream)
-                        if i in ones_in:
-                            self._bias_grads_from_wgrad([i], False, wgrad_stream)
-                    for j in pending:
-                        _, db_j = self.layer_param_views(self.grads, self.plans[j])
-                        self._launch("bgrad:" + self.plans[j].spec.name, "sl_bias_grad", buf.g[j].data_ptr(),
-                                     db_j.data_ptr(), ctypes.byref(buf.wgrad_geom[j]), self.dtype_code,
-                                     buf.bias_ws.data_ptr(), buf.bias_ws.numel(), side.cuda_stream)
-                    if self.overlap_wgrad and on_bucket_ready is not None and i == split:
-                        bucket_ready(0)
-                del pending[:]
+            closes_bucket = i in bucket_at
+            if pending and (pending_bytes >= (128 << 20) or i == first or closes_bucket):
+                flush_bias_passes(pending)
                 pending_bytes = 0
-            if i in grouped:
-                lo, hi = grouped[i]
-                if i == lo:  # every g[lo..hi] is complete now: one launch for the whole run
-                    plo = self.plans[lo]
-                    dw_lo, _ = self.layer_param_views(self.grads, plo)
-                    stride_elems = buf.batch * buf.rows * plo.cin_pad
-                    self._launch("wgrad:{}..{}".format(plo.spec.name, self.plans[hi].spec.name),
-                                 "sl_conv1d_wgrad_grouped", buf.y[lo - 1].data_ptr(), buf.g[lo].data_ptr(),
-                                 dw_lo.data_ptr(), ctypes.byref(buf.wgrad_geom[lo]), hi - lo + 1, stride_elems,
-                                 stride_elems, plo.w_numel + plo.cout_pad, 0, buf.wgrad_ws.data_ptr(),
-                                 buf.wgrad_ws.numel(), main.cuda_stream)
-                    if not simple:
-                        self._bias_grads_from_wgrad([j for j in range(lo, hi + 1) if j in ones_in], False, main)
-            elif not self.overlap_wgrad:
-                self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(),
-                             dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), self.dtype_code,
-                             self.nt_cfg.get(("wgrad", p.spec.name), 0), buf.wgrad_ws.data_ptr(),
-                             buf.wgrad_ws.numel(), main.cuda_stream)
-                if not simple and i in ones_in:
-                    self._bias_grads_from_wgrad([i], False, main)
-                if on_bucket_ready is not None and i == split:
-                    if simple:
-                        self._bias_grads_from_wgrad([j for j in ones_in if j >= split], bool(ones_db), main)
-                    join_side()
-                    bucket_ready(0)
+            self._launch_wgrad(buf, i, grouped, main.cuda_stream)
+            if closes_bucket:
+                b, layers = bucket_at[i]
+                rows = [j for j in layers if j in ones_in]
+                if rows:
+                    self._bias_grads_from_wgrad(rows, bool(ones_db), main)
+                join_side()
+                on_bucket_ready(b)
+                if self._rec is not None:
+                    self._rec.append((2, b))
             if i in dchain:
                 layers = dchain[i]
                 ys, ws, masks = self._chain_table("dgrad", layers, buf)
@@ -955,54 +975,12 @@ class Engine:
                              "sl_conv1d_chain", buf.g[i].data_ptr(), ys, ws, None, masks,
                              ctypes.byref(buf.dgrad_geom[i]), len(layers), _lib.EPI_RELU_MASK, self.dtype_code,
                              main.cuda_stream)
-            elif i in dchain_skip:
-                pass
-            elif i > first:
-                elu = self.specs[i - 1].activation == "elu"
-                elu_dropped = elu and buf.dropped and i in self._dropout_layers()
-                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(),
-                             None, None if elu_dropped else buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(),
-                             ctypes.byref(buf.dgrad_geom[i]),
-                             _lib.EPI_NONE if elu_dropped else (_lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK),
-                             self.dtype_code, 0, self.nt_cfg.get(("dgrad", p.spec.name), 0),
-                             buf.nt_ws.data_ptr(), buf.nt_ws.numel(), main.cuda_stream)
-                if elu_dropped:
-                    # a stored zero is ambiguous behind an ELU (dropped, or elu(z) == 0): both factors of the chain rule
-                    # in one elementwise pass that recomputes the keep decisions from the step's seed
-                    self._launch("dropout_elu_bwd:" + p.spec.name, "sl_elu_dropout_backward", buf.g[i - 1].data_ptr(),
-                                 buf.y[i - 1].data_ptr(), buf.g[i - 1].numel(), self.dtype_code, self.dropout_rate,
-                                 buf.dropout_seed0 + i, main.cuda_stream)
-                elif buf.dropped and i in self._dropout_layers():
-                    # the dgrad epilogue's mask (stored activation > 0) already applied the keep mask: the stored
-                    # activation is post-dropout; what is left of d dropout / dx is the 1 / (1 - rate) factor
-                    self._launch("dropout_scale:" + p.spec.name, "sl_scale", buf.g[i - 1].data_ptr(), buf.g[i - 1].numel(),
-                                 self.dtype_code, 1.0 / (1.0 - self.dropout_rate), main.cuda_stream)
-            if early_adam:
-                if i in grouped:
-                    if i == grouped[i][0]:
-                        adam_after_this_layer(list(range(grouped[i][0], grouped[i][1] + 1)))
-                else:
-                    adam_after_this_layer([i])
-                if dp and i == split:  # bucket 0 is being reduced on the communication stream: Adam goes behind it
-                    reducer.run_after_reduce(lambda st, ls=list(bucket_layers): self._adam_layers(ls, st))
-                    del bucket_layers[:]
-        if self.overlap_wgrad:
-            if on_bucket_ready is not None and split > first:
-                with torch.cuda.stream(side):
-                    bucket_ready(1)
+            elif i > first and i not in dchain_skip:
+                self._launch_dgrad(buf, i, main.cuda_stream)
+        if on_bucket_ready is None:
+            if ones_in:
+                self._bias_grads_from_wgrad(ones_in, bool(ones_db), main)
             join_side()
-        else:
-            if simple:
-                rest = [j for j in ones_in if on_bucket_ready is None or j < split]
-                if rest:
-                    self._bias_grads_from_wgrad(rest, bool(ones_db), main)
-            join_side()
-            if on_bucket_ready is not None and split > first:
-                bucket_ready(1)
-        if early_adam and dp:
-            if split > first:
-                reducer.run_after_reduce(lambda st, ls=list(bucket_layers): self._adam_layers(ls, st))
-            del bucket_layers[:]
 
     def adam_step(self, fused=True):
         """Keras-2.0 Adam on the flat fp32 masters.  fused=True: one kernel per trainable layer that applies Adam AND
@@ -1020,23 +998,27 @@ class Engine:
             self.repack_weights()  # frozen layers keep these copies; trainable ones are rewritten below
         self._adam_layers(range(self.frozen_layer_count, len(self.plans)), st)
 
+    def _adam_table(self, chunk):
+        table = self._adam_tables.get(tuple(chunk))
+        if table is None:  # (the operand copies never move: built once per set of layers)
+            table = (_lib.AdamLayer * len(chunk))()
+            for entry, i in zip(table, chunk):
+                p = self.plans[i]
+                wd = self.w_dgrad[p.index]
+                entry.offset = p.w_off
+                entry.w_fwd = self.w_fwd[p.index].data_ptr()
+                entry.w_dgrad = wd.data_ptr() if wd is not None else None
+                entry.k, entry.cin_pad, entry.cout_pad = p.spec.kernel_size, p.cin_pad, p.cout_pad
+            self._adam_tables[tuple(chunk)] = table
+        return table
+
     def _adam_layers(self, layers, st):
         """Fused Adam + bf16 operand repack of the given layers on stream st (self.adam_iterations already counts
         this step): ONE launch for all of them (sl_adam_pack_layers), 16 layers per call at most."""
         layers = list(layers)
         for lo in range(0, len(layers), 16):
             chunk = layers[lo:lo + 16]
-            table = self._adam_tables.get(tuple(chunk))
-            if table is None:  # (the operand copies never move: built once per set of layers)
-                table = (_lib.AdamLayer * len(chunk))()
-                for entry, i in zip(table, chunk):
-                    p = self.plans[i]
-                    wd = self.w_dgrad[p.index]
-                    entry.offset = p.w_off
-                    entry.w_fwd = self.w_fwd[p.index].data_ptr()
-                    entry.w_dgrad = wd.data_ptr() if wd is not None else None
-                    entry.k, entry.cin_pad, entry.cout_pad = p.spec.kernel_size, p.cin_pad, p.cout_pad
-                self._adam_tables[tuple(chunk)] = table
+            table = self._adam_table(chunk)
             self._launch("adam:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name),
                          "sl_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                          self.adam_v.data_ptr(), table, len(chunk), self.dtype_code, self.adam_iterations, self.lr,
@@ -1049,73 +1031,49 @@ class Engine:
         self.set_labels(label_batch, label_lengths, prediction_lengths)
         return self.train_step_resident(reducer)
 
-    def _graph_eligible(self, reducer):
-        return (self.use_graph and reducer is None and self.dtype == "bf16" and not self.dropout_rate and
-                self.timeline is None and self.kernel_timeline is None and not self.early_adam and
-                not self.overlap_wgrad)
-
-    def _graph_step(self):
-        """forward + CTC + backward from a captured hipGraph.  The kernels read the step's inputs through fixed
-        pointers (x0 / labels / lengths of this geometry's buffers), so a replay computes on whatever was loaded into
-        them; Adam stays outside the graph (its step count is a kernel argument)."""
-        buf = self.cur
-        # everything a launch of the step reads through a pointer or takes as an argument and that can differ between
-        # two steps on this geometry: the label / length tensors are used in place (set_labels_resident) and the CTC
-        # workspace grows with the longest label row seen
-        key = (buf.labels.data_ptr(), buf.label_len.data_ptr(), buf.input_len.data_ptr(), int(buf.labels.shape[1]),
-               buf.ctc_ws.data_ptr(), buf.t_in)
-        graphs = buf.__dict__.setdefault("graphs", {})
-        g = graphs.get(key)
-        if g is None:
-            warm = buf.__dict__.setdefault("graph_warm", {})
-            if warm.get(key, 0) < 1 or self._packed_dirty:  # an eager step first: lazy allocations, clean operands
-                warm[key] = warm.get(key, 0) + 1
-                return None
-            if len(graphs) >= 8:  # label tensors that never repeat (no slot recycling): graphs cannot pay off
-                return None
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.forward(training=True)
-                self.ctc(grad_scale=1.0 / buf.batch)
-                self.backward()
-            graphs[key] = g
-        if self._packed_dirty:  # set_weights() since the capture: the operand repack is not part of the graph
-            self.repack_weights()
-        g.replay()
-        return buf.loss
-
     def train_step_resident(self, reducer=None):
         """Same, with input / labels / lengths already resident in HBM (bench.py's timed region)."""
-        if self._graph_eligible(reducer):
-            loss = self._graph_step()
-            if loss is not None:
-                self.adam_step()
-                return loss
         self.forward(training=True)
+        dp = reducer is not None and (reducer.world_size > 1 or reducer.force)
         world = reducer.world_size if reducer is not None else 1
         loss = self.ctc(grad_scale=1.0 / (self.cur.batch * world))
-        early = self.early_adam and not self.overlap_wgrad
-        if reducer is None:
-            self.backward(early_adam=early)
-        else:
-            early = early and reducer.overlap
-            self.backward(on_bucket_ready=reducer.reduce_bucket, early_adam=early, reducer=reducer)
-            if not early and (reducer.world_size > 1 or reducer.force):
-                # bucket 0 (the three output layers, 81 % of the bytes) finished reducing under the rest of backward:
-                # update those layers while the small last bucket is still on the wire, then the rest
-                _, split = self.bucket_ranges()
-                first = self.frozen_layer_count
-                if self._packed_dirty:
-                    self.repack_weights()
-                self.adam_iterations += 1
-                reducer.wait_next()
-                self._adam_layers(range(split, len(self.plans)), self._stream())
-                reducer.wait_all()
-                if split > first:
-                    self._adam_layers(range(first, split), self._stream())
-                return loss
-            reducer.wait_all()
-        if not early:
+        if not dp:
+            self.backward()
             self.adam_step()
+            return loss
+        self.backward(on_bucket_ready=reducer.reduce_bucket)
+        # every bucket's exchange was started the moment its last weight gradient was enqueued; the big ones finished
+        # under the rest of backward.  Update bucket by bucket, in the order the exchanges complete.
+        if self._packed_dirty:
+            self.repack_weights()
+        self.adam_iterations += 1
+        st = self._stream()
+        plan = self.bucket_plan()
+        if not reducer.shard_optimizer:
+            for layers, _ in plan:
+                reducer.wait_next()
+                self._adam_layers(layers, st)
+            return loss
+        # sharded optimizer: each bucket was reduce-SCATTERED; this rank holds the summed gradient of its 1/world slice
+        # only, updates that slice (plain elementwise Adam, 1/world of the optimizer's HBM traffic), and the updated
+        # fp32 masters are all-gathered in place; the operand copies are rewritten from the gathered masters
+        for b, (layers, (lo, hi)) in enumerate(plan):
+            reducer.wait_next()
+            slo, shi = reducer.shard_of(lo, hi)
+            self._launch("adam_shard:{}".format(b), "sl_adam_step", self.params[slo:shi].data_ptr(),
+                         self.grads[slo:shi].data_ptr(), self.adam_m[slo:shi].data_ptr(), self.adam_v[slo:shi].data_ptr(),
+                         shi - slo, self.adam_iterations, self.lr, self.beta_1, self.beta_2, self.adam_epsilon, st)
+            reducer.gather_bucket(b, self.params)
+        for layers, _ in plan:
+            reducer.wait_next()
+            self._pack_layers(layers, st)
         return loss
+
+    def _pack_layers(self, layers, st):
+        """both operand copies of the given layers rewritten from the fp32 masters: one launch (sl_pack_layers)"""
+        layers = list(layers)
+        for lo in range(0, len(layers), 16):
+            chunk = layers[lo:lo + 16]
+            self._launch("pack:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name),
+                         "sl_pack_layers", self.params.data_ptr(), self._adam_table(chunk), len(chunk), self.dtype_code,
+                         st)

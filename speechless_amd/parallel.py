@@ -17,15 +17,23 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, flat_grads, ranges, process_group=None, overlap=True, force=False, compress=None):
+    def __init__(self, flat_grads, ranges, process_group=None, overlap=True, force=False, compress=None,
+                 shard_optimizer=False):
         """force: issue the collectives even in a world of one rank (tests exercise the stream / event choreography and
         the RCCL call on a single GPU that way).
         compress: None (fp32 on the wire: the reduced gradient is the exact sum, identical on every rank) or "bf16"
         (each rank's bucket is rounded to bf16, summed in bf16 by the collective and widened again: half the bytes per
         link, ~3 significant digits per gradient element -- an option for link-bound scaling, off by default; the
-        result is still identical on every rank)."""
+        result is still identical on every rank).
+        shard_optimizer: reduce-SCATTER each bucket instead of all-reducing it -- rank r ends up with the summed gradient
+        of slice r of every bucket only (shard_of), the engine runs Adam on that slice (1/world of the optimizer's HBM
+        traffic per rank) and gather_bucket() all-gathers the updated fp32 masters in place.  Same bytes on the wire as the
+        all-reduce (a ring all-reduce IS this reduce-scatter followed by this all-gather), the optimizer between the two
+        halves.  Needs every bucket length to be a multiple of the world size."""
         if compress not in (None, "bf16"):
             raise ValueError("compress must be None or 'bf16'")
+        if shard_optimizer and compress:
+            raise ValueError("shard_optimizer moves fp32 slices; it does not combine with compress")
         self.compress = compress
         self.force = force
         self.flat = flat_grads
@@ -39,6 +47,18 @@ class GradBucketReducer:
         # measurement only (bench.py's exposed-communication figure): keep the stream / event choreography of a step
         # but leave the collective itself out
         self.skip_collective = False
+        self.shard_optimizer = bool(shard_optimizer)
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        if self.shard_optimizer:
+            for lo, hi in self.ranges:
+                if (hi - lo) % self.world_size:
+                    raise ValueError("shard_optimizer: bucket [{}, {}) is not a multiple of the world size {}".format(
+                        lo, hi, self.world_size))
+
+    def shard_of(self, lo, hi):
+        """The slice of [lo, hi) this rank owns under shard_optimizer."""
+        per = (hi - lo) // self.world_size
+        return lo + self.rank * per, lo + (self.rank + 1) * per
 
     def reduce_bucket(self, index):
         """Called when every kernel writing bucket `index` has been enqueued on the current stream."""
@@ -46,18 +66,42 @@ class GradBucketReducer:
             return
         lo, hi = self.ranges[index]
         view = self.flat[lo:hi]
+        self._exchange(view, self._reduce_scatter if self.shard_optimizer else None)
+
+    def gather_bucket(self, index, flat_params):
+        """shard_optimizer: all-gathers bucket `index` of flat_params (same layout as the gradient buffer) in place, every
+        rank contributing its own slice, behind everything enqueued on the current stream so far.  The completion is
+        queued behind the outstanding buckets (wait_next / wait_all)."""
+        if self.world_size == 1 and not self.force:
+            return
+        lo, hi = self.ranges[index]
+        self._exchange(flat_params[lo:hi], self._all_gather)
+
+    def _reduce_scatter(self, view):
+        per = view.numel() // self.world_size
+        dist.reduce_scatter_tensor(view[self.rank * per:(self.rank + 1) * per], view, op=dist.ReduceOp.SUM,
+                                   group=self.group)
+
+    def _all_gather(self, view):
+        per = view.numel() // self.world_size
+        dist.all_gather_into_tensor(view, view[self.rank * per:(self.rank + 1) * per], group=self.group)
+
+    def _exchange(self, view, collective):
+        """runs collective(view) (default: the sum all-reduce) on the communication stream behind the current stream"""
         if self.overlap:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
                 if not self.skip_collective:
-                    self._all_reduce(view)
+                    (collective or self._all_reduce)(view)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
             self._pending.append(done)
         elif not self.skip_collective:
-            if self.compress:
+            if collective is not None:
+                collective(view)
+            elif self.compress:
                 self._all_reduce(view)
             else:
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -70,21 +114,6 @@ class GradBucketReducer:
             view.copy_(wire)
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-
-    def run_after_reduce(self, fn):
-        """Enqueues fn(raw_stream) on the communication stream, i.e. behind every all-reduce issued so far, after the
-        kernels enqueued on the current stream up to now; wait_all() also waits for it.  (The engine puts the Adam
-        update of a finished bucket here so that it runs underneath the rest of backward.)"""
-        if not self.overlap:
-            raise RuntimeError("run_after_reduce needs the overlapped (device) reducer")
-        issued = torch.cuda.Event()
-        issued.record(torch.cuda.current_stream(self.flat.device))
-        with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(issued)
-            fn(self.comm_stream.cuda_stream)
-            done = torch.cuda.Event()
-            done.record(self.comm_stream)
-        self._pending.append(done)
 
     def wait_next(self):
         """Makes the current stream (or the host, on CPU) wait for the OLDEST outstanding bucket only."""

@@ -24,25 +24,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-_HOST_LIB = None
-
-
-def host_lib():
-    """libspeechless_host.so (speechless_amd/csrc_host/pack_batch.cpp, built by speechless_amd.build): the C++ batch
-    packer.  ctypes releases the GIL while it runs, so packing no longer competes with the training thread."""
-    global _HOST_LIB
-    if _HOST_LIB is None:
-        path = Path(__file__).resolve().parent / "libspeechless_host.so"
-        if not path.exists():
-            raise RuntimeError("{} is missing: run `python -m speechless_amd.build`".format(path))
-        lib = ctypes.CDLL(str(path))
-        lib.sl_host_pack_batch.restype = ctypes.c_int
-        lib.sl_host_pack_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32), ctypes.c_int,
-                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-        if lib.sl_host_version() != 1:
-            raise RuntimeError("libspeechless_host.so version mismatch")
-        _HOST_LIB = lib
-    return _HOST_LIB
+from ._host_lib import host_lib  # noqa: E402  (libspeechless_host.so, include/speechless_host.h)
 
 
 def pack_spectrograms(spectrograms, dst, n_threads=4):

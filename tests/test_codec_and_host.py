@@ -89,6 +89,23 @@ def test_header_symbols_are_exported_and_bound():
     assert rc == -1 and "must be positive" in library.last_error()
 
 
+def test_host_header_symbols_are_exported_and_bound():
+    """libspeechless_host.so exports every symbol include/speechless_host.h declares and the ctypes table binds exactly
+    those (the sources include the header, so the compiler has checked the signatures against the definitions)."""
+    from speechless_amd import _host_lib
+    from speechless_amd.build import build_host
+    build_host()
+    header = (ROOT / "include" / "speechless_host.h").read_text()
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sl_host_[a-z0-9_]+)\s*\(", code))
+    assert declared == set(_host_lib.HOST_SIGNATURES), declared ^ set(_host_lib.HOST_SIGNATURES)
+    lib = _host_lib.host_lib()
+    assert lib.sl_host_version() == 1
+    assert lib.sl_host_pack_batch(None, None, 0, 0, 0, 0, None, 1) == -1  # argument validation, no work
+    for src in ("pack_batch.cpp", "beam_search.cpp"):
+        assert "speechless_host.h" in (ROOT / "speechless_amd" / "csrc_host" / src).read_text()
+
+
 def test_product_code_never_imports_the_oracle():
     for path in (ROOT / "speechless_amd").rglob("*.py"):
         text = path.read_text()

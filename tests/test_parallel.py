@@ -33,7 +33,7 @@ def _flat(grads):
     return np.concatenate([np.concatenate([dw.ravel(), db.ravel()]) for dw, db in grads]).astype(np.float32)
 
 
-def _worker(rank, world, port, out_dir, compress=None):
+def _worker(rank, world, port, out_dir, compress=None, shard=False):
     from oracle import w2l_oracle as o
     from speechless_amd.parallel import GradBucketReducer, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -46,11 +46,24 @@ def _worker(rank, world, port, out_dir, compress=None):
     flat = torch.from_numpy(_flat(r["grads"]) / world)
     n = flat.numel()
     ranges = [(n // 3, n), (0, n // 3)]  # "late layers first" bucket order, like Engine.bucket_ranges()
-    reducer = GradBucketReducer(flat, ranges, compress=compress)
+    if shard:  # bucket lengths must divide by the world size: trim the flat vector to a multiple of 2 * world
+        n = n // (3 * 2 * world) * (3 * 2 * world)
+        flat = flat[:n].clone()
+        ranges = [(n // 3, n), (0, n // 3)]
+    reducer = GradBucketReducer(flat, ranges, compress=compress, shard_optimizer=shard)
     assert reducer.world_size == world
     reducer.reduce_bucket(0)
     reducer.reduce_bucket(1)
     reducer.wait_all()
+    if shard:
+        # each rank now holds the SUM on its own slice of every bucket only; a stand-in "optimizer" (x -> 2x) on that
+        # slice, then the all-gather: every rank must end up with 2 * (all-reduced gradient) everywhere
+        for lo, hi in ranges:
+            slo, shi = reducer.shard_of(lo, hi)
+            flat[slo:shi] *= 2.0
+        reducer.gather_bucket(0, flat)
+        reducer.gather_bucket(1, flat)
+        reducer.wait_all()
     np.save(os.path.join(out_dir, "rank{}.npy".format(rank)), flat.numpy())
     dist.destroy_process_group()
 
@@ -84,6 +97,22 @@ def test_bf16_compressed_allreduce_within_bf16_tolerance(tmp_path):
     assert np.array_equal(got[0], got[1])
     assert np.linalg.norm(got[0] - ref) / np.linalg.norm(ref) < 1e-2
     assert np.linalg.norm(got[0] - ref) > 0  # it did go through bf16
+
+
+def test_sharded_exchange_equals_allreduce(tmp_path):
+    """shard_optimizer: reduce-scatter + (slice-local update) + all-gather of the same buffer reproduces what an
+    all-reduce followed by the update on every rank gives, on both ranks."""
+    from oracle import w2l_oracle as o
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), None, True), nprocs=world, join=True)
+    specs, weights, x, labels, pred_len, lab_len = _toy_problem()
+    ref = _flat(o.loss_and_gradients(specs, weights, x, labels, pred_len, lab_len)["grads"])
+    got = [np.load(str(tmp_path / "rank{}.npy".format(rank))) for rank in range(world)]
+    assert np.array_equal(got[0], got[1])
+    np.testing.assert_allclose(got[0], 2.0 * ref[:got[0].size], rtol=2e-5, atol=1e-7)
+    from speechless_amd.parallel import GradBucketReducer
+    with pytest.raises(ValueError):
+        GradBucketReducer(torch.zeros(8), [(0, 8)], shard_optimizer=True, compress="bf16")
 
 
 def test_shard_range_partitions_everything():
@@ -123,7 +152,7 @@ def _engine_case():
     return specs, weights, x, labels, lab_len, pred_len
 
 
-def _engine_worker(rank, world, port, out_dir):
+def _engine_worker(rank, world, port, out_dir, shard=False):
     from speechless_amd.engine import Engine
     from speechless_amd.parallel import GradBucketReducer, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -132,8 +161,9 @@ def _engine_worker(rank, world, port, out_dir):
     specs, weights, x, labels, lab_len, pred_len = _engine_case()
     eng = Engine(specs, 29, dtype="f32", device="cuda:0", lr=1e-3)
     eng.set_weights(weights)
-    ranges, _ = eng.bucket_ranges()
-    reducer = GradBucketReducer(eng.grads, ranges)
+    ranges = eng.bucket_ranges()
+    assert len(ranges) == 4 and sum(hi - lo for lo, hi in ranges) == eng.param_numel  # 4 buckets cover every parameter
+    reducer = GradBucketReducer(eng.grads, ranges, shard_optimizer=shard)
     lo, hi = shard_range(x.shape[0], rank, world)
     for _ in range(2):
         eng.train_step(x[lo:hi], labels[lo:hi], lab_len[lo:hi], pred_len[lo:hi], reducer)
@@ -143,13 +173,14 @@ def _engine_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_two_engine_ranks_equal_one_rank_on_the_global_batch(tmp_path):
+@pytest.mark.parametrize("shard", [False, True])
+def test_two_engine_ranks_equal_one_rank_on_the_global_batch(tmp_path, shard):
     """Two processes, each running the real HIP engine on its utterance shard with the bucketed, overlapped gradient
     all-reduce (gloo transport, both on the one GPU of the test box), must end up with the weights of a single process
     that trained on the global batch: same gradient scale (1 / (B_local * world)), same bucket ranges, same Adam."""
     from speechless_amd.engine import Engine
     world = 2
-    mp.spawn(_engine_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_engine_worker, args=(world, _free_port(), str(tmp_path), shard), nprocs=world, join=True)
     specs, weights, x, labels, lab_len, pred_len = _engine_case()
     eng = Engine(specs, 29, dtype="f32", device="cuda:0", lr=1e-3)
     eng.set_weights(weights)
@@ -158,8 +189,11 @@ def test_two_engine_ranks_equal_one_rank_on_the_global_batch(tmp_path):
     torch.cuda.synchronize()
     ref = [w for w, _ in eng.get_weights()]
     moved = 0.0
+    ranks = [np.load(str(tmp_path / "rank{}.npz".format(rank))) for rank in range(world)]
+    for i in range(len(ref)):  # the ranks agree bit for bit (same reduced gradient / the same gathered masters)
+        assert np.array_equal(ranks[0]["arr_{}".format(i)], ranks[1]["arr_{}".format(i)])
     for rank in range(world):
-        got = np.load(str(tmp_path / "rank{}.npz".format(rank)))
+        got = ranks[rank]
         for i, r in enumerate(ref):
             g = got["arr_{}".format(i)]
             # identical up to the fp32 summation order of the gradient (two partial sums added by the all-reduce); Adam's
@@ -172,7 +206,8 @@ def test_two_engine_ranks_equal_one_rank_on_the_global_batch(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_emit_the_data_parallel_diagnostics():
+@pytest.mark.parametrize("shard", [False, True])
+def test_bench_two_ranks_emit_the_data_parallel_diagnostics(shard):
     """bench.py's multi-rank control flow and its `data_parallel` object (world size, bucket sizes, all-reduce alone,
     exposed communication, identical reduced gradients / weights on all ranks), exercised with two ranks sharing the
     one GPU of the test box over gloo (SL_BENCH_SHARE_GPU=1: a test hook, never a measurement)."""
@@ -182,9 +217,9 @@ def test_bench_two_ranks_emit_the_data_parallel_diagnostics():
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, SL_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--profile-steps", "1"]
+    # plain `python bench.py --gpus 2`: the script starts its own ranks (the shape of the driver's command)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--profile-steps", "1"] + \
+        (["--shard-optimizer"] if shard else [])
     res = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(root), timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
@@ -192,5 +227,6 @@ def test_bench_two_ranks_emit_the_data_parallel_diagnostics():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
     dp = out["data_parallel"]
     assert dp["world_size"] == 2 and dp["reduced_gradients_and_weights_identical_on_all_ranks"] is True
-    assert len(dp["bucket_bytes"]) == 2 and sum(dp["bucket_bytes"]) > 90e6
+    assert len(dp["bucket_bytes"]) == 4 and sum(dp["bucket_bytes"]) > 90e6 and dp["sharded_optimizer"] is shard
+    assert dp["bucket_layers"][0] == ["big_conv_2", "output_conv"] and dp["bucket_layers"][-1] == ["striding_conv"]
     assert dp["allreduce_alone_ms"] > 0 and dp["step_ms_with_allreduce"] > 0 and np.isfinite(dp["gradient_checksum"])

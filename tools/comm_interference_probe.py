@@ -45,7 +45,7 @@ def main():
     x, labels, lab_len, pred_len = bench.synthetic_batch(0, bench.BATCH_PER_GPU)
     eng.load_input(torch.from_numpy(x).cuda())
     eng.set_labels(labels, lab_len, pred_len)
-    ranges, _ = eng.bucket_ranges()
+    ranges = eng.bucket_ranges()
     scratch_src = torch.zeros_like(eng.grads)
     scratch_dst = torch.zeros_like(eng.grads)
 

@@ -39,17 +39,13 @@ def only_conv(tag, name, *args):
     real_launch(tag, name, *args)
 variants = {
     "A default (Adam after backward, bias grads on side stream)": dict(early=False, adam=True, launch=real_launch, ow=False),
-    "B early adam (side stream)": dict(early=True, adam=True, launch=real_launch, ow=False),
     "C no adam": dict(early=False, adam=False, launch=real_launch, ow=False),
     "D no bias grads": dict(early=False, adam=True, launch=no_bias, ow=False),
-    "E wgrads on the side stream (overlap_wgrad)": dict(early=False, adam=True, launch=real_launch, ow=True),
     "F convs only": dict(early=False, adam=False, launch=only_conv, ow=False),
 }
 res = {k: [] for k in variants}
 for rep in range(4):
     for k, v in variants.items():
-        eng.early_adam = v["early"]
-        eng.overlap_wgrad = v["ow"]
         eng._adam_layers = real_adam if v["adam"] else (lambda layers, st: None)
         eng._launch = v["launch"]
         res[k].append(timed())
