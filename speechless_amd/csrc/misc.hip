@@ -103,6 +103,21 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ partial, float*
     db[c] = s;
 }
 
+// ONE definition of the element update for every Adam kernel of this file, with the contraction pinned: left to the
+// compiler, `b1 * m + (1 - b1) * g` becomes fma(b1, m, (1 - b1) * g) in one kernel and fma(1 - b1, g, b1 * m) in another,
+// and the plain elementwise kernel (the sharded optimizer's) would differ from the fused Adam + repack kernel in the
+// last bit -- data-parallel runs with and without the sharded optimizer are held to bit-identical weights.
+__device__ __forceinline__ void adam_element(float& p, const float g, float& m, float& v, const float lr_t, const float b1,
+                                             const float b2, const float eps) {
+#pragma clang fp contract(off)
+    const float gm = (1.f - b1) * g;
+    const float gv = (1.f - b2) * g * g;
+    m = __builtin_fmaf(b1, m, gm);
+    v = __builtin_fmaf(b2, v, gv);
+    const float step = lr_t * m / (sqrtf(v) + eps);
+    p = p - step;
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n4, float lr_t, float b1, float b2, float eps) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,9 +128,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     f32x4 pv = ((f32x4*)p)[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        mv[j] = b1 * mv[j] + (1.f - b1) * gv[j];
-        vv[j] = b2 * vv[j] + (1.f - b2) * gv[j] * gv[j];
-        pv[j] = pv[j] - lr_t * mv[j] / (sqrtf(vv[j]) + eps);
+        float pj = pv[j], mj = mv[j], vj = vv[j];
+        adam_element(pj, gv[j], mj, vj, lr_t, b1, b2, eps);
+        pv[j] = pj, mv[j] = mj, vv[j] = vj;
     }
     ((f32x4*)m)[i] = mv;
     ((f32x4*)v)[i] = vv;
@@ -141,9 +156,9 @@ __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __
         f32x4 mv = *(f32x4*)(m + idx), vv = *(f32x4*)(v + idx), pv = *(f32x4*)(p + idx);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mv[j] = b1 * mv[j] + (1.f - b1) * gv[j];
-            vv[j] = b2 * vv[j] + (1.f - b2) * gv[j] * gv[j];
-            pv[j] = pv[j] - lr_t * mv[j] / (sqrtf(vv[j]) + eps);
+            float pj = pv[j], mj = mv[j], vj = vv[j];
+            adam_element(pj, gv[j], mj, vj, lr_t, b1, b2, eps);
+            pv[j] = pj, mv[j] = mj, vv[j] = vj;
         }
         *(f32x4*)(m + idx) = mv;
         *(f32x4*)(v + idx) = vv;
