@@ -348,7 +348,7 @@ class Bench:
                      or t == "fwd:big_conv_1"]
         kernel_ms = self.kernel_pass(roof_tags) if config in (2, 3) else {}
         groups = {}
-        for prefix in ("fwd", "dgrad", "wgrad"):
+        for prefix in ("fwd", "dgrad", "wgrad", "bwd"):  # bwd: = weight and input gradient in one launch (output_conv)
             ms = sum(v for t, v in live_ms.items() if t.startswith(prefix + ":"))
             if ms:
                 groups[prefix] = {"ms_per_step": ms}
@@ -360,7 +360,7 @@ class Bench:
                                "note": "side stream, concurrent with the wgrad/dgrad kernels of the same layer: these "
                                        "durations are stretched by the overlap and are NOT additive with the other groups"}
         groups["per_launch_ms"] = {t: round(v, 4) for t, v in sorted(live_ms.items())}
-        conv_ms = sum(groups[g]["ms_per_step"] for g in ("fwd", "dgrad", "wgrad") if g in groups)
+        conv_ms = sum(groups[g]["ms_per_step"] for g in ("fwd", "dgrad", "wgrad", "bwd") if g in groups)
         # the 1-D conv stack alone (north_star's 40 % target): algorithmic FLOPs of this rank's step over the summed
         # live durations of its forward / dgrad / wgrad launches
         result["conv_stack_mfma_frac"] = (self.flops_per_step / 1e12) / (conv_ms * 1e-3) / self.peak

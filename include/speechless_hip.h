@@ -144,6 +144,29 @@ int sl_conv1d_wgrad_grouped(const void* x, const void* g, float* dw, const sl_co
                             int64_t x_group_stride, int64_t g_group_stride, int64_t dw_group_stride, int cfg,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- backward of a 1x1 convolution onto <= 32 real output channels in ONE launch (bf16) -----------------------------------
+ * Replaces, for output_conv (net.py:326-330: Conv1D(grapheme_set_size, 1)), the pair sl_conv1d_nt(dgrad) +
+ * sl_conv1d_wgrad reached by autodiff from net.py:389,550: both gradients of that layer are HBM-bound passes over its 2000-
+ * channel input, which this call reads ONCE.
+ *   x       : the layer's input [B][rows][x_row_stride] bf16 -- also the stored activation whose sign (ReLU) / value (ELU)
+ *             is the mask of dx
+ *   g       : gradient w.r.t. the layer's output, [B][rows][y_row_stride] bf16, columns >= k_real zero
+ *   w_dgrad : the layer's dgrad operand [cin][1][cout] bf16 (sl_pack_weights)
+ *   dx      : gradient w.r.t. x, same geometry as x:  dx = (g . w^T) * act'(x);  frames in [t_out, ceil(t_out / 64) * 64)
+ *             are written with the zeros they hold by the layout invariant
+ *   dw      : float[cin][cout], complete on return (columns >= 32 zero); its row cin - 1 is the bias gradient when x carries
+ *             the ones channel (sl_bias_grad_from_wgrad)
+ *   geom    : the layer's WEIGHT-GRADIENT geometry (taps = 1; x_* describe x and dx, y_* describe g), cin % 128 == 0
+ *   epilogue: SL_EPI_RELU_MASK or SL_EPI_ELU_MASK
+ *   cfg     : 0 = library picks the number of work-groups (one per CU); otherwise (tuner / tests) that number
+ *   workspace: sl_conv1d_backward_1x1_workspace_bytes() bytes (per-work-group partial sums of dw, combined in a fixed order
+ *             by a small second kernel of the same call: deterministic, no float atomics). */
+int sl_conv1d_backward_1x1_supported(const sl_conv_geom* geom, int k_real, int dtype);
+size_t sl_conv1d_backward_1x1_workspace_bytes(const sl_conv_geom* geom, int k_real, int dtype, int cfg);
+int sl_conv1d_backward_1x1(const void* x, const void* g, const void* w_dgrad, void* dx, float* dw, const sl_conv_geom* geom,
+                           int epilogue, int k_real, int dtype, int cfg, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* bias gradient db[co] = sum_{b,t} g[b][g_row0+t][co] (fp32 out, deterministic two-stage).  Same autodiff site. */
 size_t sl_bias_grad_workspace_bytes(const sl_conv_geom* geom);
 int sl_bias_grad(const void* g, float* db, const sl_conv_geom* geom, int dtype, void* workspace,

@@ -11,7 +11,8 @@ LIB_PATH = PACKAGE_DIR / "libspeechless_hip.so"
 HOST_LIB_PATH = PACKAGE_DIR / "libspeechless_host.so"  # plain C++ helpers of the host input pipeline (no HIP)
 HOST_SOURCES = [PACKAGE_DIR / "csrc_host" / "pack_batch.cpp", PACKAGE_DIR / "csrc_host" / "beam_search.cpp"]
 CXX = os.environ.get("CXX", "g++")
-SOURCES = ["capi.hip", "conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_f32.hip", "ctc.hip", "misc.hip", "spectrogram.hip", "conv_chain_bf16.hip"]
+SOURCES = ["capi.hip", "conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_f32.hip", "ctc.hip", "misc.hip", "spectrogram.hip", "conv_chain_bf16.hip",
+           "conv1x1_bwd_bf16.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("SL_EXTRA_FLAGS", "").split()  # experiments only (e.g. -DSL_NT_SETPRIO); the default build has none
@@ -25,7 +26,7 @@ def _newest_source_mtime():
 # These files read LDS fragments through inline asm with hand-counted s_waitcnt (the compiler does not know the
 # registers are still being filled).  A register spill would store such a register before its data has arrived, so a
 # kernel of these files that needs scratch memory is a BUILD ERROR, not a slow kernel.
-NO_SCRATCH = {"conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_chain_bf16.hip"}
+NO_SCRATCH = {"conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_chain_bf16.hip", "conv1x1_bwd_bf16.hip"}
 
 
 def _scratch_users(remarks):

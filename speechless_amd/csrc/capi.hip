@@ -144,6 +144,32 @@ extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl
     return wgrad_tn_f32(x, g, dw, geom, (float*)workspace, splits, cfg, (hipStream_t)stream);
 }
 
+extern "C" int sl_conv1d_backward_1x1_supported(const sl_conv_geom* geom, int k_real, int dtype) {
+    return geom != nullptr && dtype == SL_BF16 && conv1x1_bwd_bf16_supported(geom, k_real) ? 1 : 0;
+}
+
+extern "C" size_t sl_conv1d_backward_1x1_workspace_bytes(const sl_conv_geom* geom, int k_real, int dtype, int cfg) {
+    if (!sl_conv1d_backward_1x1_supported(geom, k_real, dtype)) return 0;
+    return conv1x1_bwd_bf16_workspace_bytes(geom, cfg);
+}
+
+extern "C" int sl_conv1d_backward_1x1(const void* x, const void* g, const void* w_dgrad, void* dx, float* dw,
+                                      const sl_conv_geom* geom, int epilogue, int k_real, int dtype, int cfg,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    SL_CHECK_ARG(x && g && w_dgrad && dx && dw && geom, "sl_conv1d_backward_1x1: null pointer");
+    SL_CHECK_ARG(epilogue == SL_EPI_RELU_MASK || epilogue == SL_EPI_ELU_MASK,
+                 "sl_conv1d_backward_1x1: epilogue must be SL_EPI_RELU_MASK or SL_EPI_ELU_MASK");
+    if (!sl_conv1d_backward_1x1_supported(geom, k_real, dtype)) {
+        sl_set_error("sl_conv1d_backward_1x1: needs bf16, a 1x1 layer with <= 32 real output channels and a multiple of 128 "
+                     "input channels");
+        return SL_ERR_UNSUPPORTED;
+    }
+    SL_CHECK_ARG(geom->x_row0 >= 0 && geom->y_row0 >= 0 && geom->x_row_stride >= geom->cin && geom->y_row_stride >= 32,
+                 "sl_conv1d_backward_1x1: bad geometry");
+    SL_CHECK_ARG(cfg >= 0, "sl_conv1d_backward_1x1: cfg must be >= 0");
+    return conv1x1_bwd_bf16(x, g, w_dgrad, dx, dw, geom, epilogue, cfg, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" size_t sl_conv1d_wgrad_grouped_workspace_bytes(const sl_conv_geom* geom, int groups, int cfg) {
     if (!geom || groups < 1 || geom->taps <= 0 || geom->cin <= 0 || geom->cout <= 0 || geom->batch <= 0) return 0;
     if (geom->cin % 128 || geom->cout % 128) return 0;

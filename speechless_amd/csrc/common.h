@@ -89,3 +89,7 @@ size_t wgrad_tn_bf16_workspace_bytes(const sl_conv_geom* g, int cfg, int groups)
 int wgrad_tn_f32(const void* x, const void* gr, float* dw, const sl_conv_geom* g, float* ws, int splits, int cfg,
                  hipStream_t s);
 int wgrad_f32_tile(const sl_conv_geom* g, int cfg);
+bool conv1x1_bwd_bf16_supported(const sl_conv_geom* g, int k_real);
+size_t conv1x1_bwd_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
+int conv1x1_bwd_bf16(const void* x, const void* gr, const void* w_dgrad, void* dx, float* dw, const sl_conv_geom* g,
+                     int epilogue, int cfg, void* ws, size_t ws_bytes, hipStream_t s);

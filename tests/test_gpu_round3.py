@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import w2l_oracle as o
-from test_gpu_parity import make_case, make_engine
+from test_gpu_parity import make_case, make_engine, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -131,3 +131,74 @@ def test_sharded_pack_layers_equals_the_fused_adam_operands():
         assert torch.equal(a, b)
     for a, b in zip(eng.w_dgrad, want_d):
         assert (a is None and b is None) or torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ fused output-layer backward
+def _output_layer_backward_reference(eng):
+    """float64 dx / dw of the output layer from the EXACT bf16 operands the kernels read (buffers of the current step)."""
+    from speechless_amd.engine import HALO
+    buf = eng.cur
+    n = len(eng.plans)
+    t = buf.t_out
+    x = buf.y[n - 2][:, HALO:HALO + t].float().cpu().numpy().astype(np.float64)      # (B, T', 2048)
+    g = buf.g[n - 1][:, HALO:HALO + t].float().cpu().numpy().astype(np.float64)      # (B, T', 128)
+    w = eng.w_dgrad[n - 1][:, 0, :].float().cpu().numpy().astype(np.float64)          # (2048, 128)
+    pre = g @ w.T
+    if eng.specs[n - 2].activation == "elu":
+        dx = pre * np.where(x > 0, 1.0, x + 1.0)
+    else:
+        dx = pre * (x > 0)
+    dw = np.einsum("btc,btk->ck", x, g)
+    return dx, dw
+
+
+@pytest.mark.parametrize("b,t,activation", [(32, 1000, "relu"), (3, 150, "relu"), (8, 8000, "relu"), (5, 333, "elu")])
+def test_fused_output_backward_against_float64_and_the_two_launches(b, t, activation):
+    """sl_conv1d_backward_1x1 (weight and input gradient of output_conv in one launch, the layer's input read once) on
+    the production geometry (32 x 1000 frames), an odd one, configuration 5's (8 x 8000 frames) and behind an ELU:
+    against float64 on the exact bf16 operands, against the dgrad + wgrad launches it replaces, and twice (bitwise)."""
+    import torch
+    from speechless_amd.engine import HALO, Engine, wav2letter_layer_specs
+    case = make_case(b=b, t=t, seed=9)
+    specs = wav2letter_layer_specs(128, 29, activation=activation)
+    eng = Engine(specs, 29, dtype="bf16")
+    eng.set_weights(case["weights"])
+    eng.load_input(case["x"])
+    eng.set_labels(case["labels"], case["label_lengths"], case["prediction_lengths"])
+    eng.use_launch_lists = False
+    eng.forward(training=True)
+    eng.ctc()
+    n = len(eng.plans)
+    results = {}
+    for mode in ("fused", "fused_again", "two_launches"):
+        eng.fuse_output_backward = mode != "two_launches"
+        eng.grads.zero_()
+        eng.cur.g[n - 2].zero_()
+        eng.timeline = []
+        eng.backward()
+        torch.cuda.synchronize()
+        tags = [tag for tag, _, _ in eng.timeline]
+        eng.timeline = None
+        assert ("bwd:output_conv" in tags) == (mode != "two_launches"), tags
+        dw, db = eng.layer_param_views(eng.grads, eng.plans[n - 1])
+        results[mode] = (eng.cur.g[n - 2].clone(), dw.clone(), db.clone())
+    assert torch.equal(results["fused"][0], results["fused_again"][0])           # deterministic
+    assert torch.equal(results["fused"][1], results["fused_again"][1])
+    dx_ref, dw_ref = _output_layer_backward_reference(eng)
+    t_out = eng.cur.t_out
+    for mode in ("fused", "two_launches"):
+        gprev, dw, db = results[mode]
+        got_dx = gprev[:, HALO:HALO + t_out].float().cpu().numpy()
+        # bf16 output rounding: 2^-9 relative per element
+        assert np.abs(got_dx - dx_ref).max() <= 2.0 ** -8 * np.abs(dx_ref).max() + 1e-30, mode
+        assert rel_l2(got_dx, dx_ref) < 3e-3, mode
+        got_dw = dw[0].cpu().numpy()                                                # (2048, 128) fp32
+        assert rel_l2(got_dw[:2000, :29], dw_ref[:2000, :29]) < 2e-6, (mode, rel_l2(got_dw[:2000, :29], dw_ref[:2000, :29]))
+        assert (got_dw[:, 29:] == 0).all() and (got_dw[2000:] == 0).all()  # (row 2047 was moved to the bias gradient)
+        assert rel_l2(db.cpu().numpy()[:29], dw_ref[2047, :29]) < 2e-6, mode     # ones channel: sum of g over the frames
+        # layout invariant of the gradient tensor: halo rows, rows beyond the valid time and the ones channel stay zero
+        full = gprev.float().cpu().numpy()
+        assert (full[:, :HALO] == 0).all() and (full[:, HALO + t_out:] == 0).all()
+    # bias gradient of output_conv: from the ones channel in both modes (row cin_pad - 1), same value
+    assert torch.allclose(results["fused"][2], results["two_launches"][2], rtol=1e-5, atol=1e-7)
+    assert rel_l2(results["fused"][0].float().cpu().numpy(), results["two_launches"][0].float().cpu().numpy()) < 1e-3

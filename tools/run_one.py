@@ -52,6 +52,7 @@ def main():
     i = p.index
     n = len(eng.plans)
     ws = torch.empty((512 << 20,), dtype=torch.uint8, device=eng.device)
+    wsz = torch.zeros((64 << 20,), dtype=torch.uint8, device=eng.device)  # zeroed: work-group tickets of bwd1x1
     st = torch.cuda.current_stream().cuda_stream
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
@@ -68,6 +69,11 @@ def main():
             eng.lib.call("sl_conv1d_nt", buf.g[i].data_ptr(), eng.w_dgrad[i].data_ptr(), None, buf.y[i - 1].data_ptr(),
                          buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_RELU_MASK, eng.dtype_code, 0,
                          args.cfg, ws.data_ptr(), ws.numel(), st)
+        elif args.kind == "bwd1x1":  # both gradients of the 1x1 output layer in one launch (--layer output_conv)
+            dw, _ = eng.layer_param_views(eng.grads, p)
+            eng.lib.call("sl_conv1d_backward_1x1", buf.y[i - 1].data_ptr(), buf.g[i].data_ptr(), eng.w_dgrad[i].data_ptr(),
+                         buf.g[i - 1].data_ptr(), dw.data_ptr(), ctypes.byref(buf.wgrad_geom[i]), _lib.EPI_RELU_MASK, 29,
+                         eng.dtype_code, args.cfg, wsz.data_ptr(), wsz.numel(), st)
         elif args.kind == "wgrad_grouped":  # --layer = first layer of a run of identical layers (inner_conv_1)
             lo, hi = [r for r in eng.runs if r[0] == i][0]
             dw_lo, _ = eng.layer_param_views(eng.grads, p)
