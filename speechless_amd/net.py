@@ -511,6 +511,22 @@ class Wav2Letter:
                 np.array([len(l) for l in labels], dtype=np.int32),
                 np.array([s.shape[0] // ratio for s in spectrograms], dtype=np.int32))
 
+    def _pack_audio_for_staging(self, labeled_example_batch):
+        """The host half of a training step from raw audio (pipeline.AudioBatchStager): samples and encoded labels."""
+        labels = [x.label for x in labeled_example_batch]
+        return ([x.get_raw_audio() for x in labeled_example_batch], self.grapheme_encoding.encode_label_batch(labels),
+                np.array([len(l) for l in labels], dtype=np.int32))
+
+    def _audio_extractor(self, example):
+        """The GPU front end matching this net's input (mel count = input size, or the linear 1 + n_fft / 2 bins) with the
+        STFT parameters of the batch's LabeledExample objects (labeled_example.py:74-92)."""
+        from .spectrogram import shared_extractor
+        n_fft = getattr(example, "fourier_window_length", 512)
+        hop = getattr(example, "hop_length", 128)
+        rate = getattr(example, "sample_rate", 16000)
+        mel = None if self.input_size_per_time_step == 1 + n_fft // 2 else self.input_size_per_time_step
+        return shared_extractor(rate, n_fft, hop, mel, self.device)
+
     def train_on_staged_batch(self, staged, stager, reducer=None):
         """train_on_batch for a pipeline.StagedBatch (input already in HBM, arrival ordered by an event)."""
         self.engine.load_input(staged.x_dev)
@@ -521,20 +537,40 @@ class Wav2Letter:
 
     def train(self, labeled_spectrogram_batches, preview_labeled_spectrogram_batch, tensor_board_log_directory,
               net_directory, batches_per_epoch, max_epochs=100000000, reducer=None, prefetch_depth=3,
-              save_optimizer_state=False):
+              save_optimizer_state=False, from_audio=False):
         """Epoch loop of reference net.py:541-576: preview, then epochs of `batches_per_epoch` steps starting at
         `load_epoch or 0`; after every epoch the preview is logged and (epoch > 0) the weights are saved as
         weights-epoch{N}.  Ends when the batch iterable is exhausted or after max_epochs (Keras: 1e8).
         prefetch_depth > 0: batches are packed on a worker thread and copied to HBM on a side stream
         (speechless_amd/pipeline.py) while the previous steps run; 0 = the reference's serial behaviour.
         save_optimizer_state: also write weights-epoch{N}.opt.npz (Adam moments + step count) with every checkpoint,
-        for Wav2Letter(..., load_optimizer_state=True) to resume exactly where the run stopped."""
+        for Wav2Letter(..., load_optimizer_state=True) to resume exactly where the run stopped.
+        from_audio: the batches hold reference-style LabeledExample objects (labeled_example.py:74-140) and the spectrograms
+        are computed on the GPU from their raw audio (`get_raw_audio()`), on the copy stream under the previous step
+        (pipeline.AudioBatchStager) -- labeled_example.py:136-140 feeding net.py:593 without the spectrogram ever
+        existing on the host.  Needs prefetch_depth > 0."""
         def print_preview_batch():
             log(self.test_and_predict_batch(preview_labeled_spectrogram_batch))
 
         print_preview_batch()
         stager = None
-        if prefetch_depth > 0:
+        if from_audio:
+            from .pipeline import AudioBatchStager
+            if prefetch_depth <= 0:
+                raise ValueError("from_audio=True trains through the staged pipeline: prefetch_depth must be > 0")
+            labeled_spectrogram_batches = iter(labeled_spectrogram_batches)
+            first = next(labeled_spectrogram_batches, None)
+
+            def with_first():
+                if first is not None:
+                    yield first
+                    yield from labeled_spectrogram_batches
+            extractor = self._audio_extractor(first[0]) if first else None
+            stager = AudioBatchStager(with_first(), self._pack_audio_for_staging, extractor,
+                                      self.input_to_prediction_length_ratio, self.engine.device,
+                                      blank=self.grapheme_encoding.grapheme_set_size - 1, depth=prefetch_depth)
+            batches = iter(stager)
+        elif prefetch_depth > 0:
             from .pipeline import BatchStager
             stager = BatchStager(labeled_spectrogram_batches, self._pack_for_staging, self.engine.device,
                                  blank=self.grapheme_encoding.grapheme_set_size - 1, depth=prefetch_depth)

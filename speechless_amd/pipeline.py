@@ -176,3 +176,79 @@ class BatchStager:
             f.cancel()
         self.pool.shutdown(wait=True)
         self.pending = []
+
+
+class AudioBatchStager(BatchStager):
+    """BatchStager for raw audio (training straight from audio).  A batch is a list of
+    reference-style LabeledExample objects (labeled_example.py:74-140: `.get_raw_audio()`, `.label`); the worker threads
+    read the audio, the H2D copy moves SAMPLES (512 bytes per 128-sample hop: the same bytes per frame as a 128-mel float32
+    spectrogram) and the front end -- STFT, power level, mel projection, z-normalisation (speechless_amd/spectrogram.py) --
+    runs on the copy stream right behind it, under the training step of the previous batch.  The spectrogram never exists
+    on the host.  pack(batch) -> (raw audio list, label_batch, label_lengths); prediction lengths follow from the frame
+    counts."""
+
+    def __init__(self, batches, pack, extractor, length_ratio, device, blank, depth=3, workers=3, spare_slots=5):
+        super().__init__(batches, pack, device, blank, depth=depth, workers=workers, spare_slots=spare_slots)
+        self.extractor = extractor
+        self.length_ratio = length_ratio
+        self.front_end_events = []  # optional (start, stop) timing events per batch, see time_front_end
+
+    time_front_end = False
+
+    def _stage(self, slot, batch):
+        torch.cuda.set_device(self.device)
+        audios, labels, label_lengths = self.pack(batch)
+        b = len(audios)
+        n = int(sum(np.asarray(a).size for a in audios))
+        if slot.copied is not None:
+            slot.copied.synchronize()      # the previous H2D out of this staging buffer is done
+        if slot.pinned is None or slot.pinned.numel() < n:
+            slot.pinned = torch.empty((n,), dtype=torch.float32)
+            slot.device = torch.empty((n,), dtype=torch.float32, device=self.device)
+        flat, offsets, lengths = self.extractor.flatten(audios, out=slot.pinned.numpy())
+        labels = np.asarray(labels, dtype=np.int32)
+        lab_len = np.asarray(label_lengths, dtype=np.int32).reshape(-1)
+        if labels.ndim != 2 or labels.shape[0] != b:
+            raise ValueError("label batch must be (B, Lmax)")
+        for i in range(b):
+            row = labels[i, :lab_len[i]]
+            if row.size and (row.min() < 0 or row.max() >= self.blank):
+                raise ValueError("label {} holds an index outside [0, {}) (blank is {})".format(i, self.blank, self.blank))
+        if labels.shape[1] == 0:
+            labels = np.zeros((b, 1), dtype=np.int32)
+        with self.copy_lock, torch.cuda.stream(self.copy_stream):
+            # (the device audio buffer of this slot is only ever touched on the copy stream: refills are ordered behind
+            # the front-end kernels that read it by the stream itself)
+            audio_dev = slot.device[:n]
+            audio_dev.copy_(slot.pinned[:n], non_blocking=True)
+            off_dev = torch.from_numpy(offsets).to(self.device)
+            len_dev = torch.from_numpy(lengths).to(self.device)
+            copied = torch.cuda.Event()
+            copied.record(self.copy_stream)
+            if self.time_front_end:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.copy_stream)
+            x_dev, frames = self.extractor.batch_device(audio_dev, off_dev, len_dev, lengths)
+            if self.time_front_end:
+                t1.record(self.copy_stream)
+                self.front_end_events.append((t0, t1))
+            pred_len = np.array([f // self.length_ratio for f in frames], dtype=np.int32)
+            labels_dev = torch.from_numpy(np.ascontiguousarray(labels)).to(self.device)
+            lab_len_dev = torch.from_numpy(lab_len).to(self.device)
+            pred_len_dev = torch.from_numpy(pred_len).to(self.device)
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        slot.copied = copied
+        slot.consumed = None
+        staged = StagedBatch(slot, x_dev, labels_dev, lab_len_dev, pred_len_dev, ready)
+        staged.frames = frames
+        return staged
+
+    def __next__(self):
+        item = super().__next__()
+        # the spectrogram was allocated on the copy stream and is read by the compute stream (sl_pack_input)
+        item.x_dev.record_stream(torch.cuda.current_stream(self.device))
+        return item
+
+    def release(self, staged):
+        pass  # nothing of the slot is read by the compute stream: x_dev is the allocator's, kept alive by record_stream

@@ -84,7 +84,16 @@ class SpectrogramExtractor:
     def batch(self, raw_audio_list):
         """raw_audio_list: 1-D float arrays (any float dtype).  Returns (x, frames): x float32 (B, Tmax, F) in HBM, every
         utterance z-normalised over its own frames and zero beyond them; frames int list."""
-        audios = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in raw_audio_list]
+        flat, offsets, lengths = self.flatten(raw_audio_list)
+        flat_dev = torch.from_numpy(flat).to(self.device, non_blocking=True)
+        off_dev = torch.from_numpy(offsets).to(self.device, non_blocking=True)
+        len_dev = torch.from_numpy(lengths).to(self.device, non_blocking=True)
+        return self.batch_device(flat_dev, off_dev, len_dev, lengths)
+
+    def flatten(self, raw_audio_list, out=None):
+        """Host half of batch(): the utterances back to back as float32 (into `out`, a flat float32 array, if given),
+        their start offsets (int64) and sample counts (int32)."""
+        audios = [np.asarray(a).reshape(-1) for a in raw_audio_list]
         if not audios:
             raise ValueError("empty batch")
         lengths = np.array([a.shape[0] for a in audios], dtype=np.int32)
@@ -93,16 +102,23 @@ class SpectrogramExtractor:
                 self.n_fft // 2 + 1))
         offsets = np.zeros(len(audios), dtype=np.int64)
         offsets[1:] = np.cumsum(lengths[:-1])
-        flat = torch.from_numpy(np.concatenate(audios)).to(self.device, non_blocking=True)
-        off_dev = torch.from_numpy(offsets).to(self.device, non_blocking=True)
-        len_dev = torch.from_numpy(lengths).to(self.device, non_blocking=True)
+        total = int(lengths.sum())
+        flat = np.empty((total,), dtype=np.float32) if out is None else out[:total]
+        for a, off, n in zip(audios, offsets, lengths):
+            flat[off:off + n] = a  # (casts float64 / int16-scaled-by-the-reader input to float32)
+        return flat, offsets, lengths
+
+    def batch_device(self, flat_dev, off_dev, len_dev, lengths):
+        """Device half of batch(): audio already in HBM (flat float32, int64 offsets, int32 sample counts; `lengths` the
+        same counts on the host).  Everything is enqueued on the CURRENT stream -- the staged input pipeline calls this
+        on its copy stream, right behind the H2D copy of the audio, so the front end of batch n + 1 runs under step n."""
         frames = [self.frame_count(int(n)) for n in lengths]
         frames_dev = torch.tensor(frames, dtype=torch.int32, device=self.device)
-        b, t_max = len(audios), max(frames)
+        b, t_max = len(frames), max(frames)
         rows = _round_up(t_max, TIME_TILE)  # sl_conv1d_nt reads whole time tiles
         st = torch.cuda.current_stream(self.device).cuda_stream
         level = torch.empty((b, rows, self.bins_pad), dtype=torch.float32, device=self.device)
-        self.lib.call("sl_stft_power_db", flat.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), level.data_ptr(), b,
+        self.lib.call("sl_stft_power_db", flat_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), level.data_ptr(), b,
                       rows, self.n_fft, self.hop, self.bins_pad, rows * self.bins_pad, self.min_decibel, st)
         src, src_stride = level, self.bins_pad
         if self.mel_w is not None:

@@ -152,12 +152,19 @@ def test_bf16_gradients_at_full_length_against_the_cpu_path():
         _report("full_length_gradient_rel_l2_vs_cpu_{}".format(dtype),
                 {s.name: [float(a), float(b)] for s, (a, b) in zip(eng.specs, errs[dtype])})
     names = [s.name for s in case["specs"]]
-    # fp32 path: the bar north_star sets, up to ReLU flips between two fp32 summation orders (see the config-5 test)
-    assert errs["f32"][-1][0] < 5e-4 and max(e for pair in errs["f32"] for e in pair) < 1e-2
-    # bf16 path, absolute bounds (measured: 1.4e-3 at output_conv ... ~0.2 at striding_conv), top of the stack downwards
-    bounds = {"output_conv": 4e-3, "big_conv_2": 2e-2, "big_conv_1": 4e-2}
+    # Bounds = what was measured (profiles/r02k_parity.json, gpurun_out/parity.json) + 20 %, per tensor, so that a regression
+    # of any single layer shows.  fp32 path: the floor of 2.5e-4 on EVERY tensor is the reference's, not the kernels' -- the
+    # torch-CPU CTC is an fp32 log-domain lattice (2.5e-4 at 500 frames), the HIP lattice runs in
+    # doubles; on top of it the ReLU flips between two fp32 summation orders (see the config-5 test) in the lowest layers.
+    f32_bounds = {"striding_conv": 4.7e-3, "inner_conv_1": 7.5e-4, "inner_conv_2": 5.4e-4, "inner_conv_3": 4.0e-4}
+    for name, (ew, eb) in zip(names, errs["f32"]):
+        assert ew < f32_bounds.get(name, 3.4e-4) and eb < f32_bounds.get(name, 3.4e-4), ("f32", name, ew, eb)
+    # bf16 path (measured: 1.75e-3 at output_conv ... 0.167 at striding_conv), top of the stack downwards
+    bounds = {"output_conv": 2.1e-3, "big_conv_2": 4.1e-3, "big_conv_1": 5.9e-3, "inner_conv_7": 6.5e-3,
+              "inner_conv_6": 8.6e-3, "inner_conv_5": 1.1e-2, "inner_conv_4": 1.38e-2, "inner_conv_3": 1.65e-2,
+              "inner_conv_2": 2.2e-2, "inner_conv_1": 3.15e-2, "striding_conv": 0.2}
     for name, (ew, eb) in zip(names, errs["bf16"]):
-        assert ew < bounds.get(name, 0.35) and eb < bounds.get(name, 0.35), (name, ew, eb)
+        assert ew < bounds[name] and eb < bounds[name], ("bf16", name, ew, eb)
     # errors grow monotonically (within noise) from the output layer down: no single layer is "broken"
     ews = [e for e, _ in errs["bf16"]]
     assert all(ews[i] < 2.5 * ews[i - 1] + 1e-3 for i in range(len(ews) - 1, 0, -1)), ews

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import w2l_oracle as o
-from test_gpu_parity import make_case, make_engine, rel_l2
+from test_gpu_parity import _report, make_case, make_engine, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -202,3 +202,88 @@ def test_fused_output_backward_against_float64_and_the_two_launches(b, t, activa
     # bias gradient of output_conv: from the ones channel in both modes (row cin_pad - 1), same value
     assert torch.allclose(results["fused"][2], results["two_launches"][2], rtol=1e-5, atol=1e-7)
     assert rel_l2(results["fused"][0].float().cpu().numpy(), results["two_launches"][0].float().cpu().numpy()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ production launches at B = 32
+def _conv_ref64(x, w, bias, stride):
+    """Conv1D(padding="same") in float64 on the GPU (torch matmul per tap: an implementation that shares nothing with the
+    HIP kernels).  x (B, T, Cin), w (k, Cin, Cout) -> (B, T', Cout); differentiable."""
+    import torch
+    k = w.shape[0]
+    t_in = x.shape[1]
+    t_out, pad_l, pad_r = o.same_padding(t_in, k, stride)
+    xp = torch.nn.functional.pad(x, (0, 0, pad_l, pad_r))
+    y = None
+    for tap in range(k):
+        term = xp[:, tap: tap + (t_out - 1) * stride + 1: stride] @ w[tap]
+        y = term if y is None else y + term
+    return y + bias
+
+
+def test_production_step_at_batch_32_layer_by_layer_against_float64():
+    """The launches the benchmark times -- 32 x 1000 frames, bf16: slab kernel with split-K, the fused inner-layer launches
+    in both directions, grouped / interleaved weight gradients with their batch splits, output layer fused with the softmax
+    and its one-launch backward -- each checked on the EXACT operands it read: every stored activation / gradient tensor is
+    bf16, so the float64 result from the stored inputs of a launch is what that launch had to produce, up to fp32
+    accumulation order (weight gradients: fp32 out) and one bf16 rounding (activations, input gradients)."""
+    import torch
+    import bench
+    from speechless_amd.engine import HALO, Engine, wav2letter_layer_specs
+    from speechless_amd.net import Wav2Letter
+    specs = wav2letter_layer_specs(bench.MEL, bench.K_CLASSES)
+    eng = Engine(specs, bench.K_CLASSES, dtype="bf16")
+    eng.set_weights(Wav2Letter._glorot_uniform(specs, 2))
+    x, labels, lab_len, pred_len = bench.synthetic_batch(0, bench.BATCH_PER_GPU)
+    eng.load_input(torch.from_numpy(x).cuda())
+    eng.set_labels(labels, lab_len, pred_len)
+    eng.timeline = []
+    eng.forward(training=True)
+    eng.ctc()
+    eng.backward()
+    torch.cuda.synchronize()
+    tags = {tag for tag, _, _ in eng.timeline}
+    eng.timeline = None
+    for tag in ("fwd:inner_conv_1..inner_conv_7", "dgrad:inner_conv_7..inner_conv_1", "wgrad:inner_conv_1..inner_conv_7",
+                "bwd:output_conv", "fwd:output_conv", "wgrad:big_conv_1", "dgrad:big_conv_1"):
+        assert tag in tags, (tag, sorted(tags))  # the production launches, not their fallbacks
+    buf = eng.cur
+    n, t_out = len(eng.plans), buf.t_out
+    f64 = torch.float64
+    # the input as the first layer read it (bf16, pair-view buffer: frame f at row pad_left + f)
+    p0 = eng.plans[0]
+    stored_in = buf.x0[:, p0.pad_left:p0.pad_left + x.shape[1], :specs[0].cin].to(f64)
+    report = {}
+    for i, (p, s) in enumerate(zip(eng.plans, specs)):
+        w = eng.w_fwd[i].to(f64).permute(1, 2, 0)[:, :s.cin, :s.cout].contiguous()       # the bf16 operand copy
+        bias = eng.layer_param_views(eng.params, p)[1][:s.cout].to(f64)
+        xin = (stored_in if i == 0 else buf.y[i - 1][:, HALO:HALO + t_out, :s.cin].to(f64)).detach().requires_grad_(True)
+        wl = w.detach().requires_grad_(True)
+        pre = _conv_ref64(xin, wl, bias, s.stride)
+        # ---- forward
+        if i < n - 1:
+            got = buf.y[i][:, HALO:HALO + t_out, :s.cout].to(f64)
+            want = torch.relu(pre.detach())
+            err = float((got - want).norm() / want.norm())
+            # measured 1.66e-3 on every layer = the rel-L2 of one bf16 rounding (2^-9 / sqrt(3) ... 2^-9), nothing else
+            assert err < 2e-3 and float((got - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()), (s.name, err)
+        else:
+            want = torch.softmax(pre.detach(), dim=2)
+            err = float((buf.probs.to(f64) - want).abs().max())
+            assert err < 2e-6, (s.name, err)                                               # probabilities: fp32 out
+        report["fwd:" + s.name] = err
+        # ---- backward from the stored gradient w.r.t. this layer's pre-activation
+        g = buf.g[i][:, HALO:HALO + t_out, :s.cout].to(f64)
+        pre.backward(g)
+        dw, db = eng.layer_param_views(eng.grads, p)
+        e_w = float((dw[:, :s.cin, :s.cout].to(f64) - wl.grad).norm() / wl.grad.norm())
+        e_b = float((db[:s.cout].to(f64) - g.sum(dim=(0, 1))).norm() / g.sum(dim=(0, 1)).norm())
+        assert e_w < 2e-6 and e_b < 1e-6, (s.name, e_w, e_b)  # measured: 1.6e-7 .. 6.5e-7 (fp32 accumulation order)
+        report["wgrad:" + s.name], report["bgrad:" + s.name] = e_w, e_b
+        if i > 0:
+            want = xin.grad * (xin.detach() > 0)
+            got = buf.g[i - 1][:, HALO:HALO + t_out, :s.cin].to(f64)
+            e_x = float((got - want).norm() / want.norm())
+            assert e_x < 2e-3, (s.name, e_x)
+            report["dgrad:" + s.name] = e_x
+        del xin, wl, pre, g
+    _report("production_launches_batch32_vs_float64", report)

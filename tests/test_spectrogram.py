@@ -154,3 +154,39 @@ def test_labeled_example_drop_in_feeds_the_net():
     # raw audio to transcription without the spectrogram leaving HBM
     assert net.predict_batch_greedily_from_audio(audios) == net.predict_batch_greedily(
         [e.z_normalized_transposed_spectrogram() for e in gpu_examples])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mel", [128, None])
+def test_training_from_audio_in_hbm_equals_training_on_the_returned_spectrograms(tmp_path, mel):
+    """Wav2Letter.train(..., from_audio=True): raw audio is staged, the front end runs on the copy stream and the conv
+    stack reads its output in HBM (pipeline.AudioBatchStager) -- labeled_example.py:136-140 feeding net.py:593 without a
+    host spectrogram.  The weights after the run must equal, bit for bit, those of the same run fed by
+    LabeledExample.z_normalized_transposed_spectrogram() (GPU -> numpy -> host packer -> GPU), for the mel input of
+    configuration 3 and the 257-bin linear input of configuration 5."""
+    from speechless_amd import Wav2Letter, english_frequent_characters
+    from speechless_amd.net import Adam
+    from speechless_amd.spectrogram import LabeledExample
+    rng = np.random.RandomState(5)
+    words = ["she", "wasn't", "three", "abc", "xyz", "a", "it's", "zoo"]
+
+    def example(i):
+        audio = synthetic_audio(float(rng.uniform(1.0, 2.2)), 100 + i)
+        return LabeledExample(lambda a=audio: a, id="u{}".format(i), mel_frequency_count=mel,
+                              label=" ".join(rng.choice(words, size=rng.randint(1, 4))))
+    batches = [[example(10 * j + i) for i in range(int(rng.randint(2, 5)))] for j in range(9)]
+    small = dict(main_filter_count=250, out_filter_count=256, inner_count=2)
+    finals = []
+    for from_audio in (False, True):
+        net = Wav2Letter(128 if mel else 257, english_frequent_characters, optimizer=Adam(1e-3), seed=4, layer_sizes=small)
+        net.train(batches, preview_labeled_spectrogram_batch=batches[0][:2], tensor_board_log_directory=None,
+                  net_directory=tmp_path / "n{}".format(int(from_audio)), batches_per_epoch=3, from_audio=from_audio)
+        finals.append([w.copy() for w, _ in net.predictive_net.get_weights()])
+    moved = 0.0
+    for a, b in zip(*finals):
+        assert np.array_equal(a, b)
+        moved = max(moved, float(np.abs(a).max()))
+    assert moved > 0
+    with pytest.raises(ValueError, match="prefetch_depth"):
+        net.train(batches, preview_labeled_spectrogram_batch=batches[0][:2], tensor_board_log_directory=None,
+                  net_directory=tmp_path / "x", batches_per_epoch=3, from_audio=True, prefetch_depth=0)

@@ -22,7 +22,12 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="utterances of 600..1000 frames: every batch is padded to its own longest member, as the "
                          "reference's generator does (corpus.py:224-226), so the frame count changes from step to step")
+    ap.add_argument("--from-audio", action="store_true",
+                    help="train from RAW AUDIO (8 s per utterance = 1001 frames): samples staged, front end on the copy "
+                         "stream (pipeline.AudioBatchStager); also times the front end alone")
     args = ap.parse_args()
+    if args.from_audio:
+        return from_audio(args)
     import torch
     from speechless_amd import Wav2Letter, english_frequent_characters
     from speechless_amd.net import LabeledSpectrogram
@@ -71,6 +76,63 @@ def main():
         32 * args.steps / serial, serial / args.steps * 1e3))
     print("staged (worker thread, copy stream): {:8.1f} utt/s ({:.2f} ms per batch)".format(
         32 * args.steps / piped, piped / args.steps * 1e3))
+
+
+def from_audio(args):
+    import torch
+    from speechless_amd import Wav2Letter, english_frequent_characters
+    from speechless_amd.pipeline import AudioBatchStager
+    from speechless_amd.spectrogram import LabeledExample
+    rng = np.random.RandomState(0)
+    chars = "abcdefghijklmnopqrstuvwxyz '"
+    pool = []
+    for i in range(64):
+        label = "".join(rng.choice(list(chars), size=rng.randint(20, 201))).strip() or "a"
+        audio = (0.1 * rng.randn(128000)).astype(np.float32)  # 8 s at 16 kHz -> 1001 frames
+        pool.append(LabeledExample(lambda a=audio: a, id=str(i), label=" ".join(label.split())[:190]))
+    batches = [[pool[(j * 7 + i) % 64] for i in range(32)] for j in range(args.steps + 8)]
+    net = Wav2Letter(128, english_frequent_characters, seed=0)
+    extractor = net._audio_extractor(pool[0])
+    # the front end alone: 32 utterances of audio already in HBM -> (32, 1001, 128) z-normalised mel batch
+    flat, offsets, lengths = extractor.flatten([e.get_raw_audio() for e in batches[0]])
+    dev = [torch.from_numpy(a).cuda() for a in (flat, offsets, lengths)]
+    for _ in range(3):
+        extractor.batch_device(dev[0], dev[1], dev[2], lengths)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        extractor.batch_device(dev[0], dev[1], dev[2], lengths)
+    torch.cuda.synchronize()
+    front = (time.perf_counter() - t0) / 20
+
+    def run(n):
+        stager = AudioBatchStager(batches[:n], net._pack_audio_for_staging, extractor,
+                                  net.input_to_prediction_length_ratio, net.engine.device,
+                                  blank=net.grapheme_encoding.grapheme_set_size - 1, depth=3, workers=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for staged in stager:
+            loss = net.train_on_staged_batch(staged, stager)
+        float(loss.item())
+        dt = time.perf_counter() - t0
+        stager.close()
+        return dt
+    run(6)
+    piped = run(args.steps)
+    eng = net.engine
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step_resident()
+    torch.cuda.synchronize()
+    resident = time.perf_counter() - t0
+    print("resident input (the bench.py regime)        : {:8.1f} utt/s ({:.2f} ms per batch)".format(
+        32 * args.steps / resident, resident / args.steps * 1e3))
+    print("from raw audio, staged (front end on the copy stream): {:8.1f} utt/s ({:.2f} ms per batch) = {:.1f} % of resident".format(
+        32 * args.steps / piped, piped / args.steps * 1e3, 100 * resident / piped))
+    print("front end alone (STFT + level + mel + z-norm, 32 x 8 s in HBM): {:.3f} ms per batch = {:.0f} utt/s = {:.1f} % of a "
+          "training step; H2D of the samples: {:.1f} MB per batch".format(
+              front * 1e3, 32 / front, 100 * front / (resident / args.steps), flat.nbytes / 1e6))
 
 
 if __name__ == "__main__":
