@@ -178,31 +178,29 @@ class PredictiveNet:
         self._engine.set_weights(weights)
 
     def save_weights(self, path):
-        """Keras writes HDF5 (net.py:572).  h5py is used when importable; otherwise the same per-layer
-        kernel/bias arrays go to an .npz next to the requested name."""
+        """Keras writes HDF5 (net.py:572: `predictive_net.save_weights(...)`): the same file -- root attribute
+        `layer_names`, one group per layer with `weight_names`, `<layer>/kernel:0` (k, Cin, Cout) and `<layer>/bias:0`
+        below it -- through speechless_amd/h5lite.py (no h5py needed; the real HDF5 library reads it, tests/test_h5lite.py).
+        A path ending in .npz keeps the flat numpy form (`<layer>/kernel`, `<layer>/bias`)."""
         path = Path(path)
         weights = self.get_weights()
-        try:
-            import h5py
-        except ImportError:
+        if path.suffix == ".npz":
             arrays = {}
             for layer, (w, b) in zip(self.layers, weights):
                 arrays[layer.name + "/kernel"] = w
                 arrays[layer.name + "/bias"] = b
-            np.savez(str(path.with_suffix(".npz")), **arrays)
+            np.savez(str(path), **arrays)
             return
-        with h5py.File(str(path), "w") as f:
-            f.attrs["layer_names"] = [layer.name.encode("utf8") for layer in self.layers]
-            for layer, (w, b) in zip(self.layers, weights):
-                group = f.create_group(layer.name)
-                names = ["{}/kernel:0".format(layer.name), "{}/bias:0".format(layer.name)]
-                group.attrs["weight_names"] = [n.encode("utf8") for n in names]
-                group.create_dataset(names[0], data=w)
-                group.create_dataset(names[1], data=b)
+        from . import h5lite
+        h5lite.write_keras_weights(path, [(layer.name, [("{}/kernel:0".format(layer.name), w),
+                                                         ("{}/bias:0".format(layer.name), b)])
+                                          for layer, (w, b) in zip(self.layers, weights)])
 
     def load_weights(self, path):
-        """Loads the file that was asked for; only when it does not exist the `.npz` twin that save_weights writes on
-        machines without h5py is used instead (and that is logged)."""
+        """Loads a Keras HDF5 checkpoint of the reference (`weights-epoch{N}.h5` from `save_weights`, net.py:209-212, or a
+        full-model file whose tree sits under `model_weights`; Keras-1 weight names `<layer>_W` / `<layer>_b` and
+        (k, 1, Cin, Cout) kernels included), or the flat .npz form.  When the .h5 that was asked for does not exist but
+        its `.npz` twin does (files written by round-1/2 versions of this class), that one is used -- and logged."""
         path = Path(path)
         npz = path.with_suffix(".npz")
         if path.suffix == ".npz" or (not path.exists() and npz.exists()):
@@ -211,16 +209,23 @@ class PredictiveNet:
             data = np.load(str(npz))
             self.set_weights([(data[layer.name + "/kernel"], data[layer.name + "/bias"]) for layer in self.layers])
             return
-        import h5py  # Keras HDF5 checkpoint (weights-epoch{N}.h5)
-        with h5py.File(str(path), "r") as f:
-            root = f["model_weights"] if "model_weights" in f else f
-            weights = []
-            for layer in self.layers:
-                group = root[layer.name]
-                names = [n.decode("utf8") if isinstance(n, bytes) else n for n in group.attrs["weight_names"]]
-                kernel = np.asarray(group[[n for n in names if "kernel" in n][0]])
-                bias = np.asarray(group[[n for n in names if "bias" in n][0]])
-                weights.append((kernel, bias))
+        from . import h5lite
+        by_name = dict(h5lite.read_keras_weights(path))
+        weights = []
+        for layer in self.layers:
+            if layer.name not in by_name:
+                raise ValueError("{} holds no weights for layer {!r} (layers with weights: {})".format(
+                    path.name, layer.name, ", ".join(by_name)))
+            entry = by_name[layer.name]
+            kernel = [v for n, v in entry.items() if "kernel" in n or n.endswith("W:0") or n.endswith("_W")]
+            bias = [v for n, v in entry.items() if "bias" in n or n.endswith("b:0") or n.endswith("_b")]
+            if len(kernel) != 1 or len(bias) != 1:
+                raise ValueError("layer {!r} of {}: expected one kernel and one bias, found {}".format(
+                    layer.name, path.name, list(entry)))
+            w = np.asarray(kernel[0])
+            if w.ndim == 4:  # Keras-1 style conv kernels (k, 1, Cin, Cout)
+                w = w.reshape(w.shape[0], w.shape[2], w.shape[3])
+            weights.append((w, np.asarray(bias[0])))
         self.set_weights(weights)
 
 

@@ -287,20 +287,48 @@ def test_transfer_learning_with_frozen_layers_and_reinitialised_top(tmp_path):
         Wav2Letter(128, german_frequent_characters, frozen_layer_count=2)  # net.py:144-145
 
 
-def test_load_weights_prefers_the_requested_file(tmp_path):
-    """PredictiveNet.load_weights loads the path it is given and falls back to the .npz twin only when the requested
-    file does not exist."""
-    from speechless_amd import Wav2Letter, english_frequent_characters
+def test_keras_hdf5_checkpoints_in_class(tmp_path):
+    """PredictiveNet.save_weights / load_weights (net.py:209-212, 558-572) on real HDF5, in class, with no h5py in the
+    interpreter: the file written is HDF5 in Keras' layout (speechless_amd/h5lite.py; tests/test_h5lite.py has the real
+    library read it), it loads back bit for bit, the .npz twin of older versions is still found, and a missing file
+    raises."""
+    from speechless_amd import Wav2Letter, english_frequent_characters, h5lite
     a = Wav2Letter(128, english_frequent_characters, seed=1, layer_sizes=SMALL)
     b = Wav2Letter(128, english_frequent_characters, seed=2, layer_sizes=SMALL)
     a.predictive_net.save_weights(tmp_path / "weights-epoch1.h5")
-    saved = sorted(p.name for p in tmp_path.iterdir())
-    b.predictive_net.load_weights(tmp_path / "weights-epoch1.h5")  # h5py present: the .h5; absent: the .npz twin
-    assert saved in (["weights-epoch1.h5"], ["weights-epoch1.npz"])
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["weights-epoch1.h5"]
+    assert (tmp_path / "weights-epoch1.h5").read_bytes()[:8] == h5lite.SIGNATURE
+    tree = h5lite.read(tmp_path / "weights-epoch1.h5")
+    assert tree.attrs["layer_names"] == [layer.name for layer in a.predictive_net.layers]
+    assert tree["big_conv_1"].attrs["weight_names"] == ["big_conv_1/kernel:0", "big_conv_1/bias:0"]
+    b.predictive_net.load_weights(tmp_path / "weights-epoch1.h5")
     for (w1, b1), (w2, b2) in zip(a.predictive_net.get_weights(), b.predictive_net.get_weights()):
         assert np.array_equal(w1, w2) and np.array_equal(b1, b2)
-    with pytest.raises((OSError, ImportError)):
+    # the .npz twin (what rounds 1-2 wrote where h5py was missing) is used when the .h5 asked for does not exist
+    a.predictive_net.save_weights(tmp_path / "weights-epoch5.npz")
+    c = Wav2Letter(128, english_frequent_characters, seed=3, layer_sizes=SMALL)
+    c.predictive_net.load_weights(tmp_path / "weights-epoch5.h5")
+    for (w1, _), (w2, _) in zip(a.predictive_net.get_weights(), c.predictive_net.get_weights()):
+        assert np.array_equal(w1, w2)
+    with pytest.raises(OSError):
         b.predictive_net.load_weights(tmp_path / "weights-epoch2.h5")
+
+
+def test_keras_written_checkpoint_loads_into_the_engine():
+    """A file the REAL HDF5 library wrote in Keras 2.0's save_weights() layout -- Dropout / Lambda groups without weights
+    included -- and its model.save() variant (tree under `model_weights`), both committed under tests/golden/
+    (make_keras_h5_fixture.py), loaded through PredictiveNet.load_weights into an engine of the fixture's toy topology."""
+    from speechless_amd import Wav2Letter
+    golden = Path(__file__).resolve().parent / "golden"
+    expected = np.load(str(golden / "keras_h5_expected.npz"))
+    for name in ("keras_weights_toy.h5", "keras_model_toy.h5"):
+        net = Wav2Letter(4, "abcd", seed=0, layer_sizes=TOY_SIZES, compute_dtype="f32")
+        net.predictive_net.load_weights(golden / name)
+        for layer, (w, b) in zip(net.predictive_net.layers, net.predictive_net.get_weights()):
+            assert np.array_equal(w, expected[layer.name + "/kernel"]) and np.array_equal(b, expected[layer.name + "/bias"])
+    with pytest.raises(ValueError, match="holds no weights for layer"):
+        Wav2Letter(4, "abcd", seed=0, layer_sizes=dict(TOY_SIZES, inner_count=3),
+                   compute_dtype="f32").predictive_net.load_weights(golden / "keras_weights_toy.h5")
 
 
 # ------------------------------------------------------------------------------------------ BatchNorm fold (a12)

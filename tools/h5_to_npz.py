@@ -1,39 +1,34 @@
 #!/usr/bin/env python
 """Converts a Keras HDF5 weight file of the reference (`weights-epoch{N}.h5`, written by `predictive_net.save_weights`,
-speechless/net.py:572; e.g. the published checkpoints linked from the reference README) into the `.npz` that
-`speechless_amd.net.PredictiveNet.load_weights` reads when `h5py` is not importable next to torch.
+speechless/net.py:572; e.g. the published checkpoints linked from the reference README) into the flat `.npz` form
+(`<layer name>/kernel` (k, Cin, Cout), `<layer name>/bias`) and back.  Since round 3 `PredictiveNet.load_weights` reads the
+.h5 itself (speechless_amd/h5lite.py); this tool remains for inspecting checkpoints with plain numpy.  numpy only.
 
-Needs only numpy + h5py, so it runs under any interpreter that has them (in this image: /opt/conda/bin/python3.9):
-
-    /opt/conda/bin/python3.9 tools/h5_to_npz.py weights-epoch1234.h5 [out.npz]
-    /opt/conda/bin/python3.9 tools/h5_to_npz.py --reverse weights-epoch1234.npz out.h5     # back to the Keras layout
-
-The .npz holds `<layer name>/kernel` (k, Cin, Cout) and `<layer name>/bias` per layer, in the layer order of the file.
+    python tools/h5_to_npz.py weights-epoch1234.h5 [out.npz]
+    python tools/h5_to_npz.py --reverse weights-epoch1234.npz out.h5     # back to the Keras layout
 """
+import importlib.util
 import sys
+from pathlib import Path
 
-import h5py
 import numpy as np
+
+_spec = importlib.util.spec_from_file_location(
+    "h5lite", str(Path(__file__).resolve().parent.parent / "speechless_amd" / "h5lite.py"))  # (no package import: no torch)
+h5lite = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(h5lite)
 
 
 def h5_to_npz(src, dst):
     arrays = {}
-    with h5py.File(src, "r") as f:
-        root = f["model_weights"] if "model_weights" in f else f
-        names = root.attrs.get("layer_names")
-        names = [n.decode("utf8") if isinstance(n, bytes) else n for n in names] if names is not None else list(root)
-        for name in names:
-            group = root[name]
-            weight_names = [n.decode("utf8") if isinstance(n, bytes) else n for n in group.attrs.get("weight_names", [])]
-            if not weight_names:  # Dropout / Lambda layers carry no weights
-                continue
-            kernel = [n for n in weight_names if "kernel" in n or n.endswith("W:0") or n.endswith("_W")]
-            bias = [n for n in weight_names if "bias" in n or n.endswith("b:0") or n.endswith("_b")]
-            w = np.asarray(group[kernel[0]])
-            if w.ndim == 4:  # Keras-1 style conv kernels (k, 1, Cin, Cout)
-                w = w.reshape(w.shape[0], w.shape[2], w.shape[3])
-            arrays[name + "/kernel"] = w
-            arrays[name + "/bias"] = np.asarray(group[bias[0]])
+    for name, weights in h5lite.read_keras_weights(src):
+        kernel = [v for n, v in weights.items() if "kernel" in n or n.endswith("W:0") or n.endswith("_W")]
+        bias = [v for n, v in weights.items() if "bias" in n or n.endswith("b:0") or n.endswith("_b")]
+        w = np.asarray(kernel[0])
+        if w.ndim == 4:  # Keras-1 style conv kernels (k, 1, Cin, Cout)
+            w = w.reshape(w.shape[0], w.shape[2], w.shape[3])
+        arrays[name + "/kernel"] = w
+        arrays[name + "/bias"] = np.asarray(bias[0])
     np.savez(dst, **arrays)
     return sorted(arrays)
 
@@ -45,14 +40,8 @@ def npz_to_h5(src, dst):
         name = key.rsplit("/", 1)[0]
         if name not in layers:
             layers.append(name)
-    with h5py.File(dst, "w") as f:
-        f.attrs["layer_names"] = [n.encode("utf8") for n in layers]
-        for name in layers:
-            group = f.create_group(name)
-            names = ["{}/kernel:0".format(name), "{}/bias:0".format(name)]
-            group.attrs["weight_names"] = [n.encode("utf8") for n in names]
-            group.create_dataset(names[0], data=data[name + "/kernel"])
-            group.create_dataset(names[1], data=data[name + "/bias"])
+    h5lite.write_keras_weights(dst, [(name, [("{}/kernel:0".format(name), data[name + "/kernel"]),
+                                             ("{}/bias:0".format(name), data[name + "/bias"])]) for name in layers])
     return layers
 
 
