@@ -150,7 +150,7 @@ def parity_object(specs, weights, names, cpu_first, device):
     ref_decoded = o.greedy_decode_indices(cpu_first["probs"], pred_len)
     out = {"checker": "first CPU step of the cpu_baseline leg (torch-CPU fp32, oracle/w2l_torch_cpu.py): the GPU step's own "
                       "batch of {} x {} frames from the same initial weights".format(BATCH_PER_GPU, FRAMES)}
-    for dtype in ("bf16", "f32"):
+    for dtype in ("bf16", "bf16x3", "f32"):
         g = gpu_first_step(specs, weights, dtype, device)
         leg = {"loss_rel_max": float(np.max(np.abs(g["losses"] - ref_losses) / np.abs(ref_losses))),
                "grad_rel_l2": {n: _rel_l2(gw, rw) for n, (gw, _), (rw, _) in zip(names, g["grads"], cpu_first["grads"])},
@@ -168,7 +168,9 @@ def parity_object(specs, weights, names, cpu_first, device):
         out[dtype] = leg
     out["note"] = ("bf16 = the benchmarked path (bf16 storage, fp32 accumulate): the loss meets north_star's 1e-3, its "
                    "gradients carry the ReLU sign flips of bf16-rounded activations (DESIGN.md section 1); f32 = the "
-                   "parity path (exact-fp32 MFMA), the one held to bit-exact decode and 1e-3 gradients")
+                   "parity path (exact-fp32 MFMA), the one held to bit-exact decode and 1e-3 gradients; bf16x3 = the fast "
+                   "parity path (hi + lo bf16 planes, three bf16 MFMA terms per product: 2.9x the f32 path's training rate, "
+                   "2.7x its forward rate)")
     return out
 
 
@@ -298,11 +300,12 @@ class Bench:
         eng.kernel_timeline = None
         return {tag: float(np.mean(v)) for tag, v in per_tag.items()}
 
-    def bf16_forward_leg(self, f32_out):
-        """config 2: the bf16 path timed beside the fp32 one, its disagreements with it counted"""
+    def other_forward_leg(self, dtype):
+        """config 2: another storage scheme timed beside the fp32 path, its disagreements with it counted.  bf16 = the
+        training path's storage; bf16x3 = hi + lo planes, three bf16 MFMA terms per product (the fast parity path)."""
         from speechless_amd.engine import Engine
         torch = self.torch
-        eng16 = Engine(self.specs, K_CLASSES, dtype="bf16", device=self.device)
+        eng16 = Engine(self.specs, K_CLASSES, dtype=dtype, device=self.device)
         eng16.set_weights(self.weights)
         eng16.load_input(torch.from_numpy(self.x).to(self.device))
         eng16.set_input_lengths(self.pred_len)
@@ -314,14 +317,18 @@ class Bench:
         el16, out16 = self.timed(self.args_steps, self.args_warmup, step16)
         decoded32, argmax32 = self.eng.greedy_decode()
         decoded16, argmax16 = out16
-        return {"dtype": "bf16", "value": self.batch_per_gpu * self.world * self.args_steps / el16, "unit": "utterances/sec",
+        notes = {"bf16": "bf16 storage is NOT bit-exact against the fp32 CPU path at random init (near-flat softmax): "
+                         "the headline value above is the fp32 path, whose decoded indices are "
+                         "(tests/test_gpu_round2.py::test_config2_greedy_decode_bit_exact_at_batch_32)",
+                 "bf16x3": "every value as hi + lo bf16 planes, three bf16 MFMA terms per product, fp32 accumulate "
+                           "(speechless_amd/csrc/split3.hip): decoded indices bit-exact against the torch-CPU fp32 path "
+                           "(tests/test_gpu_round3.py::test_bf16x3_config2_greedy_decode_bit_exact_at_batch_32)"}
+        del eng16
+        return {"dtype": dtype, "value": self.batch_per_gpu * self.world * self.args_steps / el16, "unit": "utterances/sec",
                 "ms_per_step": el16 / self.args_steps * 1e3,
                 "mismatching_frames_vs_f32": int((argmax16 != argmax32).sum()), "frames": int(argmax32.size),
                 "mismatching_sequences_vs_f32": int(sum(a != b for a, b in zip(decoded16, decoded32))),
-                "sequences": len(decoded32),
-                "note": "bf16 storage is NOT bit-exact against the fp32 CPU path at random init (near-flat softmax): "
-                        "the headline value above is the fp32 path, whose decoded indices are "
-                        "(tests/test_gpu_round2.py::test_config2_greedy_decode_bit_exact_at_batch_32)"}
+                "sequences": len(decoded32), "note": notes[dtype]}
 
     def run(self, steps, warmup):
         """Times the configuration and assembles its part of the JSON line (every rank runs it; rank 0 keeps it)."""
@@ -336,7 +343,8 @@ class Bench:
             "step_mfma_frac": self.flops_per_step * world * steps / elapsed / 1e12 / (self.peak * world),
         }
         if config == 2:
-            result["bf16_path"] = self.bf16_forward_leg(out)
+            result["bf16x3_path"] = self.other_forward_leg("bf16x3")
+            result["bf16_path"] = self.other_forward_leg("bf16")
         self.elapsed = elapsed
         return result
 

@@ -303,6 +303,35 @@ int sl_adam_pack_layer(float* param, const float* grad, float* m, float* v, void
                        int cin_pad, int cout_pad, int dtype, int step, float lr, float beta1, float beta2, float eps,
                        void* stream);
 
+/* ---- "bf16x3": the fast parity path ---------------------------------------------------------------------------------------
+ * north_star: greedy-decoded indices bit-exact against the reference's fp32 CPU path (net.py:417-436 on Keras / TF float32),
+ * gradients within 1e-3.  Every fp32 value is carried as two bf16 numbers (hi = bf16(v), lo = bf16(v - hi)) in THREE planes
+ * per tensor row, [hi | lo | hi] (3 x channels), against packed weight rows [w_hi | w_hi | w_lo]: the unchanged
+ * sl_conv1d_nt over 3 x channels then computes x_hi w_hi + x_lo w_hi + x_hi w_lo in fp32 (out_f32 into a staging buffer),
+ * and these HBM-bound helpers move between the fp32 staging form and the planes.  See csrc/split3.hip.
+ *   sl_split3            fp32 [B][src rows][channels] (valid rows t < t_out) -> planes [B][rows][3 * channels] at row
+ *                        dst_row0 + t.  mode 0: copy; 1: relu; 2: elu (Conv1D activations, net.py:304); 3 / 4: multiply by the
+ *                        ReLU / ELU derivative taken from `mask`, the stored activation in plane form (autodiff, net.py:389)
+ *   sl_split3_pack_input float[B][t_in][f] -> planes, channels >= f zero (net.py:578-587)
+ *   sl_split3_weights    v -> (float(hi), v - float(hi)): sl_pack_weights of the two arrays yields the hi and lo operands
+ *   sl_split3_assemble   rows of `width` bf16: dst[r] = [a[r] | a[r] | b[r]]
+ *   sl_split3_wgrad_combine  RA = sl_conv1d_wgrad of (x planes [hi | lo ...], g_hi), RB = of (x planes [hi ...], g_lo), float
+ *                        [taps / frames][r*_cin][c_out] -> dw[tap][ci][co] = hh + hl + lh;  frames = 2, fstride = 3 * c_in for
+ *                        the pair view of a stride-2 layer (two frames' planes per row)
+ *   sl_split3_bias_grad  db[co] = sum over valid frames of g_hi + g_lo (two stages, fixed order; workspace from
+ *                        sl_split3_bias_grad_workspace_bytes) */
+int sl_split3(const float* src, void* dst, const void* mask, int batch, int t_out, int channels, int64_t src_batch_stride,
+              int dst_row0, int64_t dst_batch_stride, int mode, void* stream);
+int sl_split3_pack_input(const float* src, void* dst, int batch, int t_in, int f, int channels, int dst_row0,
+                         int64_t dst_batch_stride, void* stream);
+int sl_split3_weights(const float* v, float* hi, float* lo, size_t n, void* stream);
+int sl_split3_assemble(const void* a, const void* b, void* dst, int64_t rows, int width, void* stream);
+int sl_split3_wgrad_combine(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out, int frames,
+                            int fstride, int ra_cin, int rb_cin, void* stream);
+size_t sl_split3_bias_grad_workspace_bytes(int channels);
+int sl_split3_bias_grad(const void* g, float* db, int batch, int t_out, int channels, int g_row0, int64_t g_batch_stride,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- audio front end (speechless/labeled_example.py:99-160, 28-29) ---------------------------
  * sl_stft_power_db: librosa.stft(y, n_fft, hop_length) with its defaults (periodic Hann window of n_fft samples,
  * center=True with reflect padding of n_fft/2, 1 + len/hop frames, 1 + n_fft/2 bins; labeled_example.py:99-100), then

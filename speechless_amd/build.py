@@ -12,7 +12,7 @@ HOST_LIB_PATH = PACKAGE_DIR / "libspeechless_host.so"  # plain C++ helpers of th
 HOST_SOURCES = [PACKAGE_DIR / "csrc_host" / "pack_batch.cpp", PACKAGE_DIR / "csrc_host" / "beam_search.cpp"]
 CXX = os.environ.get("CXX", "g++")
 SOURCES = ["capi.hip", "conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_f32.hip", "ctc.hip", "misc.hip", "spectrogram.hip", "conv_chain_bf16.hip",
-           "conv1x1_bwd_bf16.hip"]
+           "conv1x1_bwd_bf16.hip", "split3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("SL_EXTRA_FLAGS", "").split()  # experiments only (e.g. -DSL_NT_SETPRIO); the default build has none

@@ -96,13 +96,14 @@ class _Buffers:
         dev = eng.device
         dt = eng.torch_dtype
         p0 = eng.plans[0]
+        pl = eng.planes  # 3 on the bf16x3 path: every tensor row holds the planes [hi | lo | hi] (csrc/split3.hip)
         self.batch = batch
         self.tt_pad = tt_pad
         self.t_in = None
         self.t_out = None
         self.rows = HALO + self.tt_pad + HALO
         self.rows0 = 2 * (self.tt_pad + p0.taps_view)
-        self.x0 = torch.zeros((batch, self.rows0, p0.cin_pad), dtype=dt, device=dev)
+        self.x0 = torch.zeros((batch, self.rows0, p0.cin_pad * pl), dtype=dt, device=dev)
         self.x0_dropped = None  # dropout(x0), allocated by the first training forward with dropout
         self.dropped = False    # the activations of the last forward are post-dropout
         n = len(eng.plans)
@@ -111,13 +112,13 @@ class _Buffers:
         # a run of identical layers (the seven inner_conv_i) keeps its inputs y[s-1..e-1] in ONE allocation so that
         # the grouped weight-gradient launch can address layer q as base + q*stride
         for (s0, e0) in eng.runs:
-            block = torch.zeros((e0 - s0 + 1, batch, self.rows, eng.plans[s0].cin_pad), dtype=dt, device=dev)
+            block = torch.zeros((e0 - s0 + 1, batch, self.rows, eng.plans[s0].cin_pad * pl), dtype=dt, device=dev)
             self._blocks.append(block)
             for q in range(e0 - s0 + 1):
                 self.y[s0 - 1 + q] = block[q]
         for p in eng.plans[:-1]:
             if self.y[p.index] is None:
-                self.y[p.index] = torch.zeros((batch, self.rows, p.cout_pad), dtype=dt, device=dev)
+                self.y[p.index] = torch.zeros((batch, self.rows, p.cout_pad * pl), dtype=dt, device=dev)
                 self._blocks.append(self.y[p.index].unsqueeze(0))
         self.logits = torch.zeros((batch, self.tt_pad, eng.plans[-1].cout_pad), dtype=torch.float32, device=dev)
         k = eng.grapheme_set_size
@@ -136,17 +137,17 @@ class _Buffers:
             g.batch = batch
             g.t_out = self.tt_pad
             g.taps = p.taps_view
-            g.cin = p.cin_view
+            g.cin = p.cin_view * pl
             g.cout = p.cout_pad
             if p.index == 0:
                 g.x_row0 = 0
-                g.x_row_stride = p.cin_view
-                g.x_batch_stride = self.rows0 * p.cin_pad
+                g.x_row_stride = p.cin_view * pl
+                g.x_batch_stride = self.rows0 * p.cin_pad * pl
             else:
                 g.x_row0 = HALO - p.pad_left
-                g.x_row_stride = p.cin_pad
-                g.x_batch_stride = self.rows * p.cin_pad
-            if p.index == n - 1:
+                g.x_row_stride = p.cin_pad * pl
+                g.x_batch_stride = self.rows * p.cin_pad * pl
+            if p.index == n - 1 or pl > 1:  # fp32 out: the logits -- and on the bf16x3 path every layer's staging buffer
                 g.y_row0 = 0
                 g.y_row_stride = p.cout_pad
                 g.y_batch_stride = self.tt_pad * p.cout_pad
@@ -155,6 +156,11 @@ class _Buffers:
                 g.y_row_stride = p.cout_pad
                 g.y_batch_stride = self.rows * p.cout_pad
             self.fwd_geom.append(g)
+        # bf16x3: fp32 staging buffer of a layer's pre-activations / input gradients (sl_conv1d_nt out_f32 -> sl_split3)
+        self.stage32 = torch.empty((batch * self.tt_pad * max(p.cout_pad for p in eng.plans),), dtype=torch.float32,
+                                   device=dev) if pl > 1 else None
+        self.wgrad_r = None  # bf16x3: the two partial weight gradients (RA | RB) in front of sl_split3_wgrad_combine
+        self.wgrad_geom_b = [None] * n
         self.wgrad_geom = [None] * n
         self.dgrad_geom = [None] * n
         self.bwd_ready = False
@@ -218,35 +224,52 @@ class _Buffers:
         for (s0, e0) in eng.runs:  # gradients g[s..e] of a run of identical layers: one allocation (grouped wgrad)
             lo = max(s0, first)
             if e0 >= lo:
-                block = torch.zeros((e0 - lo + 1, self.batch, self.rows, eng.plans[lo].cout_pad), dtype=dt, device=dev)
+                block = torch.zeros((e0 - lo + 1, self.batch, self.rows, eng.plans[lo].cout_pad * eng.planes), dtype=dt,
+                                    device=dev)
                 self._blocks.append(block)
                 for q in range(e0 - lo + 1):
                     self.g[lo + q] = block[q]
         for p in eng.plans[first:]:
             if self.g[p.index] is None:
-                self.g[p.index] = torch.zeros((self.batch, self.rows, p.cout_pad), dtype=dt, device=dev)
+                self.g[p.index] = torch.zeros((self.batch, self.rows, p.cout_pad * eng.planes), dtype=dt, device=dev)
                 self._blocks.append(self.g[p.index].unsqueeze(0))
+            pl = eng.planes
             wg = ConvGeom()
             f = self.fwd_geom[p.index]
             for name, _ in ConvGeom._fields_:
                 setattr(wg, name, getattr(f, name))
             wg.y_row0 = HALO
-            wg.y_row_stride = p.cout_pad
-            wg.y_batch_stride = self.rows * p.cout_pad
+            wg.y_row_stride = p.cout_pad * pl
+            wg.y_batch_stride = self.rows * p.cout_pad * pl
             self.wgrad_geom[p.index] = wg
+            if pl > 1:
+                # bf16x3: two launches.  A: the [hi | lo] prefix of x against g_hi (hh and lh in one (2 Cin) x Cout product),
+                # B: x_hi against g_lo (hl); sl_split3_wgrad_combine adds the three blocks.  The pair view of the striding
+                # layer has the planes of two frames in a row, so there the whole row is the x operand of both.
+                wb = ConvGeom()
+                for name, _ in ConvGeom._fields_:
+                    setattr(wb, name, getattr(wg, name))
+                wg.cin = p.cin_view * pl if p.index == 0 else 2 * p.cin_pad
+                wb.cin = p.cin_view * pl if p.index == 0 else p.cin_pad
+                self.wgrad_geom_b[p.index] = wb
             if p.index > first:
                 dg = ConvGeom()
                 dg.batch = self.batch
                 dg.t_out = self.t_out
                 dg.taps = p.spec.kernel_size
-                dg.cin = p.cout_pad
+                dg.cin = p.cout_pad * pl
                 dg.cout = p.cin_pad
                 dg.x_row0 = HALO - p.pad_right
-                dg.x_row_stride = p.cout_pad
-                dg.x_batch_stride = self.rows * p.cout_pad
-                dg.y_row0 = HALO
-                dg.y_row_stride = p.cin_pad
-                dg.y_batch_stride = self.rows * p.cin_pad
+                dg.x_row_stride = p.cout_pad * pl
+                dg.x_batch_stride = self.rows * p.cout_pad * pl
+                if pl > 1:  # fp32 into the staging buffer, sl_split3 applies the mask and writes the planes
+                    dg.y_row0 = 0
+                    dg.y_row_stride = p.cin_pad
+                    dg.y_batch_stride = self.tt_pad * p.cin_pad
+                else:
+                    dg.y_row0 = HALO
+                    dg.y_row_stride = p.cin_pad
+                    dg.y_batch_stride = self.rows * p.cin_pad
                 self.dgrad_geom[p.index] = dg
         self.bias_ws = None
         self.bwd1x1_ws = None
@@ -268,6 +291,14 @@ class _Buffers:
                 ctypes.byref(wg), eng.dtype_code, eng.nt_cfg.get(("wgrad", p.spec.name), 0)))
             bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
         self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
+        if eng.planes > 1:
+            need = max(p.taps_view * (self.wgrad_geom[p.index].cin + self.wgrad_geom_b[p.index].cin) * p.cout_pad
+                       for p in eng.plans[first:])
+            if self.wgrad_r is None or self.wgrad_r.numel() < need:
+                self.wgrad_r = torch.empty((need,), dtype=torch.float32, device=eng.device)
+            for p in eng.plans[first:]:
+                ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
+                    ctypes.byref(self.wgrad_geom_b[p.index]), eng.dtype_code, 0))
         if eng.dtype == "bf16":
             for (s0, e0) in eng.runs:
                 lo = max(s0, first)
@@ -300,8 +331,9 @@ class _Buffers:
 
 
 class Engine:
-    """Forward / CTC / backward / Adam on one MI355X.  dtype 'bf16' (bf16 storage, fp32 accumulate, fp32 CTC) or
-    'f32' (parity path)."""
+    """Forward / CTC / backward / Adam on one MI355X.  dtype 'bf16' (bf16 storage, fp32 accumulate, fp32 CTC: the
+    benchmarked path), 'f32' (parity path: fp32 storage, exact-fp32 MFMA) or 'bf16x3' (the fast parity path: every value as
+    hi + lo bf16 planes, three bf16 MFMA terms per product, fp32 accumulate; csrc/split3.hip)."""
 
     def __init__(self, specs, grapheme_set_size, dtype="bf16", device="cuda:0", ctc_epsilon=1e-8,
                  frozen_layer_count=0, lr=1e-4, beta_1=0.9, beta_2=0.999, adam_epsilon=1e-8):
@@ -311,12 +343,15 @@ class Engine:
         self.lib = lib()
         self.device = torch.device(device)
         self.dtype = dtype
+        self.planes = 1
         if dtype == "bf16":
             self.torch_dtype, self.dtype_code = torch.bfloat16, _lib.SL_BF16
         elif dtype == "f32":
             self.torch_dtype, self.dtype_code = torch.float32, _lib.SL_F32
+        elif dtype == "bf16x3":
+            self.torch_dtype, self.dtype_code, self.planes = torch.bfloat16, _lib.SL_BF16, 3
         else:
-            raise ValueError("dtype must be 'bf16' or 'f32'")
+            raise ValueError("dtype must be 'bf16', 'f32' or 'bf16x3'")
         self.specs = specs
         self.grapheme_set_size = grapheme_set_size
         self.ctc_epsilon = ctc_epsilon
@@ -364,9 +399,10 @@ class Engine:
         self.grads = torch.zeros((off,), dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros((off,), dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros((off,), dtype=torch.float32, device=dev)
-        self.w_fwd = [torch.zeros((p.cout_pad, p.spec.kernel_size, p.cin_pad), dtype=self.torch_dtype, device=dev)
+        pl = self.planes  # bf16x3: packed weight rows are [w_hi | w_hi | w_lo]
+        self.w_fwd = [torch.zeros((p.cout_pad, p.spec.kernel_size, p.cin_pad * pl), dtype=self.torch_dtype, device=dev)
                       for p in self.plans]
-        self.w_dgrad = [torch.zeros((p.cin_pad, p.spec.kernel_size, p.cout_pad), dtype=self.torch_dtype, device=dev)
+        self.w_dgrad = [torch.zeros((p.cin_pad, p.spec.kernel_size, p.cout_pad * pl), dtype=self.torch_dtype, device=dev)
                         if p.index > 0 else None for p in self.plans]
         self._packed_dirty = True
         self._buffers = {}
@@ -402,6 +438,11 @@ class Engine:
         # DESIGN.md section 3.1).  SL_CHAIN=0 restores the single launches (A/B measurements).
         self.use_chain = os.environ.get("SL_CHAIN", "1") == "1"
         self.use_launch_lists = os.environ.get("SL_LAUNCH_LISTS", "1") != "0"
+        if self.planes > 1:  # the fused launches read and write single-plane bf16 tensors
+            self.use_chain = self.fuse_output_softmax = self.fuse_output_backward = self.group_wgrad = False
+            self.use_launch_lists = False
+            self._x3_tmp = None
+            self._x3_bias_ws = None
         self._rec = None
         self._adam_tables = {}
 
@@ -595,7 +636,35 @@ class Engine:
         self.adam_iterations = int(state["iterations"])
         self._dropout_steps = int(state.get("dropout_steps", 0))
 
+    def _repack_weights_x3(self):
+        """bf16x3 operand copies: masters -> (float(hi), v - float(hi)) -> sl_pack_weights of each (its own rounding yields
+        hi and lo exactly) -> rows [w_hi | w_hi | w_lo] in both operand layouts."""
+        st = self._stream()
+        n_max = max(p.w_numel for p in self.plans)
+        if self._x3_tmp is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            b16 = dict(dtype=torch.bfloat16, device=self.device)
+            self._x3_tmp = (torch.empty((n_max,), **f32), torch.empty((n_max,), **f32),
+                            [torch.empty((n_max,), **b16) for _ in range(4)])
+        hi32, lo32, (fh, fl, dh, dl) = self._x3_tmp
+        for p in self.plans:
+            wv, _ = self.layer_param_views(self.params, p)
+            k, wd = p.spec.kernel_size, self.w_dgrad[p.index]
+            self._launch("split:" + p.spec.name, "sl_split3_weights", wv.data_ptr(), hi32.data_ptr(), lo32.data_ptr(),
+                         p.w_numel, st)
+            for src, (f, d) in ((hi32, (fh, dh)), (lo32, (fl, dl))):
+                self._launch("pack:" + p.spec.name, "sl_pack_weights", src.data_ptr(), f.data_ptr(),
+                             d.data_ptr() if wd is not None else None, k, p.cin_pad, p.cout_pad, self.dtype_code, st)
+            self._launch("assemble:" + p.spec.name, "sl_split3_assemble", fh.data_ptr(), fl.data_ptr(),
+                         self.w_fwd[p.index].data_ptr(), p.cout_pad * k, p.cin_pad, st)
+            if wd is not None:
+                self._launch("assemble:" + p.spec.name, "sl_split3_assemble", dh.data_ptr(), dl.data_ptr(), wd.data_ptr(),
+                             p.cin_pad * k, p.cout_pad, st)
+        self._packed_dirty = False
+
     def repack_weights(self):
+        if self.planes > 1:
+            return self._repack_weights_x3()
         st = self._stream()
         for p in self.plans:
             wv, _ = self.layer_param_views(self.params, p)
@@ -619,6 +688,12 @@ class Engine:
             raise ValueError("input has {} bins per frame, the net expects {}".format(f, self.specs[0].cin))
         buf = self.buffers(batch, t_in)
         p0 = self.plans[0]
+        if self.planes > 1:
+            self._launch("pack_input", "sl_split3_pack_input", src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.cin_pad,
+                         p0.pad_left, buf.rows0 * p0.cin_pad * self.planes, self._stream())
+            self.cur = buf
+            self._src_keepalive = src
+            return buf
         self._launch("pack_input", "sl_pack_input", src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.pad_left, p0.cin_pad,
                       buf.rows0 * p0.cin_pad, self.dtype_code, self._stream())
         self.cur = buf
@@ -693,7 +768,34 @@ class Engine:
         finally:
             self._rec = None
 
+    def _forward_x3(self, buf, st):
+        """bf16x3: every layer = the unchanged NT kernel over the three planes (fp32 into the staging buffer) + sl_split3
+        (activation, back to planes); the last layer's fp32 logits go to the softmax as on the other paths."""
+        n = len(self.plans)
+        x = buf.x0
+        for p in self.plans:
+            last = p.index == n - 1
+            _, bias = self.layer_param_views(self.params, p)
+            out = buf.logits if last else buf.stage32
+            self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(),
+                         None, out.data_ptr(), ctypes.byref(buf.fwd_geom[p.index]), _lib.EPI_BIAS, self.dtype_code, 1,
+                         self.nt_cfg.get(("fwd", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+            if not last:
+                y = buf.y[p.index]
+                self._launch("split:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), y.data_ptr(), None, buf.batch,
+                             buf.t_out, p.cout_pad, buf.tt_pad * p.cout_pad, HALO, buf.rows * p.cout_pad * self.planes,
+                             2 if p.spec.activation == "elu" else 1, st)
+                x = y
+        self._launch("softmax", "sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
+                     buf.t_out, self.grapheme_set_size, self.plans[-1].cout_pad, buf.tt_pad * self.plans[-1].cout_pad,
+                     self.ctc_epsilon, st)
+        return buf.probs
+
     def _forward_eager(self, buf, rate, fuse_out, st):
+        if self.planes > 1:
+            if rate:
+                raise NotImplementedError("dropout is not implemented on the bf16x3 path")
+            return self._forward_x3(buf, st)
         n = len(self.plans)
         x = buf.x0
         if rate:
@@ -813,6 +915,16 @@ class Engine:
         if grad_scale is None:
             grad_scale = 1.0 / buf.batch
         l_max = buf.labels.shape[1]
+        if self.planes > 1:  # fp32 dL/dlogits into the staging buffer, then into the planes of g[last]
+            cp = self.plans[last].cout_pad
+            buf.stage32[:buf.batch * buf.tt_pad * cp].zero_()  # (padded classes: the CTC kernel writes the k real ones)
+            self._launch("ctc", "sl_ctc_loss_grad", buf.probs.data_ptr(), buf.logq.data_ptr(), buf.labels.data_ptr(),
+                         buf.label_len.data_ptr(), buf.input_len.data_ptr(), buf.loss.data_ptr(), buf.stage32.data_ptr(),
+                         buf.batch, buf.t_out, self.grapheme_set_size, l_max, 0, cp, buf.tt_pad * cp, _lib.SL_F32,
+                         self.ctc_epsilon, grad_scale, buf.ctc_ws.data_ptr(), buf.ctc_ws.numel(), self._stream())
+            self._launch("split:ctc", "sl_split3", buf.stage32.data_ptr(), buf.g[last].data_ptr(), None, buf.batch, buf.t_out,
+                         cp, buf.tt_pad * cp, HALO, buf.rows * cp * self.planes, 0, self._stream())
+            return buf.loss
         self._launch("ctc", "sl_ctc_loss_grad", buf.probs.data_ptr(), buf.logq.data_ptr(), buf.labels.data_ptr(),
                       buf.label_len.data_ptr(), buf.input_len.data_ptr(), buf.loss.data_ptr(), buf.g[last].data_ptr(),
                       buf.batch, buf.t_out, self.grapheme_set_size, l_max, HALO, self.plans[last].cout_pad,
@@ -949,7 +1061,52 @@ class Engine:
             self._launch("dropout_scale:" + p.spec.name, "sl_scale", buf.g[i - 1].data_ptr(), buf.g[i - 1].numel(),
                          self.dtype_code, 1.0 / (1.0 - self.dropout_rate), st)
 
+    def _backward_x3(self, buf, st):
+        """bf16x3 backward: per layer the weight gradient of the [hi | lo] prefixes + sl_split3_wgrad_combine, the input
+        gradient through the unchanged NT kernel (fp32 staging) + sl_split3 with the activation mask.  Bias gradients:
+        row cin_pad - 1 of dW where the input carries the ones channel (hi = 1, lo = 0), sl_split3_bias_grad elsewhere."""
+        first = self.frozen_layer_count
+        pl = self.planes
+        ones_in = self._ones_input_layers(first)
+        for p in reversed(self.plans[first:]):
+            i = p.index
+            x = buf.x0 if i == 0 else buf.y[i - 1]
+            dw, db = self.layer_param_views(self.grads, p)
+            wa, wb = buf.wgrad_geom[i], buf.wgrad_geom_b[i]
+            ra = buf.wgrad_r
+            rb = buf.wgrad_r[p.taps_view * wa.cin * p.cout_pad:]
+            g_lo = buf.g[i].data_ptr() + p.cout_pad * 2  # plane P1 of every row
+            cfg = self.nt_cfg.get(("wgrad", p.spec.name), 0)
+            self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), ra.data_ptr(),
+                         ctypes.byref(wa), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+            self._launch("wgrad_lo:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), g_lo, rb.data_ptr(),
+                         ctypes.byref(wb), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+            frames = 2 if p.spec.stride == 2 else 1
+            self._launch("combine:" + p.spec.name, "sl_split3_wgrad_combine", ra.data_ptr(), rb.data_ptr(), dw.data_ptr(),
+                         p.spec.kernel_size, p.cin_pad, p.cout_pad, frames, pl * p.cin_pad if frames == 2 else 0, wa.cin,
+                         wb.cin, st)
+            if i not in ones_in:
+                if self._x3_bias_ws is None:
+                    self._x3_bias_ws = torch.empty((self.lib.raw("sl_split3_bias_grad_workspace_bytes")(
+                        max(q.cout_pad for q in self.plans)),), dtype=torch.uint8, device=self.device)
+                self._launch("bgrad:" + p.spec.name, "sl_split3_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), buf.batch,
+                             buf.t_out, p.cout_pad, HALO, buf.rows * p.cout_pad * pl, self._x3_bias_ws.data_ptr(),
+                             self._x3_bias_ws.numel(), st)
+            if i > first:
+                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
+                             None, buf.stage32.data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_NONE, self.dtype_code, 1,
+                             self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+                self._launch("split:dgrad:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
+                             buf.y[i - 1].data_ptr(), buf.batch, buf.t_out, p.cin_pad, buf.tt_pad * p.cin_pad, HALO,
+                             buf.rows * p.cin_pad * pl, 4 if self.specs[i - 1].activation == "elu" else 3, st)
+        if ones_in:
+            self._bias_grads_from_wgrad(ones_in, True, torch.cuda.current_stream(self.device))
+
     def _backward_eager(self, buf, main, side, on_bucket_ready):
+        if self.planes > 1:
+            if on_bucket_ready is not None or buf.dropped:
+                raise NotImplementedError("the bf16x3 path has no data-parallel hooks / dropout (it is the parity path)")
+            return self._backward_x3(buf, main.cuda_stream)
         first = self.frozen_layer_count
         grouped = self._grouped_wgrad_runs(first)
         dchain, dchain_skip = self._dgrad_chains(buf, first)
@@ -1025,6 +1182,7 @@ class Engine:
         elementwise launch, operands repacked lazily by the next forward()."""
         self.adam_iterations += 1
         st = self._stream()
+        fused = fused and self.planes == 1  # bf16x3: elementwise Adam, the plane operands are rebuilt by the next forward
         if not fused:
             self._launch("adam", "sl_adam_step", self.params.data_ptr(), self.grads.data_ptr(),
                          self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.param_numel, self.adam_iterations,

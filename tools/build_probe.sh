@@ -9,7 +9,7 @@ SRC=$1; shift
 cd "$(dirname "$0")/../speechless_amd/csrc"
 mkdir -p ../../tools/_probe
 OBJS=""
-for f in capi conv_nt_bf16 wgrad_tn_bf16 conv_f32 ctc misc spectrogram conv_chain_bf16 conv1x1_bwd_bf16; do
+for f in capi conv_nt_bf16 wgrad_tn_bf16 conv_f32 ctc misc spectrogram conv_chain_bf16 conv1x1_bwd_bf16 split3; do
   [ "$f.hip" = "$SRC" ] || OBJS="$OBJS $f.o"
 done
 for spec in "$@"; do
