@@ -83,47 +83,46 @@ __global__ __launch_bounds__(64) void stft_power_db_kernel(const float* __restri
 }
 
 // z-normalisation statistics of one utterance: mean and population standard deviation over frames[b] x f values, two
-// passes, double accumulation (numpy computes them in float64).  One 1024-thread work-group per utterance.
-__global__ __launch_bounds__(1024) void znorm_stats_kernel(const float* __restrict__ src, const int* __restrict__ frames,
-                                                           double* __restrict__ stats, int f, int row_stride,
-                                                           long batch_stride) {
-    __shared__ double part[1024];
-    __shared__ double mean_s;
-    const int b = blockIdx.x;
-    const long n = (long)frames[b] * f;
+// passes, double accumulation (numpy computes them in float64).  ZCH work-groups per utterance and pass (one work-group
+// per utterance took 94 us of a 0.26 ms front end): pass 0 leaves per-chunk sums, pass 1 per-chunk sums of squared
+// deviations from the mean it rebuilds from pass 0's chunks -- always summed in chunk order, so the statistics of an
+// utterance do not depend on the batch it sits in.   part: double[B][2][ZCH]
+constexpr int ZCH = 32;
+__device__ __forceinline__ double znorm_mean(const double* part, int b, long n) {
+    double s = 0.0;
+    for (int j = 0; j < ZCH; ++j) s += part[((long)b * 2 + 0) * ZCH + j];
+    return s / (double)n;
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void znorm_partial_kernel(const float* __restrict__ src, const int* __restrict__ frames,
+                                                            double* __restrict__ part, int f, int row_stride,
+                                                            long batch_stride) {
+    __shared__ double sh[256];
+    const int b = blockIdx.y, j = blockIdx.x;
+    const int rows = frames[b];
+    const long n = (long)rows * f;
+    const int per = (rows + ZCH - 1) / ZCH;
+    const int t0 = j * per, t1 = min(rows, t0 + per);
+    const double mean = PASS == 1 ? znorm_mean(part, b, n) : 0.0;
     const float* base = src + (long)b * batch_stride;
     double acc = 0.0;
-    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)base[(i / f) * row_stride + (i % f)];
-    part[threadIdx.x] = acc;
+    const long m = (long)max(t1 - t0, 0) * f;
+    for (long i = threadIdx.x; i < m; i += 256) {
+        const double v = (double)base[(t0 + i / f) * (long)row_stride + (i % f)];
+        acc += PASS == 0 ? v : (v - mean) * (v - mean);
+    }
+    sh[threadIdx.x] = acc;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) mean_s = part[0] / (double)n;
-    __syncthreads();
-    const double mean = mean_s;
-    acc = 0.0;
-    for (long i = threadIdx.x; i < n; i += 1024) {
-        const double d = (double)base[(i / f) * row_stride + (i % f)] - mean;
-        acc += d * d;
-    }
-    __syncthreads();
-    part[threadIdx.x] = acc;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        stats[2 * b] = mean;
-        stats[2 * b + 1] = sqrt(part[0] / (double)n);
-    }
+    if (threadIdx.x == 0) part[((long)b * 2 + PASS) * ZCH + j] = sh[0];
 }
 
 // dst[b][t][c] = (src - mean_b) / std_b for t < frames[b], 0 beyond (the zero padding of the batch, net.py:583-586)
 __global__ __launch_bounds__(256) void znorm_apply_kernel(const float* __restrict__ src, const int* __restrict__ frames,
-                                                          const double* __restrict__ stats, float* __restrict__ dst,
+                                                          const double* __restrict__ part, float* __restrict__ dst,
                                                           int max_frames, int f, int row_stride, long batch_stride) {
     const int b = blockIdx.y;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -131,7 +130,11 @@ __global__ __launch_bounds__(256) void znorm_apply_kernel(const float* __restric
     const int t = (int)(i / f), c = (int)(i % f);
     float v = 0.f;
     if (t < frames[b]) {
-        const double mean = stats[2 * b], sd = stats[2 * b + 1];
+        const long n = (long)frames[b] * f;
+        const double mean = znorm_mean(part, b, n);
+        double sq = 0.0;
+        for (int j = 0; j < ZCH; ++j) sq += part[((long)b * 2 + 1) * ZCH + j];
+        const double sd = sqrt(sq / (double)n);
         v = (float)(((double)src[(long)b * batch_stride + (long)t * row_stride + c] - mean) / sd);
     }
     dst[((long)b * max_frames + t) * f + c] = v;
@@ -155,7 +158,9 @@ extern "C" int sl_stft_power_db(const float* audio, const int64_t* offsets, cons
     return sl_check_launch("sl_stft_power_db");
 }
 
-extern "C" size_t sl_z_normalize_workspace_bytes(int batch) { return batch > 0 ? (size_t)batch * 2 * sizeof(double) : 0; }
+extern "C" size_t sl_z_normalize_workspace_bytes(int batch) {
+    return batch > 0 ? (size_t)batch * 2 * ZCH * sizeof(double) : 0;
+}
 
 extern "C" int sl_z_normalize(const float* src, const int32_t* frames, float* dst, int batch, int max_frames, int f,
                               int src_row_stride, int64_t src_batch_stride, void* workspace, size_t workspace_bytes,
@@ -168,7 +173,9 @@ extern "C" int sl_z_normalize(const float* src, const int32_t* frames, float* ds
         return SL_ERR_WORKSPACE_TOO_SMALL;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(znorm_stats_kernel, dim3(batch), dim3(1024), 0, s, src, frames, (double*)workspace, f,
+    hipLaunchKernelGGL(znorm_partial_kernel<0>, dim3(ZCH, batch), dim3(256), 0, s, src, frames, (double*)workspace, f,
+                       src_row_stride, (long)src_batch_stride);
+    hipLaunchKernelGGL(znorm_partial_kernel<1>, dim3(ZCH, batch), dim3(256), 0, s, src, frames, (double*)workspace, f,
                        src_row_stride, (long)src_batch_stride);
     int rc = sl_check_launch("sl_z_normalize(stats)");
     if (rc != SL_OK) return rc;
