@@ -167,6 +167,24 @@ int sl_conv1d_backward_1x1(const void* x, const void* g, const void* w_dgrad, vo
                            int epilogue, int k_real, int dtype, int cfg, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* ---- the weight gradients of SEVERAL layers in one balanced launch (bf16) ------------------------------------------------
+ * Replaces a sequence of sl_conv1d_wgrad / sl_conv1d_wgrad_grouped calls (TF Conv2DBackpropFilter of several Conv1D layers,
+ * net.py:389,550) for layers with few 256 x 256 tiles -- inner_conv_1..7 and striding_conv of net.py:317-323: the
+ * (tile, 64-frame step) space of all jobs is cut into one equal range per CU, so no CU idles behind a batch split whose
+ * granularity is an utterance; per-range partial tiles are added in a fixed order by a second kernel of the same call
+ * (deterministic).  job.geom: the layer's weight-gradient geometry as for sl_conv1d_wgrad; every job needs the same
+ * batch and t_out, cin % 256 == 0, cout % 256 == 0.  SL_ERR_UNSUPPORTED otherwise (use the per-layer calls). */
+#define SL_WGRAD_MULTI_MAX_JOBS 16
+typedef struct sl_wgrad_job {
+    const void* x;     /* the layer's input  (geom.x_*) */
+    const void* g;     /* the gradient w.r.t. its output (geom.y_*) */
+    float* dw;         /* float[taps][cin][cout] */
+    sl_conv_geom geom;
+} sl_wgrad_job;
+size_t sl_conv1d_wgrad_multi_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs, int dtype);
+int sl_conv1d_wgrad_multi(const sl_wgrad_job* jobs, int n_jobs, int dtype, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* bias gradient db[co] = sum_{b,t} g[b][g_row0+t][co] (fp32 out, deterministic two-stage).  Same autodiff site. */
 size_t sl_bias_grad_workspace_bytes(const sl_conv_geom* geom);
 int sl_bias_grad(const void* g, float* db, const sl_conv_geom* geom, int dtype, void* workspace,

@@ -54,6 +54,11 @@ class ConvGeom(ctypes.Structure):
     ]
 
 
+class WgradJob(ctypes.Structure):
+    """Mirror of sl_wgrad_job (include/speechless_hip.h)."""
+    _fields_ = [("x", c_void_p), ("g", c_void_p), ("dw", c_void_p), ("geom", ConvGeom)]
+
+
 # name -> (restype, argtypes); every symbol include/speechless_hip.h declares
 SIGNATURES = {
     "sl_version": (c_int, []),
@@ -114,6 +119,8 @@ SIGNATURES = {
                                         c_void_p]),
     "sl_split3_bias_grad_workspace_bytes": (c_size_t, [c_int]),
     "sl_split3_bias_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t, c_void_p]),
+    "sl_conv1d_wgrad_multi_workspace_bytes": (c_size_t, [POINTER(WgradJob), c_int, c_int]),
+    "sl_conv1d_wgrad_multi": (c_int, [POINTER(WgradJob), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "sl_pack_layers": (c_int, [c_void_p, POINTER(AdamLayer), c_int, c_int, c_void_p]),
 }
 

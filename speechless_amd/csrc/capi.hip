@@ -144,6 +144,21 @@ extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl
     return wgrad_tn_f32(x, g, dw, geom, (float*)workspace, splits, cfg, (hipStream_t)stream);
 }
 
+extern "C" size_t sl_conv1d_wgrad_multi_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs, int dtype) {
+    if (!jobs || dtype != SL_BF16) return 0;
+    return wgrad_multi_bf16_workspace_bytes(jobs, n_jobs);
+}
+
+extern "C" int sl_conv1d_wgrad_multi(const sl_wgrad_job* jobs, int n_jobs, int dtype, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    SL_CHECK_ARG(jobs != nullptr, "sl_conv1d_wgrad_multi: jobs is null");
+    if (dtype != SL_BF16) {
+        sl_set_error("sl_conv1d_wgrad_multi: bf16 only");
+        return SL_ERR_UNSUPPORTED;
+    }
+    return wgrad_multi_bf16(jobs, n_jobs, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" int sl_conv1d_backward_1x1_supported(const sl_conv_geom* geom, int k_real, int dtype) {
     return geom != nullptr && dtype == SL_BF16 && conv1x1_bwd_bf16_supported(geom, k_real) ? 1 : 0;
 }

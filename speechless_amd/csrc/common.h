@@ -93,3 +93,5 @@ bool conv1x1_bwd_bf16_supported(const sl_conv_geom* g, int k_real);
 size_t conv1x1_bwd_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
 int conv1x1_bwd_bf16(const void* x, const void* gr, const void* w_dgrad, void* dx, float* dw, const sl_conv_geom* g,
                      int epilogue, int cfg, void* ws, size_t ws_bytes, hipStream_t s);
+size_t wgrad_multi_bf16_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs);
+int wgrad_multi_bf16(const sl_wgrad_job* jobs, int n_jobs, void* ws, size_t ws_bytes, hipStream_t s);

@@ -486,6 +486,237 @@ int launch_ilv(const TnArgs& a, hipStream_t s) {
     return sl_check_launch("sl_conv1d_wgrad(bf16, interleaved)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Several layers' weight gradients in ONE balanced launch (sl_conv1d_wgrad_multi).  The layers at the bottom of the stack
+// have few 256 x 256 tiles (inner_conv_1..7: 49, striding_conv: 24): as launches of their own they need a batch split,
+// whose granularity is an utterance -- 196 work-groups on 256 CUs for the grouped inner layers, 128 x 128 tiles at 30 % of
+// the matrix peak for striding_conv, each followed by a reduction launch.  Here the tiles of ALL the jobs share one grid
+// and the step sequence of a tile (utterance-major, 64-frame chunks) is cut into P = floor(2 * 256 / tiles) SEGMENTS whose
+// boundaries are the same for every tile; a work-group takes two segments -- two consecutive ones of one tile (one item,
+// one partial tile) or, when P is odd, the last segment of two neighbouring tiles (two items) -- so that every CU gets the
+// same number of steps.  Work-groups that run side by side work on the same frames of neighbouring taps and share their
+// operand tiles in the XCD's L2.  (A first version cut the concatenated (tile, step) sequence into equal ranges,
+// "stream-K": balanced too, but neighbouring work-groups then sit at unrelated frames, nothing is shared and the launch
+// became bandwidth-bound: 2.1 us per step instead of 1.4.)  Every item's partial tile goes to its own slot and one
+// table-free reduction launch adds a tile's slots in a fixed order (deterministic).  The step loop is the interleaved
+// 8-wave loop of wgrad_tn_ilv_kernel, unchanged.
+constexpr int MULTI_MAX_JOBS = 16;
+struct MultiJob {
+    const __bf16* x;
+    const __bf16* g;
+    float* dw;
+    int taps, cin, cout, ci_tiles, co_tiles;
+    int x_row0, x_rs, g_row0, g_rs;
+    long x_bs, g_bs;
+    int tile_begin;  // first tile of this job in the common tile sequence
+};
+struct MultiArgs {
+    MultiJob job[MULTI_MAX_JOBS];
+    int n_jobs, total_tiles;
+    int batch, t_chunks, spt;  // steps per tile = batch * t_chunks (the same for every job)
+    int segs;                  // P: segments per tile
+    int pair_wgs;              // total_tiles * (P / 2) work-groups take a pair of segments of one tile ...
+    int workers;               // ... the others (P odd) the last segment of two neighbouring tiles
+    float* slots;              // [workers][2][256 * 256] partial tiles
+};
+__device__ __forceinline__ int multi_seg_begin(const MultiArgs& a, int p) { return (int)((long)a.spt * p / a.segs); }
+
+__global__ __launch_bounds__(512, 2) void wgrad_tn_ilv_multi_kernel(MultiArgs a) {
+    constexpr int NW = 8, STAGES = 2;
+    constexpr int XRB = 512, GRB = 512;
+    constexpr int X_BYTES = TK * XRB;
+    constexpr int STAGE_BYTES = TK * (XRB + GRB);
+    constexpr int XPW = 32 / NW, GPW = 32 / NW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wm = wave >> 2;
+    const int wn = wave & 3;
+
+    if (xcd_remap(blockIdx.x, a.workers) >= a.workers) return;  // grid padding (xcd_grid)
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned wave_x = (wave * XPW) * 1024, wave_g = X_BYTES + (wave * GPW) * 1024;
+
+    for (int item = 0; item < 2; ++item) {
+        // ---- this work-group's item: one or two per work-group, derived from the block id again for the second one (all
+        // wave-uniform and pinned into scalar registers; kept live across the step loop they would not fit: this kernel
+        // fills the scalar register file as well as the vector one)
+        const int ws = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, a.workers));
+        const bool pair = ws < a.pair_wgs;
+        const int tile = __builtin_amdgcn_readfirstlane(pair ? ws % a.total_tiles : 2 * (ws - a.pair_wgs) + item);
+        if (item == 1 && (pair || tile >= a.total_tiles)) break;
+        const int k0 = __builtin_amdgcn_readfirstlane(pair ? ws / a.total_tiles : 0);
+        const int off = __builtin_amdgcn_readfirstlane(multi_seg_begin(a, pair ? 2 * k0 : a.segs - 1));
+        const int n = __builtin_amdgcn_readfirstlane(multi_seg_begin(a, pair ? 2 * k0 + 2 : a.segs)) - off;
+        // Lane-derived values are rebuilt per item (and once more for the epilogue) from an opaque copy of the thread id:
+        // hoisted out of the item loop they would stay live across the step loop, which has two registers to spare.
+        int zero_i = 0;  // (the lane id from the hardware's mbcnt, not from threadIdx.x: v0 need not stay alive either)
+        asm volatile("" : "+v"(zero_i));
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero_i));
+        const int g = lane >> 4;
+        const int i16 = lane & 15;
+        const int rkey = (i16 >> 2) | ((g & 1) << 2);
+        const int rrow = g * 8 + (i16 >> 2);
+        int ji = 0;
+        while (ji + 1 < a.n_jobs && tile >= a.job[ji + 1].tile_begin) ++ji;
+        const MultiJob& J = a.job[ji];
+        int lt = tile - J.tile_begin;
+        const int tap = __builtin_amdgcn_readfirstlane(lt % J.taps);
+        lt = __builtin_amdgcn_readfirstlane(lt / J.taps);
+        const int ci_tile = __builtin_amdgcn_readfirstlane(lt % J.ci_tiles);
+        const int co_tile = __builtin_amdgcn_readfirstlane(lt / J.ci_tiles);
+        const int b_begin = __builtin_amdgcn_readfirstlane(off / a.t_chunks), tc_begin = off - b_begin * a.t_chunks;
+        const int x_rs = J.x_rs, g_rs = J.g_rs;
+
+        int xoff[XPW], goff_src[GPW];
+#pragma unroll
+        for (int q = 0; q < XPW; ++q) xoff[q] = dma_src_offset<4>(wave * XPW + q, lane, x_rs);
+#pragma unroll
+        for (int q = 0; q < GPW; ++q) goff_src[q] = dma_src_offset<4>(wave * GPW + q, lane, g_rs);
+        // (32-bit strides: the host checks that an utterance's tensor has fewer than 2^31 elements; the scalar register
+        // file is as full as the vector one in this kernel)
+        const int x_step = TK * x_rs, g_step = TK * g_rs;
+        const int x_wrap = (int)J.x_bs - (a.t_chunks - 1) * x_step;
+        const int g_wrap = (int)J.g_bs - (a.t_chunks - 1) * g_step;
+        const __bf16* xs_r = J.x + (long)(J.x_row0 + tap) * x_rs + ci_tile * 256 + (long)b_begin * J.x_bs + (long)tc_begin * x_step;
+        const __bf16* gs_r = J.g + (long)J.g_row0 * g_rs + co_tile * 256 + (long)b_begin * J.g_bs + (long)tc_begin * g_step;
+        const __bf16* xs_n = nullptr;
+        const __bf16* gs_n = nullptr;
+        unsigned xl_n = 0, gl_n = 0;
+        int tc_r = tc_begin, left = n;
+        auto begin_stage = [&](int buf) {
+            xs_n = xs_r;
+            gs_n = gs_r;
+            xl_n = buf * STAGE_BYTES + wave_x;
+            gl_n = buf * STAGE_BYTES + wave_g;
+            const bool more = left > 1;
+            const bool wrap = tc_r + 1 == a.t_chunks;
+            int dx = wrap ? x_wrap : x_step;
+            int dg = wrap ? g_wrap : g_step;
+            dx = more ? dx : 0;
+            dg = more ? dg : 0;
+            xs_r += dx;
+            gs_r += dg;
+            tc_r = wrap ? 0 : tc_r + 1;
+            left = more ? left - 1 : left;
+        };
+        auto dma_piece = [&](auto q_c) {
+            constexpr int Q = decltype(q_c)::value;
+            if constexpr (Q < XPW)
+                glds16(xs_n + xoff[Q], smem + xl_n + Q * 1024);
+            else if constexpr (Q < XPW + GPW)
+                glds16(gs_n + goff_src[Q - XPW], smem + gl_n + (Q - XPW) * 1024);
+        };
+
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        if (item > 0) {  // the previous item's last fragment reads must be over before its slots are refilled
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < STAGES; ++i) {
+            begin_stage(i);
+#pragma unroll
+            for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], smem + xl_n + q * 1024);
+#pragma unroll
+            for (int q = 0; q < GPW; ++q) glds16(gs_n + goff_src[q], smem + gl_n + q * 1024);
+        }
+        wait_vmcnt<(XPW + GPW) * (STAGES - 1)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TrFrags f0, f1;
+        unsigned ga[4], xa[8];  // (rebuilt per item: kept live across items they cost the twelve registers that spill)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ga[j] = lds0 + X_BYTES + rrow * GRB + (((wn * 4 + j) ^ rkey) * 32) + (i16 & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[j] = lds0 + rrow * XRB + (((wm * 8 + j) ^ rkey) * 32) + (i16 & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_read8<0, GRB>(f0.gl[j], f0.gh[j], ga[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tr_read8<0, XRB>(f0.xl[j], f0.xh[j], xa[j]);
+        int cur = 0;
+        int slot_delta = 0;
+        auto pin_stage = [&]() {
+            begin_stage(cur);
+            asm volatile("" : "+s"(xs_n), "+s"(gs_n), "+s"(xl_n), "+s"(gl_n), "+s"(xs_r), "+s"(gs_r));
+        };
+        auto move_g = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ga[j] += slot_delta;
+            asm volatile("" : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]));
+        };
+        auto move_x = [&](int j0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xa[j0 + j] += slot_delta;
+            asm volatile("" : "+v"(xa[j0]), "+v"(xa[j0 + 1]), "+v"(xa[j0 + 2]), "+v"(xa[j0 + 3]));
+        };
+        auto hook_a = [&](auto q_c) {
+            constexpr int Q = decltype(q_c)::value;
+            if constexpr (Q == 1) pin_stage();
+            if constexpr (Q == 12) move_g();
+            if constexpr (Q == 13) move_x(0);
+            if constexpr (Q == 14) move_x(4);
+        };
+        for (int i = 0; i < n; ++i) {
+            const int nxt = cur ^ 1;
+            slot_delta = (nxt - cur) * STAGE_BYTES;
+            wait_trfrags(f0);
+            TrPhase<1, 0, 16>::run(acc, f0, f1, ga, xa, hook_a);
+            wait_trfrags(f1);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            TrPhase<0, 0, 16>::run(acc, f1, f0, ga, xa, dma_piece);
+            cur = nxt;
+        }
+        wait_vmcnt<0>();
+        wait_trfrags(f0);
+
+        // ---- this item's partial tile: dense [256 ci][256 co] floats in slot (w, item)
+        float* out = a.slots + ((long)__builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, a.workers)) * 2 + item) * (256 * 256);
+        int zero_e = 0;
+        asm volatile("" : "+v"(zero_e));
+        const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero_e));
+        const int ci_l = wm * 128 + (lane_e & 15);
+        const int co_l = wn * 64 + (lane_e >> 4) * 4;
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) *(f32x4*)(out + (ci_l + it * 16) * 256 + co_l + jn * 16) = acc[jn][it];
+    }
+}
+
+// dw tile = sum of its items' slots: the pair items in segment order, then the single last segment (P odd).
+// grid (64, total_tiles), 256 threads x one float4
+__global__ __launch_bounds__(256) void wgrad_multi_reduce_kernel(MultiArgs a) {
+    const int tile = blockIdx.y;
+    int ji = 0;
+    while (ji + 1 < a.n_jobs && tile >= a.job[ji + 1].tile_begin) ++ji;
+    const MultiJob& J = a.job[ji];
+    int lt = tile - J.tile_begin;
+    const int tap = lt % J.taps;
+    lt /= J.taps;
+    const int ci_tile = lt % J.ci_tiles, co_tile = lt / J.ci_tiles;
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;  // float index inside the 256 x 256 tile
+    const int ci = e >> 8, co = e & 255;
+    const int pairs = a.segs / 2;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < pairs; ++k) {
+        const f32x4 v = *(const f32x4*)(a.slots + ((long)(k * a.total_tiles + tile) * 2) * (256 * 256) + e);
+        s = k == 0 ? v : s + v;
+    }
+    if (a.segs & 1) {
+        const f32x4 v = *(const f32x4*)(a.slots + ((long)(a.pair_wgs + tile / 2) * 2 + (tile & 1)) * (256 * 256) + e);
+        s = pairs == 0 ? v : s + v;
+    }
+    *(f32x4*)(J.dw + ((long)tap * J.cin + ci_tile * 256 + ci) * J.cout + co_tile * 256 + co) = s;
+}
+
 template <int WM, int WN, int STAGES>
 int launch(const TnArgs& a, hipStream_t s) {
     constexpr int LDS_BYTES = STAGES * TK * 128 * (WM + WN);
@@ -667,4 +898,89 @@ int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* 
         return sl_check_launch("wgrad_reduce");
     }
     return SL_OK;
+}
+
+// ---- sl_conv1d_wgrad_multi: see wgrad_tn_ilv_multi_kernel
+static int multi_fill(const sl_wgrad_job* jobs, int n_jobs, MultiArgs* a) {
+    if (n_jobs < 1 || n_jobs > MULTI_MAX_JOBS) {
+        sl_set_error("sl_conv1d_wgrad_multi: 1..%d jobs per call", MULTI_MAX_JOBS);
+        return SL_ERR_INVALID_ARGUMENT;
+    }
+    a->n_jobs = n_jobs;
+    a->batch = jobs[0].geom.batch;
+    a->t_chunks = (jobs[0].geom.t_out + TK - 1) / TK;
+    a->spt = a->batch * a->t_chunks;
+    int tiles = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const sl_conv_geom& g = jobs[i].geom;
+        if (g.batch != a->batch || g.t_out != jobs[0].geom.t_out || g.batch <= 0 || g.t_out <= 0 || g.taps <= 0 ||
+            g.cin <= 0 || g.cout <= 0 || g.cin % 256 || g.cout % 256 || g.x_row_stride % 8 || g.y_row_stride % 8 ||
+            g.x_row_stride < g.cin || g.y_row_stride < g.cout || g.x_batch_stride >= (1LL << 31) ||
+            g.y_batch_stride >= (1LL << 31)) {
+            sl_set_error("sl_conv1d_wgrad_multi: job %d: all jobs need the same batch and t_out, channel counts that are "
+                         "multiples of 256 and row strides that are multiples of 8", i);
+            return SL_ERR_UNSUPPORTED;
+        }
+        MultiJob& J = a->job[i];
+        J.x = (const __bf16*)jobs[i].x;
+        J.g = (const __bf16*)jobs[i].g;
+        J.dw = jobs[i].dw;
+        J.taps = g.taps;
+        J.cin = g.cin;
+        J.cout = g.cout;
+        J.ci_tiles = g.cin / 256;
+        J.co_tiles = g.cout / 256;
+        J.x_row0 = g.x_row0;
+        J.x_rs = g.x_row_stride;
+        J.x_bs = g.x_batch_stride;
+        J.g_row0 = g.y_row0;
+        J.g_rs = g.y_row_stride;
+        J.g_bs = g.y_batch_stride;
+        J.tile_begin = tiles;
+        tiles += g.taps * J.ci_tiles * J.co_tiles;
+    }
+    a->total_tiles = tiles;
+    // P aligned segments per tile, two per work-group, about one work-group per CU (the interleaved kernel takes a whole CU)
+    int segs = 512 / tiles;
+    if (segs > a->spt) segs = a->spt;
+    if (segs < 1) segs = 1;
+    a->segs = segs;
+    a->pair_wgs = tiles * (segs / 2);
+    a->workers = a->pair_wgs + ((segs & 1) ? (tiles + 1) / 2 : 0);
+    return SL_OK;
+}
+
+size_t wgrad_multi_bf16_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs) {
+    MultiArgs a;
+    if (multi_fill(jobs, n_jobs, &a) != SL_OK) return 0;
+    return (size_t)a.workers * 2 * 256 * 256 * sizeof(float);
+}
+
+int wgrad_multi_bf16(const sl_wgrad_job* jobs, int n_jobs, void* ws, size_t ws_bytes, hipStream_t s) {
+    MultiArgs a;
+    int rc = multi_fill(jobs, n_jobs, &a);
+    if (rc != SL_OK) return rc;
+    for (int i = 0; i < n_jobs; ++i)
+        if (!jobs[i].x || !jobs[i].g || !jobs[i].dw) {
+            sl_set_error("sl_conv1d_wgrad_multi: null pointer in job %d", i);
+            return SL_ERR_INVALID_ARGUMENT;
+        }
+    if (ws == nullptr || ws_bytes < (size_t)a.workers * 2 * 256 * 256 * sizeof(float)) {
+        sl_set_error("sl_conv1d_wgrad_multi: workspace too small");
+        return SL_ERR_WORKSPACE_TOO_SMALL;
+    }
+    a.slots = (float*)ws;
+    constexpr int LDS_BYTES = 2 * TK * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_ilv_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    sl_prof_begin(s);
+    hipLaunchKernelGGL(wgrad_tn_ilv_multi_kernel, dim3(xcd_grid(a.workers)), dim3(512), LDS_BYTES, s, a);
+    sl_prof_end(s);
+    rc = sl_check_launch("sl_conv1d_wgrad_multi");
+    if (rc != SL_OK) return rc;
+    hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3(64, a.total_tiles), dim3(256), 0, s, a);
+    return sl_check_launch("sl_conv1d_wgrad_multi(reduce)");
 }

@@ -168,6 +168,8 @@ class _Buffers:
         self.wgrad_ws = None
         self.launch_lists = {}   # recorded launch lists (Engine._replay); dropped whenever a pointer they hold changes
         self.chain_tables = {}   # sl_conv1d_chain pointer tables of this buffer set (Engine._chain_table)
+        self.multi_tables = {}   # sl_conv1d_wgrad_multi job tables (their geometries follow set_length)
+        self.wgrad_multi_ws = None
         self._ws_sized_fwd = set()   # output lengths whose forward / backward workspace needs have been checked
         self._ws_sized_bwd = set()   # (a length first seen by predict() and trained on later still gets its dgrad sizing)
         self._clean_in = 0       # input frames / output rows up to which stale data may sit in the buffers
@@ -199,6 +201,9 @@ class _Buffers:
             for g in geoms:
                 if g is not None:
                     g.t_out = t_out
+        for table in self.multi_tables.values():
+            for job in table:
+                job.geom.t_out = t_out
         if t_out not in self._ws_sized_fwd:  # split counts (hence workspace sizes) depend on the number of time tiles
             self._ws_sized_fwd.add(t_out)
             self.size_nt_workspace(eng, self.fwd_geom, "fwd")
@@ -427,6 +432,10 @@ class Engine:
         # both gradients of the 1x1 output layer in one launch that reads the layer's input once (sl_conv1d_backward_1x1):
         # 0.038 ms against 0.040 + 0.032 ms of dgrad + wgrad launches at config 3.  SL_FUSE_OUTPUT_BWD=0: the two launches.
         self.fuse_output_backward = os.environ.get("SL_FUSE_OUTPUT_BWD", "1") != "0"
+        # the weight gradients of the layers with few 256 x 256 tiles (the run of inner layers, striding_conv) in ONE launch
+        # whose (tile, 64-frame step) space is cut into one equal range per CU (sl_conv1d_wgrad_multi) instead of a grouped
+        # launch + a 128 x 128-tile launch with utterance-granular batch splits.  SL_WGRAD_MULTI=0: those launches.
+        self.use_wgrad_multi = os.environ.get("SL_WGRAD_MULTI", "1") != "0"
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
         # Launch lists: the ~60 C-ABI calls and 4 stream hand-overs of a step are recorded the first time a buffer set
         # runs them and replayed afterwards with their arguments already marshalled -- the Python around each launch
@@ -951,6 +960,7 @@ class Engine:
         # launch list: not with dropout (its scale passes take the rate by value)
         key = None if buf.dropped else ("bwd", main.cuda_stream, on_bucket_ready is not None, self.ones_channel,
                                         self.frozen_layer_count, self.group_wgrad, self.use_chain, self.fuse_output_backward,
+                                        self.use_wgrad_multi,
                                         tuple(sorted(self.nt_cfg.items())))
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
@@ -1102,6 +1112,41 @@ class Engine:
         if ones_in:
             self._bias_grads_from_wgrad(ones_in, True, torch.cuda.current_stream(self.device))
 
+    def _wgrad_multi_layers(self, buf, first, grouped, on_bucket_ready):
+        """layers whose weight gradients go into ONE sl_conv1d_wgrad_multi launch (at the lowest of them): the runs of
+        identical layers and -- single GPU only: its gradient bucket closes last -- the striding layer below them"""
+        if not self.use_wgrad_multi or self.dtype != "bf16" or not grouped:
+            return []
+        layers = sorted(grouped)
+        if on_bucket_ready is None and first == 0 and self.plans[0].spec.stride == 2 and layers[0] == 1:
+            layers = [0] + layers
+        ok = all(self.plans[i].cin_view % 256 == 0 and self.plans[i].cout_pad % 256 == 0 and
+                 ("wgrad", self.specs[i].name) not in self.nt_cfg for i in layers)
+        if not ok and layers[0] == 0:
+            layers = layers[1:]
+            ok = all(self.plans[i].cin_view % 256 == 0 and self.plans[i].cout_pad % 256 == 0 and
+                     ("wgrad", self.specs[i].name) not in self.nt_cfg for i in layers)
+        return layers if ok and len(layers) <= 16 else []
+
+    def _launch_wgrad_multi(self, buf, layers, st):
+        key = (tuple(layers), buf.dropped)
+        table = buf.multi_tables.get(key)
+        if table is None:
+            table = (_lib.WgradJob * len(layers))()
+            for job, i in zip(table, layers):
+                x = (buf.x0_dropped if buf.dropped else buf.x0) if i == 0 else buf.y[i - 1]
+                dw, _ = self.layer_param_views(self.grads, self.plans[i])
+                job.x, job.g, job.dw = x.data_ptr(), buf.g[i].data_ptr(), dw.data_ptr()
+                for name, _ in ConvGeom._fields_:
+                    setattr(job.geom, name, getattr(buf.wgrad_geom[i], name))
+            buf.multi_tables[key] = table
+            need = self.lib.raw("sl_conv1d_wgrad_multi_workspace_bytes")(table, len(layers), self.dtype_code)
+            if buf.wgrad_multi_ws is None or buf.wgrad_multi_ws.numel() < need:
+                buf.wgrad_multi_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=self.device)
+        self._launch("wgrad:{}..{}".format(self.specs[layers[0]].name, self.specs[layers[-1]].name),
+                     "sl_conv1d_wgrad_multi", table, len(layers), self.dtype_code, buf.wgrad_multi_ws.data_ptr(),
+                     buf.wgrad_multi_ws.numel(), st)
+
     def _backward_eager(self, buf, main, side, on_bucket_ready):
         if self.planes > 1:
             if on_bucket_ready is not None or buf.dropped:
@@ -1110,6 +1155,7 @@ class Engine:
         first = self.frozen_layer_count
         grouped = self._grouped_wgrad_runs(first)
         dchain, dchain_skip = self._dgrad_chains(buf, first)
+        multi = self._wgrad_multi_layers(buf, first, grouped, on_bucket_ready)
         # bias gradients out of the weight-gradient GEMM (self.ones_channel): which layers, and whether the row holds the
         # bias gradient (the ones were not touched by dropout) or only has to be zeroed before the optimizer sees it
         ones_in = self._ones_input_layers(first)
@@ -1151,6 +1197,9 @@ class Engine:
             fused_bwd = self._fused_output_backward(buf, i, first, grouped, dchain, dchain_skip)
             if fused_bwd:
                 self._launch_output_backward(buf, i, main.cuda_stream)
+            elif i in multi:
+                if i == multi[0]:  # every gradient tensor the launch reads is complete at its lowest layer
+                    self._launch_wgrad_multi(buf, multi, main.cuda_stream)
             else:
                 self._launch_wgrad(buf, i, grouped, main.cuda_stream)
             if closes_bucket:

@@ -222,8 +222,8 @@ def _conv_ref64(x, w, bias, stride):
 
 def test_production_step_at_batch_32_layer_by_layer_against_float64():
     """The launches the benchmark times -- 32 x 1000 frames, bf16: slab kernel with split-K, the fused inner-layer launches
-    in both directions, grouped / interleaved weight gradients with their batch splits, output layer fused with the softmax
-    and its one-launch backward -- each checked on the EXACT operands it read: every stored activation / gradient tensor is
+    in both directions, interleaved weight gradients with their batch splits and the balanced multi-layer launch for the
+    inner and striding layers, output layer fused with the softmax and its one-launch backward -- each checked on the EXACT operands it read: every stored activation / gradient tensor is
     bf16, so the float64 result from the stored inputs of a launch is what that launch had to produce, up to fp32
     accumulation order (weight gradients: fp32 out) and one bf16 rounding (activations, input gradients)."""
     import torch
@@ -243,7 +243,7 @@ def test_production_step_at_batch_32_layer_by_layer_against_float64():
     torch.cuda.synchronize()
     tags = {tag for tag, _, _ in eng.timeline}
     eng.timeline = None
-    for tag in ("fwd:inner_conv_1..inner_conv_7", "dgrad:inner_conv_7..inner_conv_1", "wgrad:inner_conv_1..inner_conv_7",
+    for tag in ("fwd:inner_conv_1..inner_conv_7", "dgrad:inner_conv_7..inner_conv_1", "wgrad:striding_conv..inner_conv_7",
                 "bwd:output_conv", "fwd:output_conv", "wgrad:big_conv_1", "dgrad:big_conv_1"):
         assert tag in tags, (tag, sorted(tags))  # the production launches, not their fallbacks
     buf = eng.cur
@@ -371,3 +371,42 @@ def test_bf16x3_gradients_at_full_length_against_the_cpu_path():
     bounds = {"striding_conv": 1e-2, "inner_conv_1": 2e-3, "inner_conv_2": 1.5e-3}
     for name, (ew, eb) in errs.items():
         assert ew < bounds.get(name, 1e-3) and eb < bounds.get(name, 1e-3), (name, ew, eb)
+
+
+# ------------------------------------------------------------------------------------------ balanced multi-layer weight gradient
+@pytest.mark.parametrize("b,t,f", [(32, 1000, 128), (3, 150, 128), (5, 333, 128), (8, 4000, 257), (1, 70, 128)])
+def test_wgrad_multi_against_the_per_layer_launches(b, t, f):
+    """sl_conv1d_wgrad_multi (the inner layers' and the striding layer's weight gradients in one launch whose (tile, step)
+    space is cut into one equal range per CU) against the grouped + single launches it replaces: same gradients up to fp32
+    summation order, bitwise reproducible, every padded lane still zero.  257 bins: the striding layer (pair view of 640
+    channels) does not fit the 256 x 256 tiles and stays a launch of its own."""
+    import torch
+    case = make_case(b=b, t=t, f=f, seed=13)
+    eng = make_engine(case, "bf16")
+    eng.use_launch_lists = False
+    eng.load_input(case["x"])
+    eng.set_labels(case["labels"], case["label_lengths"], case["prediction_lengths"])
+    eng.forward(training=True)
+    eng.ctc()
+    results = {}
+    for mode in ("multi", "multi_again", "single"):
+        eng.use_wgrad_multi = mode != "single"
+        eng.grads.zero_()
+        eng.timeline = []
+        eng.backward()
+        torch.cuda.synchronize()
+        tags = [tag for tag, _, _ in eng.timeline]
+        eng.timeline = None
+        want_tag = "wgrad:striding_conv..inner_conv_7" if f == 128 else "wgrad:inner_conv_1..inner_conv_7"
+        assert (want_tag in tags) == (mode != "single") or mode == "single", (mode, tags)
+        if mode == "single":
+            assert "wgrad:inner_conv_1..inner_conv_7" in tags and "wgrad:striding_conv" in tags  # grouped + single launch
+        results[mode] = eng.grads.clone()
+    assert torch.equal(results["multi"], results["multi_again"])
+    for p in eng.plans[:8]:
+        a = eng.layer_param_views(results["multi"], p)
+        s = eng.layer_param_views(results["single"], p)
+        assert rel_l2(a[0].cpu().numpy(), s[0].cpu().numpy()) < 2e-6, p.spec.name
+        assert rel_l2(a[1].cpu().numpy(), s[1].cpu().numpy()) < 2e-6, p.spec.name
+        full = a[0].cpu().numpy()
+        assert not full[:, :, p.spec.cout:].any() and not full[:, p.spec.cin:p.cin_pad, :].any(), p.spec.name

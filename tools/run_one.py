@@ -69,6 +69,8 @@ def main():
             eng.lib.call("sl_conv1d_nt", buf.g[i].data_ptr(), eng.w_dgrad[i].data_ptr(), None, buf.y[i - 1].data_ptr(),
                          buf.g[i - 1].data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_RELU_MASK, eng.dtype_code, 0,
                          args.cfg, ws.data_ptr(), ws.numel(), st)
+        elif args.kind == "wgrad_multi":  # the balanced launch for striding_conv + inner_conv_1..7 (--layer ignored)
+            eng._launch_wgrad_multi(buf, list(range(0, 8)) if args.cfg == 0 else list(range(1, 8)), st)
         elif args.kind == "bwd1x1":  # both gradients of the 1x1 output layer in one launch (--layer output_conv)
             dw, _ = eng.layer_param_views(eng.grads, p)
             eng.lib.call("sl_conv1d_backward_1x1", buf.y[i - 1].data_ptr(), buf.g[i].data_ptr(), eng.w_dgrad[i].data_ptr(),
