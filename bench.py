@@ -392,36 +392,40 @@ class Bench:
 
     def roofline_wgrad(self, live_ms, kernel_ms):
         """Dominant kernel (largest share of main-stream GPU time, profiles/*_kernel_stats.csv): wgrad_tn_ilv_kernel, the
-        8-wave interleaved 256x256-tile weight-gradient kernel.  THREE launches per step use it (the library's measured
-        table picks it for big_conv_1, big_conv_2 and the grouped launch that covers the seven inner_conv_i);
-        algorithmic FLOPs per launch = (sum of those nine layers' wgrad FLOPs) / 3."""
+        8-wave interleaved 256x256-tile weight-gradient kernel, TWO launches per step (big_conv_1, big_conv_2); its loop
+        also runs the balanced launch for striding_conv + inner_conv_1..7 (wgrad_tn_ilv_multi_kernel), listed beside
+        them in per_launch.  algorithmic FLOPs per launch = (sum of the two layers' wgrad FLOPs) / 2."""
         fl, names = self.fl, self.names
-        dom_tags = sorted(t for t in live_ms if t.startswith("wgrad:") and
-                          t not in ("wgrad:output_conv", "wgrad:striding_conv"))
+        tags = sorted(t for t in live_ms if t.startswith("wgrad:") and t in kernel_ms)
         per_launch = {}
-        for t in dom_tags:
+        for t in tags:
             lo = t.split(":", 1)[1].split("..")
             layers = [lo[0]] if len(lo) == 1 else names[names.index(lo[0]): names.index(lo[1]) + 1]
             flops = sum(fl[names.index(n)] for n in layers) * BATCH_PER_GPU
             per_launch[t] = {"flops": flops, "ms": kernel_ms[t],
                              "frac": flops / (kernel_ms[t] * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS}
-        dom_flops = sum(v["flops"] for v in per_launch.values()) / len(dom_tags)
+        dom_tags = [t for t in tags if t in ("wgrad:big_conv_1", "wgrad:big_conv_2")]
+        dom_flops = sum(per_launch[t]["flops"] for t in dom_tags) / len(dom_tags)
         dom_ms = sum(kernel_ms[t] for t in dom_tags) / len(dom_tags)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         traffic, traffic_source, per_launch_traffic = None, None, None
         for name in sorted((ROOT / "profiles").glob("r*_pmc_traffic_wgrad_ilv.json"), reverse=True):
             pmc = json.loads(name.read_text())  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh
-            traffic = pmc["traffic_bytes_per_launch_avg"]
             per_launch_traffic = {k: v["traffic_bytes"] for k, v in pmc.get("launches", {}).items()}
+            dom = [v for k, v in per_launch_traffic.items() if k in ("big_conv_1", "big_conv_2")]
+            traffic = sum(dom) / len(dom) if dom else pmc["traffic_bytes_per_launch_avg"]
             traffic_source = "profiles/" + name.name
             break
         return {
-            "bound": "mfma", "kernel": "wgrad_tn_ilv_kernel (weight gradient of big_conv_1, big_conv_2 and the grouped "
-                                       "inner_conv_1..7 launch; average over its {} launches per "
-                                       "step)".format(len(dom_tags)),
+            "bound": "mfma", "kernel": "wgrad_tn_ilv_kernel (weight gradient of big_conv_1 and big_conv_2; average over its {} "
+                                       "launches per step)".format(len(dom_tags)),
             "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
             "traffic_source": traffic_source, "traffic_per_launch": per_launch_traffic,
+            "algorithmic_bytes_per_launch": {
+                "big_conv_1": BATCH_PER_GPU * (FRAMES // 2) * (256 + 2048) * 2 + 32 * 256 * 2048 * 4,
+                "big_conv_2": BATCH_PER_GPU * (FRAMES // 2) * (2048 + 2048) * 2 + 2048 * 2048 * 4,
+                "note": "padded operands read once (bf16) + the fp32 weight gradient written once"},
             "traffic_note": "NOT measured in this run (PMC counters need rocprofv3 around the process): bytes per launch "
                             "from the committed file named in traffic_source -- rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE "
                             "in separate passes (tools/pmc_traffic.sh), Infinity-Cache hits included, average of the "

@@ -473,6 +473,196 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_ilv_kernel(TnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Deep-ring variant of the interleaved kernel (cfg stages 11): 32-frame stages, FOUR LDS slots of 32 KB, one barrier per
+// stage.  Same tile (256 x 256, eight waves of 128 x 64), same fragment reads, same MFMA order inside a stage; what changes
+// is the distance between a tile's request and its first read: three stages (~2 us) instead of one 64-frame step (~1.3 us).
+// The launches whose operand tiles are new data at every step (big_conv_2, the inner layers: each tile is shared by only
+// 4-8 work-groups of an XCD, so a step's tiles are compulsory L2 misses) wait for exactly that with the 2-slot ring:
+// PMC (profiles/r03_pmc_wgrad_*.json) MFMA pipe busy 59 % / 53 % against 71 % for big_conv_1, whose operands stay in L2.
+//   phase(j): MFMAs of stage j from registers | fragment reads of stage j + 1 | requests of stage j + 4 into slot j % 4
+//   barrier(j + 1): stage j + 2 landed (vmcnt: two younger stages may stay in flight), everybody done reading slot (j+1) % 4
+__global__ __launch_bounds__(512, 2) void wgrad_tn_ilv32_kernel(TnArgs a) {
+    constexpr int NW = 8, SLOTS = 4, TS = 32;
+    constexpr int TCI = 256, TCO = 256;
+    constexpr int XRB = 512, GRB = 512;
+    constexpr int X_BYTES = TS * XRB;               // 16 KB
+    constexpr int STAGE_BYTES = TS * (XRB + GRB);   // 32 KB
+    constexpr int XPW = 16 / NW, GPW = 16 / NW;     // 1-KiB DMA instructions per wave, stage and operand
+    constexpr int NI = XPW + GPW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;
+    const int wn = wave & 3;
+    const int g = lane >> 4;
+
+    int wg = xcd_remap(blockIdx.x, a.tiles * a.splits * a.groups);
+    if (wg >= a.tiles * a.splits * a.groups) return;
+    const int group = wg / (a.tiles * a.splits);
+    wg -= group * (a.tiles * a.splits);
+    const int tap = wg % a.taps;
+    wg /= a.taps;
+    const int ci_tile = wg % a.ci_tiles;
+    wg /= a.ci_tiles;
+    const int co_tile = wg % a.co_tiles;
+    const int split = wg / a.co_tiles;
+    const int b_begin = split * a.b_per_split;
+    int b_end = b_begin + a.b_per_split;
+    if (b_end > a.batch) b_end = a.batch;
+    const int tc32 = 2 * a.t_chunks;             // 32-frame stages per utterance
+    const int n = (b_end - b_begin) * tc32;      // stages of this work-group (even)
+
+    int xoff[XPW], goff_src[GPW];
+#pragma unroll
+    for (int q = 0; q < XPW; ++q) xoff[q] = dma_src_offset<4>(wave * XPW + q, lane, a.x_rs);
+#pragma unroll
+    for (int q = 0; q < GPW; ++q) goff_src[q] = dma_src_offset<4>(wave * GPW + q, lane, a.g_rs);
+    const __bf16* xbase = a.x + group * a.x_gs + (long)(a.x_row0 + tap) * a.x_rs + ci_tile * TCI;
+    const __bf16* gbase = a.g + group * a.g_gs + (long)a.g_row0 * a.g_rs + co_tile * TCO;
+
+    const __bf16* xs_n = nullptr;
+    const __bf16* gs_n = nullptr;
+    unsigned xl_n = 0, gl_n = 0;
+    const long x_step = (long)TS * a.x_rs, g_step = (long)TS * a.g_rs;
+    const long x_wrap = (long)a.x_bs - (long)(tc32 - 1) * x_step;
+    const long g_wrap = (long)a.g_bs - (long)(tc32 - 1) * g_step;
+    const __bf16* xs_r = xbase + (long)b_begin * a.x_bs;
+    const __bf16* gs_r = gbase + (long)b_begin * a.g_bs;
+    int tc_r = 0, left = n;
+    const unsigned wave_x = (wave * XPW) * 1024, wave_g = X_BYTES + (wave * GPW) * 1024;
+    auto begin_stage = [&](int slot) {
+        xs_n = xs_r;
+        gs_n = gs_r;
+        xl_n = slot * STAGE_BYTES + wave_x;
+        gl_n = slot * STAGE_BYTES + wave_g;
+        const bool more = left > 1;
+        const bool wrap = tc_r + 1 == tc32;
+        long dx = wrap ? x_wrap : x_step;
+        long dg = wrap ? g_wrap : g_step;
+        dx = more ? dx : 0L;
+        dg = more ? dg : 0L;
+        xs_r += dx;
+        gs_r += dg;
+        tc_r = wrap ? 0 : tc_r + 1;
+        left = more ? left - 1 : left;
+    };
+    auto dma_piece = [&](auto q_c) {
+        constexpr int Q = decltype(q_c)::value;
+        if constexpr (Q < XPW)
+            glds16(xs_n + xoff[Q], smem + xl_n + Q * 1024);
+        else if constexpr (Q < XPW + GPW)
+            glds16(gs_n + goff_src[Q - XPW], smem + gl_n + (Q - XPW) * 1024);
+    };
+    const int i16 = lane & 15;
+    const int rkey = (i16 >> 2) | ((g & 1) << 2);
+    const int rrow = g * 8 + (i16 >> 2);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (n > 0) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            begin_stage(i);
+#pragma unroll
+            for (int q = 0; q < XPW; ++q) glds16(xs_n + xoff[q], smem + xl_n + q * 1024);
+#pragma unroll
+            for (int q = 0; q < GPW; ++q) glds16(gs_n + goff_src[q], smem + gl_n + q * 1024);
+        }
+        wait_vmcnt<NI*(SLOTS - 1)>();  // stage 0
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TrFrags f0, f1;
+        unsigned ga[4], xa[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ga[j] = lds0 + X_BYTES + rrow * GRB + (((wn * 4 + j) ^ rkey) * 32) + (i16 & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[j] = lds0 + rrow * XRB + (((wm * 8 + j) ^ rkey) * 32) + (i16 & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_read8<0, GRB>(f0.gl[j], f0.gh[j], ga[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tr_read8<0, XRB>(f0.xl[j], f0.xh[j], xa[j]);
+        // the read addresses point at the slot read NEXT (stage 1); every phase moves them one slot on behind its reads
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ga[j] += STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[j] += STAGE_BYTES;
+        int rd = 1;           // slot the next phase reads
+        int slot_delta = 0;   // set per phase: distance to the slot after that
+        int rq = 0;           // slot the next phase refills (= the slot of the stage it multiplies)
+        auto pin_stage = [&]() {
+            begin_stage(rq);
+            asm volatile("" : "+s"(xs_n), "+s"(gs_n), "+s"(xl_n), "+s"(gl_n), "+s"(xs_r), "+s"(gs_r));
+        };
+        auto move_g = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ga[j] += slot_delta;
+            asm volatile("" : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]));
+        };
+        auto move_x = [&](int j0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xa[j0 + j] += slot_delta;
+            asm volatile("" : "+v"(xa[j0]), "+v"(xa[j0 + 1]), "+v"(xa[j0 + 2]), "+v"(xa[j0 + 3]));
+        };
+        // groups 0 .. 3 of a phase: one request each (the stage's four instructions of this wave); group 4: the request
+        // stream's arithmetic for the NEXT phase; groups 12 .. 14: the read addresses move on (their twelve reads are out)
+        auto hook = [&](auto q_c) {
+            constexpr int Q = decltype(q_c)::value;
+            dma_piece(q_c);
+            if constexpr (Q == 12) move_g();
+            if constexpr (Q == 13) move_x(0);
+            if constexpr (Q == 14) move_x(4);
+        };
+        auto phase = [&](TrFrags& cur, TrFrags& nxt) {
+            wait_trfrags(cur);
+            wait_vmcnt<NI * 2>();  // the stage the reads below address has landed; the two younger ones stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            slot_delta = rd == SLOTS - 1 ? -(SLOTS - 1) * STAGE_BYTES : STAGE_BYTES;
+            pin_stage();  // requests of this phase go to slot rq
+            TrPhase<0, 0, 16>::run(acc, cur, nxt, ga, xa, hook);
+            rd = rd == SLOTS - 1 ? 0 : rd + 1;
+            rq = rq == SLOTS - 1 ? 0 : rq + 1;
+        };
+        for (int i = 0; i < n; i += 2) {
+            phase(f0, f1);
+            phase(f1, f0);
+        }
+        wait_vmcnt<0>();   // the surplus requests still target this work-group's LDS
+        wait_trfrags(f0);  // ... and the surplus fragment reads these registers
+    }
+
+    float* out = a.splits > 1 ? a.out + ((long)group * a.splits + split) * a.split_stride : a.out + group * a.dw_gs;
+    const int ci_base = ci_tile * TCI + wm * 128 + (lane & 15);
+    const int co_base = co_tile * TCO + wn * 64 + g * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const long row = ((long)tap * a.cin + ci_base + it * 16) * a.cout;
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) *(f32x4*)(out + row + co_base + jn * 16) = acc[jn][it];
+    }
+}
+
+int launch_ilv32(const TnArgs& a, hipStream_t s) {
+    constexpr int LDS_BYTES = 4 * 32 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_ilv32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    sl_prof_begin(s);
+    hipLaunchKernelGGL(wgrad_tn_ilv32_kernel, dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(512), LDS_BYTES, s, a);
+    sl_prof_end(s);
+    return sl_check_launch("sl_conv1d_wgrad(bf16, interleaved, 4-slot ring)");
+}
+
 int launch_ilv(const TnArgs& a, hipStream_t s) {
     constexpr int LDS_BYTES = 2 * TK * 1024;
     static bool attr_set = false;
@@ -785,7 +975,7 @@ bool valid_wcfg(const WCfg& c, const sl_conv_geom* g) {
     const bool shape = (c.wm == 2 && c.wn == 2 && c.stages >= 2 && c.stages <= 4) ||
                        (c.wm == 4 && c.wn == 2 && (c.stages == 2 || c.stages == 3)) ||
                        (c.wm == 2 && c.wn == 4 && (c.stages == 2 || c.stages == 3)) ||
-                       (c.wm == 4 && c.wn == 4 && (c.stages == 2 || c.stages == 10));  // 10: 8-wave interleaved kernel
+                       (c.wm == 4 && c.wn == 4 && (c.stages == 2 || c.stages == 10 || c.stages == 11));  // 10: 8-wave interleaved kernel, 11: its 4-slot ring variant
     return shape && g->cin % (64 * c.wm) == 0 && g->cout % (64 * c.wn) == 0 && c.splits >= 1 && c.splits <= g->batch;
 }
 
@@ -890,6 +1080,7 @@ int wgrad_tn_bf16(const void* x, const void* gr, float* dw, const sl_conv_geom* 
     SL_TN_CASE(4, 4, 2)
 #undef SL_TN_CASE
     if (c.wm == 4 && c.wn == 4 && c.stages == 10) rc = launch_ilv(a, s);
+    if (c.wm == 4 && c.wn == 4 && c.stages == 11) rc = launch_ilv32(a, s);
     if (rc != SL_OK) return rc;
     if (a.splits > 1) {
         const long n4 = a.split_stride / 4;

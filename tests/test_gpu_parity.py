@@ -860,7 +860,7 @@ def test_every_nt_tile_configuration_against_float64(hip_lib, taps, t_out, batch
 
 
 WGRAD_CONFIGS = [(2, 2, 2), (2, 2, 3), (2, 2, 4), (4, 2, 2), (4, 2, 3), (2, 4, 2), (2, 4, 3), (4, 4, 2),
-                 (4, 4, 10)]  # stages 10: the 8-wave interleaved 256x256 kernel
+                 (4, 4, 10), (4, 4, 11)]  # stages 10: the 8-wave interleaved 256x256 kernel, 11: its 4-slot 32-frame ring
 
 
 @pytest.mark.parametrize("taps,t_out,batch,groups", [(7, 200, 6, 1), (3, 130, 5, 3), (1, 64, 4, 1)])

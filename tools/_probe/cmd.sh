@@ -1,7 +1,3 @@
-python tools/run_one.py --kind wgrad_multi --layer striding_conv --cfg 0 --reps 50 2>&1 | grep -v amdgpu
-python tools/run_one.py --kind wgrad_multi --layer striding_conv --cfg 1 --reps 50 2>&1 | grep -v amdgpu
-python tools/run_one.py --kind wgrad_grouped --layer inner_conv_1 --reps 50 2>&1 | grep -v amdgpu
-python tools/run_one.py --kind wgrad --layer striding_conv --reps 50 2>&1 | grep -v amdgpu
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03i_prof -o p -- python tools/run_one.py --kind wgrad_multi --layer striding_conv --cfg 0 --reps 30 > /dev/null 2>&1
-grep -h "multi\|reduce" gpurun_out/r03i_prof/*kernel_stats.csv | cut -c1-200
+python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "every_wgrad_tile" 2>&1 | tail -3
+for L in big_conv_2 big_conv_1; do for cfg in 0 2884; do python tools/run_one.py --kind wgrad --layer $L --cfg $cfg --reps 40 2>&1 | grep -v amdgpu; done; done
+for cfg in 0 2884; do python tools/run_one.py --kind wgrad_grouped --layer inner_conv_1 --cfg $cfg --reps 40 2>&1 | grep -v amdgpu; done
