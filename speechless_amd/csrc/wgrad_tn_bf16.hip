@@ -1144,7 +1144,9 @@ static int multi_fill(const sl_wgrad_job* jobs, int n_jobs, MultiArgs* a) {
 size_t wgrad_multi_bf16_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs) {
     MultiArgs a;
     if (multi_fill(jobs, n_jobs, &a) != SL_OK) return 0;
-    return (size_t)a.workers * 2 * 256 * 256 * sizeof(float);
+    // an upper bound that does not depend on the frame count (the segment count -- and with it the number of work-groups --
+    // changes with it for very short batches): tiles * floor(P / 2) + ceil(tiles / 2) <= 256 + tiles work-groups
+    return (size_t)(256 + a.total_tiles) * 2 * 256 * 256 * sizeof(float);
 }
 
 int wgrad_multi_bf16(const sl_wgrad_job* jobs, int n_jobs, void* ws, size_t ws_bytes, hipStream_t s) {

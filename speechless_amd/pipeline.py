@@ -187,10 +187,14 @@ class AudioBatchStager(BatchStager):
     on the host.  pack(batch) -> (raw audio list, label_batch, label_lengths); prediction lengths follow from the frame
     counts."""
 
-    def __init__(self, batches, pack, extractor, length_ratio, device, blank, depth=3, workers=3, spare_slots=5):
+    def __init__(self, batches, pack, extractor, length_ratio, device, blank, depth=3, workers=3, spare_slots=5,
+                 front_end_on_copy_stream=True):
         super().__init__(batches, pack, device, blank, depth=depth, workers=workers, spare_slots=spare_slots)
         self.extractor = extractor
         self.length_ratio = length_ratio
+        # False: only the samples travel on the copy stream; the front end runs on the COMPUTE stream in front of the step
+        # that consumes it (measurement variant: the big MFMA kernels leave a side stream's kernels no room on the CUs)
+        self.front_end_on_copy_stream = front_end_on_copy_stream
         self.front_end_events = []  # optional (start, stop) timing events per batch, see time_front_end
 
     time_front_end = False
@@ -199,13 +203,24 @@ class AudioBatchStager(BatchStager):
         torch.cuda.set_device(self.device)
         audios, labels, label_lengths = self.pack(batch)
         b = len(audios)
-        n = int(sum(np.asarray(a).size for a in audios))
+        # the samples go into the staging buffer as a (B, longest, 1) batch through the native packer (several threads, no
+        # GIL: a Python loop of 32 slice copies holds the interpreter for milliseconds, which the training thread feels)
+        arrays = [np.asarray(a).reshape(-1, 1) for a in audios]
+        arrays = [a if a.dtype in (np.float32, np.float64) else a.astype(np.float32) for a in arrays]
+        lengths = np.array([a.shape[0] for a in arrays], dtype=np.int32)
+        if lengths.min() <= self.extractor.n_fft // 2:
+            raise ValueError("audio shorter than {} samples cannot be reflect-padded".format(self.extractor.n_fft // 2 + 1))
+        t_max = int(lengths.max())
+        n = b * t_max
+        offsets = np.arange(b, dtype=np.int64) * t_max
         if slot.copied is not None:
             slot.copied.synchronize()      # the previous H2D out of this staging buffer is done
+        if slot.consumed is not None:
+            slot.consumed.synchronize()    # ... and the readers of the slot's device buffers have run
         if slot.pinned is None or slot.pinned.numel() < n:
             slot.pinned = torch.empty((n,), dtype=torch.float32)
             slot.device = torch.empty((n,), dtype=torch.float32, device=self.device)
-        flat, offsets, lengths = self.extractor.flatten(audios, out=slot.pinned.numpy())
+        pack_spectrograms(arrays, slot.pinned[:n].view(b, t_max, 1).numpy())
         labels = np.asarray(labels, dtype=np.int32)
         lab_len = np.asarray(label_lengths, dtype=np.int32).reshape(-1)
         if labels.ndim != 2 or labels.shape[0] != b:
@@ -228,7 +243,12 @@ class AudioBatchStager(BatchStager):
             if self.time_front_end:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(self.copy_stream)
-            x_dev, frames = self.extractor.batch_device(audio_dev, off_dev, len_dev, lengths)
+            if self.front_end_on_copy_stream:
+                x_dev, frames = self.extractor.batch_device(audio_dev, off_dev, len_dev, lengths, bufs=slot.__dict__.setdefault(
+                    "front_end_buffers", {}))
+            else:
+                x_dev, frames = None, [self.extractor.frame_count(int(m)) for m in lengths]
+                frames_dev = torch.tensor(frames, dtype=torch.int32, device=self.device)
             if self.time_front_end:
                 t1.record(self.copy_stream)
                 self.front_end_events.append((t0, t1))
@@ -242,13 +262,18 @@ class AudioBatchStager(BatchStager):
         slot.consumed = None
         staged = StagedBatch(slot, x_dev, labels_dev, lab_len_dev, pred_len_dev, ready)
         staged.frames = frames
+        staged.audio = (audio_dev, off_dev, len_dev, lengths, None if self.front_end_on_copy_stream else frames_dev)
         return staged
 
     def __next__(self):
         item = super().__next__()
-        # the spectrogram was allocated on the copy stream and is read by the compute stream (sl_pack_input)
-        item.x_dev.record_stream(torch.cuda.current_stream(self.device))
+        stream = torch.cuda.current_stream(self.device)
+        if item.x_dev is None:  # front end on the compute stream, in front of the step
+            audio_dev, off_dev, len_dev, lengths, frames_dev = item.audio
+            for tensor in (off_dev, len_dev, frames_dev):
+                tensor.record_stream(stream)
+            item.x_dev, _ = self.extractor.batch_device(audio_dev, off_dev, len_dev, lengths, frames_dev,
+                                                        bufs=item.slot.__dict__.setdefault("front_end_buffers", {}))
         return item
-
-    def release(self, staged):
-        pass  # nothing of the slot is read by the compute stream: x_dev is the allocator's, kept alive by record_stream
+    # release() is the base class's: the slot (audio buffer, front-end buffers incl. the spectrogram the step's
+    # sl_pack_input reads) may be refilled once everything enqueued up to the end of the step has run

@@ -108,21 +108,35 @@ class SpectrogramExtractor:
             flat[off:off + n] = a  # (casts float64 / int16-scaled-by-the-reader input to float32)
         return flat, offsets, lengths
 
-    def batch_device(self, flat_dev, off_dev, len_dev, lengths):
+    def batch_device(self, flat_dev, off_dev, len_dev, lengths, frames_dev=None, bufs=None):
         """Device half of batch(): audio already in HBM (flat float32, int64 offsets, int32 sample counts; `lengths` the
         same counts on the host).  Everything is enqueued on the CURRENT stream -- the staged input pipeline calls this
-        on its copy stream, right behind the H2D copy of the audio, so the front end of batch n + 1 runs under step n."""
+        on its copy stream, right behind the H2D copy of the audio, so the front end of batch n + 1 runs under step n.
+        bufs: a dict the caller owns (one per staging slot): intermediate and output tensors are kept there and reused, so
+        that a steady-state call allocates nothing (allocations on a side stream whose results another stream reads make
+        the caching allocator fall back to hipMalloc whenever the reader has not caught up: the staged run then jitters
+        between 69 and 86 % of the resident rate)."""
+        def tensor(name, shape, dtype):
+            n = int(np.prod(shape))
+            if bufs is None:
+                return torch.empty(shape, dtype=dtype, device=self.device)
+            flat = bufs.get(name)
+            if flat is None or flat.numel() < n or flat.dtype != dtype:
+                flat = bufs[name] = torch.empty((n,), dtype=dtype, device=self.device)
+            return flat[:n].view(shape)
+
         frames = [self.frame_count(int(n)) for n in lengths]
-        frames_dev = torch.tensor(frames, dtype=torch.int32, device=self.device)
+        if frames_dev is None:  # (a pageable H2D copy: callers on the compute stream bring it along from their copy stream)
+            frames_dev = torch.tensor(frames, dtype=torch.int32, device=self.device)
         b, t_max = len(frames), max(frames)
         rows = _round_up(t_max, TIME_TILE)  # sl_conv1d_nt reads whole time tiles
         st = torch.cuda.current_stream(self.device).cuda_stream
-        level = torch.empty((b, rows, self.bins_pad), dtype=torch.float32, device=self.device)
+        level = tensor("level", (b, rows, self.bins_pad), torch.float32)
         self.lib.call("sl_stft_power_db", flat_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), level.data_ptr(), b,
                       rows, self.n_fft, self.hop, self.bins_pad, rows * self.bins_pad, self.min_decibel, st)
         src, src_stride = level, self.bins_pad
         if self.mel_w is not None:
-            mel = torch.empty((b, rows, self.mel_pad), dtype=torch.float32, device=self.device)
+            mel = tensor("mel", (b, rows, self.mel_pad), torch.float32)
             g = ConvGeom()
             g.batch, g.t_out, g.taps, g.cin, g.cout = b, t_max, 1, self.bins_pad, self.mel_pad
             g.x_row0, g.x_row_stride, g.x_batch_stride = 0, self.bins_pad, rows * self.bins_pad
@@ -130,8 +144,8 @@ class SpectrogramExtractor:
             self.lib.call("sl_conv1d_nt", level.data_ptr(), self.mel_w.data_ptr(), None, None, mel.data_ptr(),
                           ctypes.byref(g), _lib.EPI_NONE, _lib.SL_F32, 0, 0, None, 0, st)
             src, src_stride = mel, self.mel_pad
-        out = torch.empty((b, t_max, self.features), dtype=torch.float32, device=self.device)
-        ws = torch.empty((self.lib.raw("sl_z_normalize_workspace_bytes")(b),), dtype=torch.uint8, device=self.device)
+        out = tensor("out", (b, t_max, self.features), torch.float32)
+        ws = tensor("ws", (self.lib.raw("sl_z_normalize_workspace_bytes")(b),), torch.uint8)
         self.lib.call("sl_z_normalize", src.data_ptr(), frames_dev.data_ptr(), out.data_ptr(), b, t_max, self.features,
                       src_stride, rows * src_stride, ws.data_ptr(), ws.numel(), st)
         return out, frames

@@ -25,7 +25,10 @@ def main():
     ap.add_argument("--from-audio", action="store_true",
                     help="train from RAW AUDIO (8 s per utterance = 1001 frames): samples staged, front end on the copy "
                          "stream (pipeline.AudioBatchStager); also times the front end alone")
+    ap.add_argument("--switch-interval", type=float, default=None, help="sys.setswitchinterval() for the run (experiment)")
     args = ap.parse_args()
+    if args.switch_interval:
+        sys.setswitchinterval(args.switch_interval)
     if args.from_audio:
         return from_audio(args)
     import torch
@@ -105,10 +108,11 @@ def from_audio(args):
     torch.cuda.synchronize()
     front = (time.perf_counter() - t0) / 20
 
-    def run(n):
+    def run(n, on_copy=True):
         stager = AudioBatchStager(batches[:n], net._pack_audio_for_staging, extractor,
                                   net.input_to_prediction_length_ratio, net.engine.device,
-                                  blank=net.grapheme_encoding.grapheme_set_size - 1, depth=3, workers=3)
+                                  blank=net.grapheme_encoding.grapheme_set_size - 1, depth=3, workers=3,
+                                  front_end_on_copy_stream=on_copy)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for staged in stager:
@@ -119,6 +123,8 @@ def from_audio(args):
         return dt
     run(6)
     piped = run(args.steps)
+    run(6, False)
+    piped_c = run(args.steps, False)
     eng = net.engine
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -130,6 +136,8 @@ def from_audio(args):
         32 * args.steps / resident, resident / args.steps * 1e3))
     print("from raw audio, staged (front end on the copy stream): {:8.1f} utt/s ({:.2f} ms per batch) = {:.1f} % of resident".format(
         32 * args.steps / piped, piped / args.steps * 1e3, 100 * resident / piped))
+    print("from raw audio, staged (front end on the COMPUTE stream) : {:8.1f} utt/s ({:.2f} ms per batch) = {:.1f} % of resident".format(
+        32 * args.steps / piped_c, piped_c / args.steps * 1e3, 100 * resident / piped_c))
     print("front end alone (STFT + level + mel + z-norm, 32 x 8 s in HBM): {:.3f} ms per batch = {:.0f} utt/s = {:.1f} % of a "
           "training step; H2D of the samples: {:.1f} MB per batch".format(
               front * 1e3, 32 / front, 100 * front / (resident / args.steps), flat.nbytes / 1e6))
