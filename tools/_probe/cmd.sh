@@ -1,3 +1,6 @@
-python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "every_wgrad_tile" 2>&1 | tail -3
-for L in big_conv_2 big_conv_1; do for cfg in 0 2884; do python tools/run_one.py --kind wgrad --layer $L --cfg $cfg --reps 40 2>&1 | grep -v amdgpu; done; done
-for cfg in 0 2884; do python tools/run_one.py --kind wgrad_grouped --layer inner_conv_1 --cfg $cfg --reps 40 2>&1 | grep -v amdgpu; done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu | tail -15 > gpurun_out/r03_gpu_tests.txt
+tail -3 gpurun_out/r03_gpu_tests.txt
+bash tools/profile_round.sh r03f
+tail -8 gpurun_out/r03f_e2e.txt
