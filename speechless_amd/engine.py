@@ -541,7 +541,8 @@ class Engine:
         {output_conv, big_conv_2} (17 % of the bytes, complete after the second weight gradient of the step), {big_conv_1}
         (64 %, its exchange runs under big_conv_1's input gradient and the whole inner run), the run of identical inner layers
         (one grouped weight-gradient launch at the very end of backward), then what is left (striding_conv, whose weight
-        gradient is the last kernel of backward: the only exchange nothing covers).  Frozen layers are in no bucket."""
+        gradient is the last kernel of backward: the only exchange nothing covers) -- one bucket with the run when
+        sl_conv1d_wgrad_multi writes both (_wgrad_multi_layers).  Frozen layers are in no bucket."""
         n = len(self.plans)
         first = self.frozen_layer_count
         groups = []
@@ -560,6 +561,11 @@ class Engine:
                 rest_hi = lo
         if rest_hi > first:
             groups.append(list(range(first, rest_hi)))
+        # one launch writes the weight gradients of the striding layer and of the run above it: one bucket
+        multi = self._wgrad_multi_layers(first)
+        if multi and multi[0] == 0:
+            merged = sorted(set(l for g in groups for l in g if l in multi))
+            groups = [g for g in groups if not set(g) & set(multi)] + [merged]
         plan = []
         for layers in groups:
             if layers:
@@ -1112,21 +1118,24 @@ class Engine:
         if ones_in:
             self._bias_grads_from_wgrad(ones_in, True, torch.cuda.current_stream(self.device))
 
-    def _wgrad_multi_layers(self, buf, first, grouped, on_bucket_ready):
+    def _wgrad_multi_layers(self, first, grouped=None):
         """layers whose weight gradients go into ONE sl_conv1d_wgrad_multi launch (at the lowest of them): the runs of
-        identical layers and -- single GPU only: its gradient bucket closes last -- the striding layer below them"""
+        identical layers and the striding layer below them.  The same with and without a data-parallel exchange (the step
+        is then bit-identical either way); bucket_plan() closes the striding layer's bucket together with the run's."""
+        if grouped is None:
+            grouped = self._grouped_wgrad_runs(first)
         if not self.use_wgrad_multi or self.dtype != "bf16" or not grouped:
             return []
+
+        def fits(i):
+            return self.plans[i].cin_view % 256 == 0 and self.plans[i].cout_pad % 256 == 0 and \
+                ("wgrad", self.specs[i].name) not in self.nt_cfg
         layers = sorted(grouped)
-        if on_bucket_ready is None and first == 0 and self.plans[0].spec.stride == 2 and layers[0] == 1:
+        if not all(fits(i) for i in layers) or len(layers) > 15:
+            return []
+        if first == 0 and self.plans[0].spec.stride == 2 and layers[0] == 1 and fits(0):
             layers = [0] + layers
-        ok = all(self.plans[i].cin_view % 256 == 0 and self.plans[i].cout_pad % 256 == 0 and
-                 ("wgrad", self.specs[i].name) not in self.nt_cfg for i in layers)
-        if not ok and layers[0] == 0:
-            layers = layers[1:]
-            ok = all(self.plans[i].cin_view % 256 == 0 and self.plans[i].cout_pad % 256 == 0 and
-                     ("wgrad", self.specs[i].name) not in self.nt_cfg for i in layers)
-        return layers if ok and len(layers) <= 16 else []
+        return layers
 
     def _launch_wgrad_multi(self, buf, layers, st):
         key = (tuple(layers), buf.dropped)
@@ -1155,7 +1164,7 @@ class Engine:
         first = self.frozen_layer_count
         grouped = self._grouped_wgrad_runs(first)
         dchain, dchain_skip = self._dgrad_chains(buf, first)
-        multi = self._wgrad_multi_layers(buf, first, grouped, on_bucket_ready)
+        multi = self._wgrad_multi_layers(first, grouped)
         # bias gradients out of the weight-gradient GEMM (self.ones_channel): which layers, and whether the row holds the
         # bias gradient (the ones were not touched by dropout) or only has to be zeroed before the optimizer sees it
         ones_in = self._ones_input_layers(first)

@@ -171,15 +171,19 @@ def test_bf16_gradients_at_full_length_against_the_cpu_path():
 
 
 def test_bf16_and_fp32_training_trajectories_stay_together():
-    """200 Adam(1e-4) steps on one synthetic batch of 32 utterances (128 mel x 200 frames), three runs from the same
-    data: the fp32 path, the fp32 path from initial weights perturbed by 1e-6 relative, and the bf16 path.
+    """200 Adam(1e-4) steps on one synthetic batch of 32 utterances (128 mel x 200 frames), four runs from the same
+    data: the fp32 path; the fp32 path from initial weights perturbed by 1e-6 relative (how chaotic is the optimisation
+    itself?); the fp32 path from weights perturbed by 2e-3 relative -- the size of the rounding bf16 storage applies to
+    every weight and activation (2^-9); and the bf16 path.
     Measured (tools/trajectory_probe.py): through the well-conditioned first 100 steps (loss 270 -> 62) the bf16 curve
-    stays within 7e-4 .. 2e-3 of the fp32 one; after that the optimisation itself is chaotic -- the 1e-6 perturbation of the
-    fp32 run has grown to a 10 % loss gap by step 160 and to O(1) by step 180 -- and the bf16 gap follows the same
-    envelope a small factor above it.  So: (1) bf16 within 5e-3 of fp32 at each of the first 100 steps; (2) at every
-    later step the running maximum of the bf16 gap is at most 10x that of the perturbed fp32 run (+ 2e-3), while the
-    latter is below 0.3; (3) all three runs make progress.  I.e. the gradient noise of bf16 storage is noise of the
-    size the problem already amplifies, not a bias."""
+    stays within 7e-4 .. 3e-3 of the fp32 one; after that the optimisation itself is chaotic -- the 1e-6 perturbation of the
+    fp32 run has grown to a 10 % loss gap by step 160 and to O(1) by step 180 -- and the bf16 gap follows the envelope
+    of a perturbation of its own size.  WHEN a run leaves the common curve is itself chaotic (kernel changes that only
+    alter rounding move it by ten steps), so envelopes are compared with 15 steps of slack.  So: (1) bf16 within 5e-3 of
+    fp32 at each of the first 100 steps; (2) at every step the running maximum of the bf16 gap is at most 4x what the
+    2e-3-perturbed fp32 run reaches within the next 15 steps (+ 2e-3), as long as the latter is below 0.3; (3) all runs
+    make progress.  I.e. the gradient noise of bf16 storage is noise of the size the problem already amplifies, not a
+    bias."""
     import torch
     b, t, steps = 32, 200, 200
     case = make_case(b=b, t=t, seed=77)
@@ -187,11 +191,14 @@ def test_bf16_and_fp32_training_trajectories_stay_together():
     lab_len = rng.randint(5, 31, size=b)
     labels = o.pack_label_batch([list(rng.randint(0, 28, size=n)) for n in lab_len])
     pred_len = np.full((b,), t // 2, dtype=np.int32)
-    prng = np.random.RandomState(5)
-    perturbed = [((w * (1 + 1e-6 * prng.randn(*w.shape))).astype(np.float32), bb) for w, bb in case["weights"]]
+
+    def perturbed(scale, seed):
+        prng = np.random.RandomState(seed)
+        return [((w * (1 + scale * prng.randn(*w.shape))).astype(np.float32), bb) for w, bb in case["weights"]]
+
     curves = {}
-    for name, dtype, weights in (("f32", "f32", case["weights"]), ("f32_perturbed", "f32", perturbed),
-                                 ("bf16", "bf16", case["weights"])):
+    for name, dtype, weights in (("f32", "f32", case["weights"]), ("f32_perturbed", "f32", perturbed(1e-6, 5)),
+                                 ("f32_perturbed_2e-3", "f32", perturbed(2e-3, 6)), ("bf16", "bf16", case["weights"])):
         eng = make_engine(case, dtype)
         eng.set_weights(weights)
         eng.load_input(case["x"])
@@ -199,16 +206,22 @@ def test_bf16_and_fp32_training_trajectories_stay_together():
         means = [eng.train_step_resident().mean() for _ in range(steps)]
         torch.cuda.synchronize()
         curves[name] = np.array([float(m.item()) for m in means])
-    a, p, c = curves["f32"], curves["f32_perturbed"], curves["bf16"]
+    a, p, q, c = curves["f32"], curves["f32_perturbed"], curves["f32_perturbed_2e-3"], curves["bf16"]
     gap_b = np.maximum.accumulate(np.abs(c / a - 1))
     gap_p = np.maximum.accumulate(np.abs(p / a - 1))
-    _report("trajectory_bf16_vs_f32_gap_envelope_at_steps_50_100_150_200", [float(gap_b[i]) for i in (49, 99, 149, 199)])
-    _report("trajectory_f32_perturbed_1e-6_gap_envelope_at_steps_50_100_150_200",
-            [float(gap_p[i]) for i in (49, 99, 149, 199)])
+    gap_q = np.maximum.accumulate(np.abs(q / a - 1))
+    marks = (49, 99, 149, 199)
+    _report("trajectory_bf16_vs_f32_gap_envelope_at_steps_50_100_150_200", [float(gap_b[i]) for i in marks])
+    _report("trajectory_f32_perturbed_1e-6_gap_envelope_at_steps_50_100_150_200", [float(gap_p[i]) for i in marks])
+    _report("trajectory_f32_perturbed_2e-3_gap_envelope_at_steps_50_100_150_200", [float(gap_q[i]) for i in marks])
     _report("trajectory_losses_first_100th_last", {k: [float(v[0]), float(v[99]), float(v[-1])] for k, v in curves.items()})
     assert gap_b[99] < 5e-3, gap_b[99]
-    comparable = gap_p < 0.3
-    assert np.all(gap_b[comparable] <= 10 * gap_p[comparable] + 2e-3), (gap_b[comparable], gap_p[comparable])
+    assert gap_p[99] < 1e-3 < 0.05 < gap_p[-1], gap_p[marks,]  # the optimisation amplifies 1e-6 to O(0.1 .. 1) by itself
+    ahead = gap_q[np.minimum(np.arange(steps) + 15, steps - 1)]  # what the bf16-sized perturbation reaches 15 steps on
+    comparable = ahead < 0.3
+    worst = float(np.max(gap_b[comparable] / (4 * ahead[comparable] + 2e-3)))
+    _report("trajectory_bf16_gap_over_4x_2e-3_perturbed_envelope_max", worst)
+    assert worst <= 1.0, (gap_b[comparable][::10], ahead[comparable][::10])
     for v in curves.values():
         assert v[99] < 0.3 * v[0] and v[:150].min() < 0.2 * v[0]
 

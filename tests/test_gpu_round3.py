@@ -95,9 +95,15 @@ def test_bucket_plan_covers_every_trainable_parameter_in_completion_order():
     eng = make_engine(case, "bf16")
     names = [s.name for s in eng.specs]
     plan = eng.bucket_plan()
+    # the balanced weight-gradient launch writes striding_conv and the seven inner layers: one bucket, closed by it
     assert [[names[i] for i in layers] for layers, _ in plan] == [
+        ["big_conv_2", "output_conv"], ["big_conv_1"],
+        ["striding_conv"] + ["inner_conv_{}".format(i) for i in range(1, 8)]]
+    eng.use_wgrad_multi = False  # two launches: the run's bucket leaves while striding_conv's gradient is computed
+    assert [[names[i] for i in layers] for layers, _ in eng.bucket_plan()] == [
         ["big_conv_2", "output_conv"], ["big_conv_1"], ["inner_conv_{}".format(i) for i in range(1, 8)],
         ["striding_conv"]]
+    eng.use_wgrad_multi = True
     covered = sorted(plan, key=lambda e: e[1][0])
     assert covered[0][1][0] == 0 and covered[-1][1][1] == eng.param_numel
     for (_, (_, hi)), (_, (lo, _)) in zip(covered, covered[1:]):
