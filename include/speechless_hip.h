@@ -248,7 +248,7 @@ int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* label
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Measurement / test hook: which lattice sl_ctc_loss_grad runs.  0 (default) = as described above, 1 = log-domain lattice
- * only; probability-domain lattice in doubles: 2 = without the repair launches, 3 = and then EVERY utterance redone by the
+ * only; probability-domain lattice in doubles: 2 = without the repair pass, 3 = and then EVERY utterance redone by the
  * repair pass, 4 = + repair; in floats (faster, but the repair pass is needed in some regimes: ctc.hip:WaveReal): 6 / 7 / 5
  * likewise.  Process-wide; not for concurrent use with sl_ctc_loss_grad. */
 int sl_ctc_select(int variant);

@@ -231,55 +231,106 @@ __device__ __forceinline__ float log2_of_double(double x) {
 // frame's alpha / beta loads are issued before the first one is used (one HBM/L2 round trip per frame instead of NJ).
 // LIN: the lattice comes from ctc_lattice_wave_kernel (doubles in linear units with one exponent per frame, emissions
 // u = p + eps instead of q) and is brought to log2 units on the fly; the sum of a frame's state posteriors must then be
-// 1 -- if the linear lattice lost mass to underflow it is not, and the utterance is flagged for the log-domain repair
-// pass.  only_flagged: this launch IS the repair pass (log-domain lattice): utterances that are not flagged are skipped.
+// ---- repair of one utterance inside the gradient kernel (see ctc_grad_kernel) ------------------------------------------
+// Log-domain alpha or beta lattice of utterance b by ONE work-group of 256 threads (two states per thread, S <= 512): the
+// recursion of ctc_lattice_kernel, operation for operation (same results), without its tuning -- this runs only for an
+// utterance whose linear lattice lost mass, and then on one work-group while the rest of the chip goes on.
+template <int DIR>
+__device__ void repair_lattice(const float* __restrict__ lq_b, const int* s_lab, int L, int S, int T, int t_out, int k,
+                               int blank, int sp, float* __restrict__ out, float* rows, float* loss_b) {
+    constexpr int RS = 512 + 4;  // row stride in LDS: index s + 2, two pads either side
+    const int tid = threadIdx.x;
+    int my[2];
+    bool skip[2], live[2], mine[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int st = tid + 256 * i;
+        mine[i] = st < sp;
+        live[i] = st < S;
+        my[i] = blank;
+        skip[i] = false;
+        if (live[i] && (st & 1)) {
+            my[i] = s_lab[st >> 1];
+            if (DIR == 0)
+                skip[i] = (st >= 3) && (s_lab[(st >> 1) - 1] != my[i]);
+            else
+                skip[i] = (st + 2 < S) && (s_lab[(st >> 1) + 1] != my[i]);
+        }
+    }
+    for (int i = tid; i < 2 * RS; i += 256) rows[i] = -INFINITY;
+    __syncthreads();
+    float* prev = rows;
+    float* cur = rows + RS;
+    const int tstart = DIR == 0 ? 0 : T - 1;
+    const int tstep = DIR == 0 ? 1 : -1;
+    const int nb = DIR == 0 ? -1 : 1;
+    float e[2], en[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) e[i] = lq_b[(long)tstart * k + my[i]];
+    for (int step = 0; step < T; ++step) {
+        const int t = tstart + tstep * step;
+        const int tn = tstart + tstep * (step + 1 < T ? step + 1 : step);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) en[i] = lq_b[(long)tn * k + my[i]];  // next frame's emission, a frame ahead
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int st = tid + 256 * i;
+            if (mine[i]) {
+                float v;
+                if (step == 0) {
+                    const bool init = DIR == 0 ? (st <= 1) : (st >= S - 2);
+                    v = (live[i] && init) ? e[i] * LOG2E : -INFINITY;
+                } else {
+                    const float a0 = prev[st + 2];
+                    const float a1 = prev[st + 2 + nb];
+                    const float a2 = skip[i] ? prev[st + 2 + 2 * nb] : -INFINITY;
+                    v = fmaf(e[i], LOG2E, lse3_2(a0, a1, a2));
+                    if (!live[i]) v = -INFINITY;
+                }
+                cur[st + 2] = v;
+                out[(long)t * sp + st] = v;
+            }
+            e[i] = en[i];
+        }
+        __syncthreads();
+        float* tmp = prev;
+        prev = cur;
+        cur = tmp;
+    }
+    if (DIR == 0 && tid == 0) {
+        const float last = prev[S - 1 + 2];
+        const float last2 = S >= 2 ? prev[S - 2 + 2] : -INFINITY;
+        const float m = fmaxf(last, last2);
+        const float lp2 = (m == -INFINITY) ? -INFINITY : m + log2f(exp2f(last - m) + exp2f(last2 - m));
+        *loss_b = -lp2 * LN2;
+    }
+    __syncthreads();
+}
+
+// The frames [t_begin, t_begin + frames) of utterance b, one wave per frame (the body of ctc_grad_kernel; the repair of an
+// utterance runs it a second time over ALL its frames on the log-domain lattices).
+// one wave per frame; work-group = 4 waves x FRAMES_PER_WAVE frames.  NJ = SP / 64 lattice columns per lane: all of a
+// frame's alpha / beta loads are issued before the first one is used (one HBM/L2 round trip per frame instead of NJ).
+// LIN: the lattice comes from ctc_lattice_wave_kernel (doubles in linear units with one exponent per frame, emissions
+// u = p + eps instead of q) and is brought to log2 units on the fly; the sum of a frame's state posteriors must then be
+// 1 -- if the linear lattice lost mass to underflow it is not, and the utterance is flagged for the log-domain repair.
 template <int NJ, int LIN>  // LIN: 0 = log-domain rows; 1 = linear rows in doubles (exponent blocks of 16); 2 = in floats (of 8)
-__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ probs, const float* __restrict__ logq,
-                                                       const int32_t* __restrict__ labels,
-                                                       const int32_t* __restrict__ label_len,
-                                                       const int32_t* __restrict__ input_len,
-                                                       const void* __restrict__ alpha_v, const void* __restrict__ beta_v,
-                                                       const int32_t* __restrict__ ea, const int32_t* __restrict__ eb,
-                                                       const float* __restrict__ logz2, const int32_t* __restrict__ zint,
-                                                       float* __restrict__ loss,
-                                                       const int32_t* __restrict__ cls, void* __restrict__ dlogits,
-                                                       int t_out, int k, int l_max, int sp, int blank, int frames_per_wg,
-                                                       int g_row0, int g_rs, long g_bs, int out_f32, float eps,
-                                                       float grad_scale, int32_t* __restrict__ flags,
-                                                       const int32_t* __restrict__ only_flagged) {
-    // LDS: labels[l_max] | class_pos[l_max] | class_start[k+1] | lq[4][64] | gamma[4][l_max]
-    extern __shared__ int lds_i[];
-    int* s_lab = lds_i;
-    int* s_pos = s_lab + l_max;
-    int* s_start = s_pos + l_max;
-    float* s_lq = (float*)(s_start + (k + 1));
-    float* s_gam = s_lq + 4 * 64;
-    const int b = blockIdx.y;
-    if (only_flagged != nullptr && only_flagged[b] == 0) return;
+__device__ __forceinline__ void ctc_grad_frames(
+    const float* __restrict__ probs, const float* __restrict__ logq, const void* __restrict__ alpha_v,
+    const void* __restrict__ beta_v, const int32_t* __restrict__ ea, const int32_t* __restrict__ eb,
+    const float* __restrict__ logz2, const int32_t* __restrict__ zint, const float nll, void* __restrict__ dlogits,
+    const int* s_lab, const int* s_pos, const int* s_start, float* s_lq, float* s_gam, int b, int S, int T, int t_out,
+    int k, int l_max, int sp, int blank, int t_begin, int frames_per_wg, int g_row0, int g_rs, long g_bs, int out_f32,
+    float eps, float grad_scale, int32_t* __restrict__ flags) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int L = label_len[b];
-    const int S = 2 * L + 1;
-    int T = input_len[b];
-    if (T > t_out) T = t_out;
-    const int32_t* lab = labels + (long)b * l_max;
-    const int32_t* cpos = cls + (long)b * (l_max + k + 1);
-    for (int i = tid; i < L; i += 256) {
-        s_lab[i] = lab[i];
-        s_pos[i] = cpos[i];
-    }
-    if (tid <= k) s_start[tid] = cpos[l_max + tid];
-    __syncthreads();
-
     // LIN: log2 of the partition sum in u units = zint[b] + logz2[b], integer part and fraction kept apart
     // (loss[b] = -ln Z_u - sum_t ln c_t was written by the lattice wave)
-    const float nll = loss[b];
     const bool feasible = nll < INFINITY;
     const float log_p = LIN ? logz2[b] : -nll * LOG2E;  // lattice units are log2
     float* gam = s_gam + wave * l_max;
     float* wlq = s_lq + wave * 64;
-    const int t_begin = blockIdx.x * frames_per_wg;
     for (int tt = wave; tt < frames_per_wg; tt += 4) {
         const int t = t_begin + tt;
         if (t >= t_out) break;
@@ -367,7 +418,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                 blank_part = wave_sum(blank_part);
                 if (LIN && flags != nullptr) {
                     const float total = blank_part + wave_sum(label_part);
-                    if (lane == 0 && !(fabsf(total - 1.f) < 4e-3f)) atomicOr(&flags[b], 1);
+                    if (lane == 0 && !(fabsf(total - 1.f) < 4e-3f))
+                        __hip_atomic_fetch_or(&flags[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -391,11 +443,118 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         }
         if (lane < k) {
             const long gi = (long)b * g_bs + (long)(g_row0 + t) * g_rs + lane;
+            // device-scope stores (written through this XCD's L2): the repair pass at the tail of ctc_grad_kernel may
+            // rewrite these rows from a work-group on another XCD, and a line left dirty here would land on top of it
             if (out_f32)
-                ((float*)dlogits)[gi] = dz;
+                __hip_atomic_store((float*)dlogits + gi, dz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else
-                ((unsigned short*)dlogits)[gi] = f32_to_bf16_bits(dz);
+                __hip_atomic_store((unsigned short*)dlogits + gi, f32_to_bf16_bits(dz), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// One wave per frame; work-group = 4 waves x frames_per_wg / 4 frames of one utterance.
+// only_flagged: this launch is the second pass behind the log-domain lattice of labels too long for the wave lattice -- never
+// set together with tickets.
+// tickets (with LIN): THE REPAIR PASS LIVES IN THIS KERNEL.  Every work-group of utterance b raises its done slot when its
+// frames are written; the work-group with the utterance's highest index waits for the others' slots, reads the utterance's flag
+// -- set by the lattice wave (no alignment / overflow) or by any work-group of this launch (a frame's posteriors did not
+// sum to 1) -- and, if it is set, redoes the whole utterance by itself: log-domain alpha and beta lattices into rep_alpha /
+// rep_beta (repair_lattice), the loss, then the gradient of every frame from them.  Normally no flag is set and it just
+// leaves: the two launches that used to follow (an empty log-domain lattice and an empty gradient pass, 5.5 + 5.3 us
+// every step) are gone.
+template <int NJ, int LIN>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ probs, const float* __restrict__ logq,
+                                                       const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ label_len,
+                                                       const int32_t* __restrict__ input_len,
+                                                       const void* __restrict__ alpha_v, const void* __restrict__ beta_v,
+                                                       const int32_t* __restrict__ ea, const int32_t* __restrict__ eb,
+                                                       const float* __restrict__ logz2, const int32_t* __restrict__ zint,
+                                                       float* __restrict__ loss,
+                                                       const int32_t* __restrict__ cls, void* __restrict__ dlogits,
+                                                       int t_out, int k, int l_max, int sp, int blank, int frames_per_wg,
+                                                       int g_row0, int g_rs, long g_bs, int out_f32, float eps,
+                                                       float grad_scale, int32_t* __restrict__ flags,
+                                                       const int32_t* __restrict__ only_flagged,
+                                                       int32_t* __restrict__ tickets, float* __restrict__ rep_alpha,
+                                                       float* __restrict__ rep_beta, int rep_sp) {
+    // LDS: labels[l_max] | class_pos[l_max] | class_start[k+1] | lq[4][64] | gamma[4][l_max]
+    extern __shared__ int lds_i[];
+    int* s_lab = lds_i;
+    int* s_pos = s_lab + l_max;
+    int* s_start = s_pos + l_max;
+    float* s_lq = (float*)(s_start + (k + 1));
+    float* s_gam = s_lq + 4 * 64;
+    const int b = blockIdx.y;
+    if (only_flagged != nullptr && only_flagged[b] == 0) return;
+    const int tid = threadIdx.x;
+    const int L = label_len[b];
+    const int S = 2 * L + 1;
+    int T = input_len[b];
+    if (T > t_out) T = t_out;
+    const int32_t* lab = labels + (long)b * l_max;
+    const int32_t* cpos = cls + (long)b * (l_max + k + 1);
+    for (int i = tid; i < L; i += 256) {
+        s_lab[i] = lab[i];
+        s_pos[i] = cpos[i];
+    }
+    if (tid <= k) s_start[tid] = cpos[l_max + tid];
+    __syncthreads();
+    ctc_grad_frames<NJ, LIN>(probs, logq, alpha_v, beta_v, ea, eb, logz2, zint, loss[b], dlogits, s_lab, s_pos, s_start, s_lq,
+                             s_gam, b, S, T, t_out, k, l_max, sp, blank, blockIdx.x * frames_per_wg, frames_per_wg, g_row0,
+                             g_rs, g_bs, out_f32, eps, grad_scale, flags);
+    if constexpr (LIN != 0) {
+        if (tickets == nullptr) return;
+        __shared__ int s_flag;
+        __shared__ float s_rows[2 * (512 + 4)];
+        // No fence, no shared counter and nobody waiting in the common path.  The gradient rows are device-scope stores and
+        // the flag updates device-scope atomics, complete once acknowledged: every wave waits for its own, then one
+        // thread of the work-group raises the work-group's OWN done slot (a device-scope release here writes back the
+        // whole L2 -- 2000 of them cost 60 us; tickets added to one counter per utterance serialise at 0.2-0.4 us each
+        // across the XCDs -- 11 us with returning adds, what the two launches had cost, 25 us polled).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int siblings = (int)gridDim.x - 1;
+        int32_t* slots = tickets + (long)b * gridDim.x;
+        if ((int)blockIdx.x != siblings) {
+            if (tid == 0) __hip_atomic_store(&slots[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // The work-group with the HIGHEST index of the utterance is dispatched after all its siblings (work-groups start in
+        // index order), so they are running or done when it gets here: it polls their slots -- once or twice -- and then
+        // reads the flag.  (Should the assumption ever fail the wait gives up and the loss says so; it cannot hang.)
+        int polls = 0;
+        for (;;) {
+            int done = 1;
+            for (int i = tid; i < siblings; i += 256)
+                done &= __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__syncthreads_and(done) || ++polls >= (1 << 20)) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_flag = polls >= (1 << 20) ? -1 : (__hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+        }
+        __syncthreads();
+        if (s_flag == 0 || T <= 0) return;
+        if (s_flag < 0) {
+            if (tid == 0) loss[b] = NAN;
+            return;
+        }
+        __threadfence();
+        const float* lq_b = logq + (long)b * t_out * k;
+        repair_lattice<0>(lq_b, s_lab, L, S, T, t_out, k, blank, rep_sp, rep_alpha + (long)b * t_out * rep_sp, s_rows,
+                          &loss[b]);
+        repair_lattice<1>(lq_b, s_lab, L, S, T, t_out, k, blank, rep_sp, rep_beta + (long)b * t_out * rep_sp, s_rows,
+                          &loss[b]);
+        __threadfence();  // the lattice rows and the loss, written by other threads of this work-group
+        __syncthreads();
+        const float nll = *(volatile float*)&loss[b];
+        ctc_grad_frames<8, 0>(probs, logq, rep_alpha, rep_beta, nullptr, nullptr, nullptr, nullptr, nll, dlogits, s_lab,
+                              s_pos, s_start, s_lq, s_gam, b, S, T, t_out, k, l_max, rep_sp, blank, 0, t_out, g_row0, g_rs,
+                              g_bs, out_f32, eps, grad_scale, nullptr);
     }
 }
 
@@ -410,7 +569,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 // the end; beta: one the start can reach) sits at 2^TARGET, the exponent travelling per frame; irrelevant states are
 // zeroed at the same time (they never feed relevant ones).  A state more than ~2^1500 below the relevant maximum
 // underflows; whether that lost anything is checked by the gradient kernel (sum of a frame's posteriors = 1), and a
-// flagged utterance is redone by the log-domain kernels (repair pass, normally two empty launches).
+// flagged utterance is redone in the log domain (repair pass: the tail of ctc_grad_kernel, nothing to launch).
 constexpr int WNS = 8;         // states per lane
 
 // Number type of the lattice.  double (the default): 2^+-1022 of range, rescale every 16 frames to 2^500.
@@ -723,8 +882,9 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
                                                               int32_t* __restrict__ eb, float* __restrict__ logz2,
                                                               int32_t* __restrict__ zint, float* __restrict__ loss,
                                                               int32_t* __restrict__ cls,
-                                                              int32_t* __restrict__ flags, int t_out, int k, int l_max,
-                                                              int blank, float eps) {
+                                                              int32_t* __restrict__ flags,
+                                                              int32_t* __restrict__ tickets, int grad_wgs, int t_out,
+                                                              int k, int l_max, int blank, float eps) {
     extern __shared__ int wl_lds[];  // list builder: l_max + k + 1 ints; alpha wave: 2 doubles
     const int b = blockIdx.x;
     const int dir = blockIdx.y;
@@ -732,6 +892,8 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
     const int L = label_len[b];
     if (dir == 2) {
         // per-class position lists for the gradient kernel (same as in ctc_lattice_kernel, 64 threads)
+        // the done slots of this utterance's gradient work-groups (repair pass inside ctc_grad_kernel)
+        for (int i = lane; i < grad_wgs; i += 64) tickets[(long)b * grad_wgs + i] = 0;
         int* s_lab = wl_lds;
         int* s_start = s_lab + l_max;
         int32_t* pos_out = cls + (long)b * (l_max + k + 1);
@@ -893,13 +1055,13 @@ __host__ int lattice_sp(int l_max) { return ((2 * l_max + 1) + 63) / 64 * 64; }
 // which lattice sl_ctc_loss_grad runs (sl_ctc_select): 0 = automatic -- when the labels fit (2 * l_max + 1 <= 512, k <= 63)
 // the probability-domain wave lattice in doubles with the log-domain repair pass behind it, otherwise the log-domain
 // lattice (per call at 32 x 500 frames: 108 vs 132 us; at 8 x 4000 frames 556 vs 912); 1 = log-domain lattice only; 2 =
-// double wave lattice without the repair launches (measurement); 3 = double wave lattice, then every utterance redone by
+// double wave lattice without the repair pass (measurement); 3 = double wave lattice, then every utterance redone by
 // the repair pass (tests); 4 = double wave lattice + repair; 5 / 6 / 7 = the FLOAT wave lattice with repair / without /
 // with forced repair (measurement: 87 / 463 us, but see WaveReal)
 int g_ctc_variant = 0;
 
 struct CtcLayout {
-    size_t log_alpha, log_beta, cls, lin_alpha, lin_beta, dump, ea, eb, logz2, zint, flags, total;
+    size_t log_alpha, log_beta, cls, lin_alpha, lin_beta, dump, ea, eb, logz2, zint, flags, tickets, total;
 };
 __host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
     CtcLayout w;
@@ -923,6 +1085,7 @@ __host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
     w.logz2 = take((size_t)batch * sizeof(float));
     w.zint = take((size_t)batch * sizeof(int32_t));
     w.flags = take((size_t)batch * sizeof(int32_t));
+    w.tickets = take((size_t)batch * ((t_out + 7) / 8) * sizeof(int32_t));  // one done slot per gradient work-group
     w.total = off;
     return w;
 }
@@ -1004,37 +1167,39 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
         int32_t* eb = (int32_t*)(base + w.eb);
         float* logz2 = (float*)(base + w.logz2);
         int32_t* zint = (int32_t*)(base + w.zint);
+        int32_t* tickets = (int32_t*)(base + w.tickets);
         size_t lds = (size_t)(l_max + k + 1) * sizeof(int);
         if (lds < 2 * sizeof(double) + 2 * sizeof(int)) lds = 2 * sizeof(double) + 2 * sizeof(int);
         if (wave_f32)
             hipLaunchKernelGGL(ctc_lattice_wave_kernel<float>, dim3(batch, 3), dim3(64), lds, s, probs, logq, labels,
                                label_len, input_len, (float*)la, (float*)lb, (float*)(base + w.dump), ea, eb, logz2, zint,
-                               loss, cls, flags, t_out, k, l_max, k - 1, eps);
+                               loss, cls, flags, tickets, (int)grid.x, t_out, k, l_max, k - 1, eps);
         else
             hipLaunchKernelGGL(ctc_lattice_wave_kernel<double>, dim3(batch, 3), dim3(64), lds, s, probs, logq, labels,
                                label_len, input_len, (double*)la, (double*)lb, (double*)(base + w.dump), ea, eb, logz2, zint,
-                               loss, cls, flags, t_out, k, l_max, k - 1, eps);
+                               loss, cls, flags, tickets, (int)grid.x, t_out, k, l_max, k - 1, eps);
         rc = sl_check_launch("sl_ctc_loss_grad(wave lattice)");
         if (rc != SL_OK) return rc;
-        // rows are 512 values wide; the kernel reads 8 columns per lane
+        if (force_repair) {  // tests: every utterance is redone by the repair pass inside the gradient kernel
+            rc = (int)hipMemsetAsync(flags, 1, (size_t)batch * sizeof(int32_t), s);
+            if (rc != 0) return SL_ERR_LAUNCH_FAILED;
+        }
+        // rows are 512 values wide; the kernel reads 8 columns per lane.  The repair pass is the tail of this launch
+        // (ctc_grad_kernel: the work-group that finishes an utterance last redoes it if it was flagged).
+        int32_t* rep_tickets = repair ? tickets : nullptr;
         if (wave_f32)
             hipLaunchKernelGGL((ctc_grad_kernel<8, 2>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
                                input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
                                l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
-                               eps, grad_scale, force_repair ? nullptr : flags, nullptr);
+                               eps, grad_scale, flags, nullptr, rep_tickets, alpha, beta, sp);
         else
             hipLaunchKernelGGL((ctc_grad_kernel<8, 1>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
                                input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
                                l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
-                               eps, grad_scale, force_repair ? nullptr : flags, nullptr);
-        rc = sl_check_launch("sl_ctc_loss_grad(grad)");
-        if (rc != SL_OK || !repair) return rc;
-        if (force_repair) {  // tests: redo everything
-            rc = (int)hipMemsetAsync(flags, 1, (size_t)batch * sizeof(int32_t), s);
-            if (rc != 0) return SL_ERR_LAUNCH_FAILED;
-        }
+                               eps, grad_scale, flags, nullptr, rep_tickets, alpha, beta, sp);
+        return sl_check_launch("sl_ctc_loss_grad(grad)");
     }
-    const int32_t* only = wave ? flags : nullptr;
+    const int32_t* only = nullptr;  // labels beyond the wave lattice: the log-domain lattice for every utterance
     const int threads = sp;  // multiple of 64, >= S
     size_t lds = 2 * (threads + 4) * sizeof(float);
     const size_t lds_lists = (size_t)(l_max + k + 1) * sizeof(int);
@@ -1048,7 +1213,7 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
                        input_len, (const void*)alpha, (const void*)beta, nullptr, nullptr, nullptr, nullptr, loss, cls,   \
                        dlogits,                                                                                        \
                        t_out, k, l_max, sp, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,  \
-                       eps, grad_scale, nullptr, only)
+                       eps, grad_scale, nullptr, only, nullptr, nullptr, nullptr, 0)
     if (sp <= 256) {
         SL_CTC_GRAD(4);
     } else if (sp <= 512) {

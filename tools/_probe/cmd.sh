@@ -1,3 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python tools/_probe/garbage_probe.py 2>&1 | grep -v amdgpu | tail -20
+timeout 1200 python -m pytest tests -m gpu -q -x -k "ctc or lattice or repair or golden or loss" 2>&1 | grep -v amdgpu | tail -15
+timeout 300 python tools/ctc_time.py 2>&1 | grep -v amdgpu | tail -12
+timeout 600 python bench.py --no-cpu-baseline --no-also | cut -c1-400

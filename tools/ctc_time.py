@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Times sl_ctc_loss_grad alone (lattice + gradient [+ repair launches]) at a BASELINE shape, per lattice variant.
+"""Times sl_ctc_loss_grad alone (lattice + gradient [+ repair pass]) at a BASELINE shape, per lattice variant.
     python tools/ctc_time.py [--batch 32] [--frames 500] [--lmax 200]        (SL_LIB_PATH selects a probe build)"""
 import argparse
 import sys
@@ -49,9 +49,9 @@ def main():
     need = lib.raw("sl_ctc_workspace_bytes")(b, t, args.lmax)
     ws = torch.empty((need,), dtype=torch.uint8, device=dev)
     ref = None
-    for variant, name in ((1, "log-domain lattice"), (2, "wave lattice (double), no repair launches"),
-                          (4, "wave lattice (double) + repair launches"), (6, "wave lattice (float), no repair launches"),
-                          (5, "wave lattice (float) + repair launches"), (0, "automatic (bf16 output)")):
+    for variant, name in ((1, "log-domain lattice"), (2, "wave lattice (double), no repair pass"),
+                          (4, "wave lattice (double) + repair pass"), (6, "wave lattice (float), no repair pass"),
+                          (5, "wave lattice (float) + repair pass"), (0, "automatic (bf16 output)")):
         lib.call("sl_ctc_select", variant)
 
         def run():
