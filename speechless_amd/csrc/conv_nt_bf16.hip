@@ -1552,17 +1552,22 @@ Cfg auto_cfg(const sl_conv_geom* g) {
         // un-interleaved, 0.372 for the 16-wave tap-major kernel); 1x1 layers: the same 8-wave tile, tap-major,
         // interleaved (big_conv_2 forward 0.104 ms = 1.24 PFLOP/s, 0.107 for the 16-wave kernel)
         if (tiles256 >= 192) return slab_ok ? Cfg{2, 4, 10, 1, 8, 0, 0, 1, 1} : Cfg{2, 4, 10, 1, 8, 0, 0, 0, 1};
-        if (nsteps >= 256) {  // long contraction but few tiles (dgrad of big_conv_1: 64 tiles, K = 65536): split K
+        if (nsteps >= 192) {  // long contraction but few tiles (dgrad of big_conv_1: 64 tiles, K = 65536): split K
             // among the split counts that divide the chunks (whole chunks per split, the slab kernel's requirement) take
-            // the one with the least (rounds of 256 work-groups) x (steps per split); ties go to the smaller split
+            // the one with the least (rounds of 256 work-groups) x (steps per split + 35); ties go to the smaller split
             // (less partial-tile traffic).  B = 48: 96 tiles -> 2 splits (192 work-groups), not 3 (288 = two rounds).
+            // The 35 steps stand for a work-group's prologue, its fp32 partial tile and the epilogue pass over it --
+            // fitted to config 5's shapes, where the counts differ most: striding_conv on 640 pair channels (240 steps;
+            // 48 / 80 / 120 tiles -> 5 / 2 / 2 splits: 0.100 / 0.173 / 0.199 ms against 0.103 / 0.229 / 0.260 ms on 128 x
+            // 128 tiles, and 0.154 / 0.185 / 0.263 ms for the other count), big_conv_1's input gradient (1024 steps; 80 /
+            // 120 tiles -> 8 / 2 splits: 0.570 / 0.688 ms against 0.603 / 0.792 ms).
             const long chunks = g->cin / BK;
             int best = 1;
             double best_cost = 1e30;
             for (int ks = 1; ks <= 8; ++ks) {
                 if (chunks % ks) continue;
                 const double rounds = (double)((tiles256 * ks + 255) / 256);
-                const double cost = rounds / ks;
+                const double cost = rounds * ((double)nsteps / ks + 35.0);
                 if (cost < best_cost - 1e-9) {
                     best_cost = cost;
                     best = ks;

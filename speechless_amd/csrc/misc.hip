@@ -34,16 +34,32 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// one wave per input row (b, t): 64 consecutive bins per load (coalesced for any bin count -- 257 as well as 128), all
+// loads of two rows in flight before the first store; 32-bit index arithmetic, one division per row
 template <typename T>
-__global__ void pack_input_kernel(const float* __restrict__ src, T* __restrict__ dst, int t_in, int f, int dst_row0,
-                                  int dst_rs, long dst_bs, long total) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % f);
-    const long r = i / f;
-    const int t = (int)(r % t_in);
-    const long b = r / t_in;
-    dst[b * dst_bs + (long)(dst_row0 + t) * dst_rs + c] = cvt_out<T>(src[i]);
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, T* __restrict__ dst, int t_in,
+                                                         int f, int dst_row0, int dst_rs, long dst_bs, long rows) {
+    constexpr int ROWS = 2, COLS = 8;  // per wave and pass; bins beyond 64 * COLS go through the tail loop
+    const int lane = threadIdx.x & 63;
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    float v[ROWS][COLS];
+    T* dp[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        const long r = r0 + q < rows ? r0 + q : rows - 1;  // (a duplicate of the last row: same values, same place)
+        const long b = r / t_in;
+        const int t = (int)(r - b * t_in);
+        const float* sp = src + r * f;
+        dp[q] = dst + b * dst_bs + (long)(dst_row0 + t) * dst_rs;
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) v[q][k] = lane + 64 * k < f ? sp[lane + 64 * k] : 0.f;
+        for (int c = lane + 64 * COLS; c < f; c += 64) dp[q][c] = cvt_out<T>(sp[c]);
+    }
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+        for (int k = 0; k < COLS; ++k)
+            if (lane + 64 * k < f) dp[q][lane + 64 * k] = cvt_out<T>(v[q][k]);
 }
 
 // stage 1: partial[b][co] = sum_t g[b][row0+t][co]; block = 256 threads = 16 column-groups(8 ch) x 16 row lanes
@@ -372,8 +388,8 @@ extern "C" int sl_pack_weights(const float* w_master, void* w_fwd, void* w_dgrad
 extern "C" int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,
                              int64_t dst_batch_stride, int dtype, void* stream) {
     SL_CHECK_ARG(batch > 0 && t_in > 0 && f > 0 && dst_row_stride >= f, "sl_pack_input: bad sizes");
-    const long total = (long)batch * t_in * f;
-    const unsigned grid = (unsigned)((total + 255) / 256);
+    const long total = (long)batch * t_in;  // rows; 8 per work-group
+    const unsigned grid = (unsigned)((total + 7) / 8);
     if (dtype == SL_BF16)
         hipLaunchKernelGGL((pack_input_kernel<unsigned short>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src,
                            (unsigned short*)dst, t_in, f, dst_row0, dst_row_stride, (long)dst_batch_stride, total);

@@ -22,12 +22,13 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--bins", type=int, default=128, help="input bins (257: config 5)")
     args = ap.parse_args()
     import torch
     from speechless_amd import _lib
     from speechless_amd.engine import Engine, wav2letter_layer_specs
 
-    specs = wav2letter_layer_specs(128, 29)
+    specs = wav2letter_layer_specs(args.bins, 29)
     eng = Engine(specs, 29, dtype="bf16")
     rng = np.random.RandomState(0)
     weights = []
@@ -36,7 +37,7 @@ def main():
         weights.append((rng.uniform(-limit, limit, size=(s.kernel_size, s.cin, s.cout)).astype(np.float32),
                         rng.uniform(-0.05, 0.05, size=(s.cout,)).astype(np.float32)))
     eng.set_weights(weights)
-    x = rng.randn(args.batch, args.frames, 128).astype(np.float32)
+    x = rng.randn(args.batch, args.frames, args.bins).astype(np.float32)
     lab_len = rng.randint(20, 201, size=args.batch)
     labels = -np.ones((args.batch, 200), dtype=np.int32)
     for i, n in enumerate(lab_len):
