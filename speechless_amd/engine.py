@@ -436,6 +436,7 @@ class Engine:
         # whose (tile, 64-frame step) space is cut into one equal range per CU (sl_conv1d_wgrad_multi) instead of a grouped
         # launch + a 128 x 128-tile launch with utterance-granular batch splits.  SL_WGRAD_MULTI=0: those launches.
         self.use_wgrad_multi = os.environ.get("SL_WGRAD_MULTI", "1") != "0"
+        self.small_bias_pass_on_main = os.environ.get("SL_BIAS_MAIN", "1") != "0"  # A/B knob
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
         # Launch lists: the ~60 C-ABI calls and 4 stream hand-overs of a step are recorded the first time a buffer set
         # runs them and replayed afterwards with their arguments already marshalled -- the Python around each launch
@@ -966,7 +967,7 @@ class Engine:
         # launch list: not with dropout (its scale passes take the rate by value)
         key = None if buf.dropped else ("bwd", main.cuda_stream, on_bucket_ready is not None, self.ones_channel,
                                         self.frozen_layer_count, self.group_wgrad, self.use_chain, self.fuse_output_backward,
-                                        self.use_wgrad_multi,
+                                        self.use_wgrad_multi, self.small_bias_pass_on_main,
                                         tuple(sorted(self.nt_cfg.items())))
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
@@ -1177,7 +1178,18 @@ class Engine:
         side_busy = [False]
 
         def flush_bias_passes(pending):
-            """sl_bias_grad passes of the layers in `pending` (their g is complete at this point of MAIN) on SIDE"""
+            """sl_bias_grad passes of the layers in `pending` (their g is complete at this point of MAIN) on SIDE -- a lone
+            small pass (the first layer's 8 MB, the only one left beside the ones channel) on MAIN: two hand-overs cost the
+            main stream 6.5 us each (rocprof timeline), the pass itself 9"""
+            if len(pending) == 1 and buf.g[pending[0]].numel() * buf.g[pending[0]].element_size() <= (32 << 20) \
+                    and self.small_bias_pass_on_main:
+                j = pending[0]
+                _, db_j = self.layer_param_views(self.grads, self.plans[j])
+                self._launch("bgrad:" + self.plans[j].spec.name, "sl_bias_grad", buf.g[j].data_ptr(), db_j.data_ptr(),
+                             ctypes.byref(buf.wgrad_geom[j]), self.dtype_code, buf.bias_ws.data_ptr(),
+                             buf.bias_ws.numel(), main.cuda_stream)
+                del pending[:]
+                return
             self._hand_over(main, side)
             with torch.cuda.stream(side):
                 for j in pending:

@@ -1,53 +1,65 @@
+#!/usr/bin/env python
+"""Interleaved same-box A/B of the resident config-3 training step over one Engine attribute.
+
+    python tools/step_ab.py --attr small_bias_pass_on_main [--reps 6] [--steps 40]
+    attributes: small_bias_pass_on_main, use_wgrad_multi, fuse_output_backward, use_chain, ones_channel, group_wgrad
+Boxes differ by +-4 %, a change of 0.5 % shows only when both settings alternate on the SAME box within one process."""
+import argparse
+import statistics
 import sys
 from pathlib import Path
+
 import numpy as np
+
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-import torch
-from speechless_amd.engine import Engine, wav2letter_layer_specs
-specs = wav2letter_layer_specs(128, 29)
-eng = Engine(specs, 29, dtype="bf16")
-rng = np.random.RandomState(0)
-ws = []
-for s in specs:
-    lim = np.sqrt(6.0 / (s.kernel_size * (s.cin + s.cout)))
-    ws.append((rng.uniform(-lim, lim, size=(s.kernel_size, s.cin, s.cout)).astype(np.float32), np.zeros(s.cout, np.float32)))
-eng.set_weights(ws)
-B = 32
-x = rng.randn(B, 1000, 128).astype(np.float32)
-lab_len = rng.randint(20, 201, size=B)
-labels = -np.ones((B, 200), dtype=np.int32)
-for i, n in enumerate(lab_len):
-    labels[i, :n] = rng.randint(0, 28, size=n)
-eng.load_input(x)
-eng.set_labels(labels, lab_len, np.full(B, 500))
-import statistics
-def timed(steps=40):
-    for _ in range(3): eng.train_step_resident()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(steps): eng.train_step_resident()
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / steps
-real_adam = eng._adam_layers
-real_launch = eng._launch
-def no_bias(tag, name, *args):
-    if name == "sl_bias_grad": return
-    real_launch(tag, name, *args)
-def only_conv(tag, name, *args):
-    if name in ("sl_bias_grad", "sl_ctc_loss_grad", "sl_softmax_logq"): return
-    real_launch(tag, name, *args)
-variants = {
-    "A default (Adam after backward, bias grads on side stream)": dict(early=False, adam=True, launch=real_launch, ow=False),
-    "C no adam": dict(early=False, adam=False, launch=real_launch, ow=False),
-    "D no bias grads": dict(early=False, adam=True, launch=no_bias, ow=False),
-    "F convs only": dict(early=False, adam=False, launch=only_conv, ow=False),
-}
-res = {k: [] for k in variants}
-for rep in range(4):
-    for k, v in variants.items():
-        eng._adam_layers = real_adam if v["adam"] else (lambda layers, st: None)
-        eng._launch = v["launch"]
-        res[k].append(timed())
-for k, v in res.items():
-    print("%-62s median %.4f  min %.4f  all %s" % (k, statistics.median(v), min(v), [round(x, 3) for x in v]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--attr", required=True)
+    ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=40)
+    args = ap.parse_args()
+    import torch
+    from speechless_amd.engine import Engine, wav2letter_layer_specs
+    from speechless_amd.net import Wav2Letter
+    specs = wav2letter_layer_specs(128, 29)
+    eng = Engine(specs, 29, dtype="bf16")
+    eng.set_weights(Wav2Letter._glorot_uniform(specs, 2))
+    rng = np.random.RandomState(0)
+    b = 32
+    x = rng.randn(b, 1000, 128).astype(np.float32)
+    lab_len = rng.randint(20, 201, size=b)
+    labels = -np.ones((b, 200), dtype=np.int32)
+    for i, n in enumerate(lab_len):
+        labels[i, :n] = rng.randint(0, 28, size=n)
+    eng.load_input(x)
+    eng.set_labels(labels, lab_len, np.full(b, 500))
+    assert isinstance(getattr(eng, args.attr), bool), args.attr
+
+    def timed():
+        for _ in range(4):
+            eng.train_step_resident()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            eng.train_step_resident()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.steps
+
+    res = {True: [], False: []}
+    for _ in range(args.reps):
+        for value in (True, False):
+            setattr(eng, args.attr, value)
+            res[value].append(timed())
+    for value in (True, False):
+        v = res[value]
+        print("{} = {!s:5}  median {:.4f} ms  min {:.4f}  all {}".format(args.attr, value, statistics.median(v), min(v),
+                                                                      [round(t, 3) for t in v]))
+    print("difference of medians (True - False): {:+.4f} ms".format(statistics.median(res[True]) - statistics.median(res[False])))
+
+
+if __name__ == "__main__":
+    main()
