@@ -13,72 +13,109 @@ namespace {
 
 constexpr int FFT_MAX = 1024;
 
-// One 64-lane work-group per (frame, utterance): reflect-padded, Hann-windowed frame -> in-place radix-2 decimation-in-
-// time FFT in LDS (input written in bit-reversed order) -> |X_k|^2 -> dB with floor -> row t of the output.
-__global__ __launch_bounds__(64) void stft_power_db_kernel(const float* __restrict__ audio,
-                                                          const long* __restrict__ offsets,
-                                                          const int* __restrict__ lengths, float* __restrict__ out,
-                                                          int n_fft, int log2n, int hop, int row_stride,
-                                                          long batch_stride, float min_db) {
-    __shared__ float re[FFT_MAX];
-    __shared__ float im[FFT_MAX];
-    __shared__ float twr[FFT_MAX / 2];
+// FRAMES_PER_WG frames of one utterance per work-group of four waves, one wave per frame at a time.
+// The window and the twiddle factors are computed once per work-group (they were 768 sincospi per FRAME: most of the 126 us
+// the first version of this kernel took for 32 x 1001 frames).  The n_fft real samples of a frame go through a COMPLEX FFT of
+// half the length (z[n] = x[2n] + i x[2n+1]; radix-2 decimation in time in the wave's own LDS buffer, input written in
+// bit-reversed order, a lone wave's LDS operations execute in order: no barrier) and are split into the spectrum of the
+// real sequence afterwards:  X[k] = (Z[k] + conj Z[N/2-k]) / 2  -  i/2 e^{-2 pi i k/N} (Z[k] - conj Z[N/2-k]),  k = 0 .. N/2.
+// -> |X_k|^2 -> dB with floor -> row t of the output.
+constexpr int FRAMES_PER_WG = 16;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(256) void stft_power_db_kernel(const float* __restrict__ audio,
+                                                           const long* __restrict__ offsets,
+                                                           const int* __restrict__ lengths, float* __restrict__ out,
+                                                           int n_fft, int log2n, int hop, int row_stride,
+                                                           long batch_stride, float min_db, int max_frames) {
+    __shared__ float win[FFT_MAX];          // periodic Hann window
+    __shared__ float twr[FFT_MAX / 2];      // e^{-2 pi i k / n_fft}, k < n_fft / 2
     __shared__ float twi[FFT_MAX / 2];
-    const int lane = threadIdx.x;
-    const int t = blockIdx.x;
+    __shared__ float zre[4][FFT_MAX / 2];   // one half-length complex buffer per wave
+    __shared__ float zim[4][FFT_MAX / 2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int len = lengths[b];
     const int n_frames = 1 + len / hop;
-    const int bins = n_fft / 2 + 1;
-    float* row = out + (long)b * batch_stride + (long)t * row_stride;
-    if (t >= n_frames) {  // frames beyond this utterance: zero rows (the batch is padded with zeros, net.py:583)
-        for (int k = lane; k < row_stride; k += 64) row[k] = 0.f;
-        return;
+    const int half = n_fft / 2;  // length of the complex transform; bins = half + 1
+    const int log2h = log2n - 1;
+    for (int n = tid; n < n_fft; n += 256) {
+        float sn, cs;
+        sincospif(2.f * (float)n / (float)n_fft, &sn, &cs);
+        win[n] = 0.5f - 0.5f * cs;
     }
-    const float* y = audio + offsets[b];
-    const int half = n_fft / 2;
-    for (int n = lane; n < n_fft; n += 64) {
-        int idx = t * hop + n - half;          // center=True: the frame is centred on sample t * hop
-        if (idx < 0) idx = -idx;               // np.pad(mode="reflect"): edge sample not repeated
-        if (idx >= len) idx = 2 * (len - 1) - idx;
-        float s, c;
-        sincospif(2.f * (float)n / (float)n_fft, &s, &c);
-        const float w = 0.5f - 0.5f * c;       // periodic Hann window
-        const int r = (int)(__brev((unsigned)n) >> (32 - log2n));
-        re[r] = w * y[idx];
-        im[r] = 0.f;
-    }
-    for (int k = lane; k < half; k += 64) {
-        float s, c;
-        sincospif(-2.f * (float)k / (float)n_fft, &s, &c);
-        twr[k] = c;
-        twi[k] = s;
+    for (int k = tid; k < half; k += 256) {
+        float sn, cs;
+        sincospif(-2.f * (float)k / (float)n_fft, &sn, &cs);
+        twr[k] = cs;
+        twi[k] = sn;
     }
     __syncthreads();
-    for (int s = 1; s <= log2n; ++s) {
-        const int m = 1 << s, mh = m >> 1, tstep = n_fft >> s;
-        for (int j = lane; j < half; j += 64) {
-            const int pos = j & (mh - 1);
-            const int i0 = ((j >> (s - 1)) << s) + pos;
-            const int i1 = i0 + mh;
-            const float wr = twr[pos * tstep], wi = twi[pos * tstep];
-            const float xr = re[i1], xi = im[i1];
-            const float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
-            const float ur = re[i0], ui = im[i0];
-            re[i0] = ur + tr;
-            im[i0] = ui + ti;
-            re[i1] = ur - tr;
-            im[i1] = ui - ti;
+    const float* y = audio + offsets[b];
+    float* re = zre[wave];
+    float* im = zim[wave];
+    const int t_first = blockIdx.x * FRAMES_PER_WG;
+    for (int q = wave; q < FRAMES_PER_WG; q += 4) {
+        const int t = t_first + q;
+        if (t >= max_frames) break;
+        float* row = out + (long)b * batch_stride + (long)t * row_stride;
+        if (t >= n_frames) {  // frames beyond this utterance: zero rows (the batch is padded with zeros, net.py:583)
+            for (int k = lane; k < row_stride; k += 64) row[k] = 0.f;
+            continue;
         }
-        __syncthreads();
-    }
-    for (int k = lane; k < row_stride; k += 64) {
-        float v = 0.f;
-        if (k < bins) {
-            const float p = re[k] * re[k] + im[k] * im[k];
-            v = p == 0.f ? min_db : fmaxf(10.f * log10f(p), min_db);
+        for (int n = lane; n < half; n += 64) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int idx = t * hop + 2 * n + e - half;  // center=True: the frame is centred on sample t * hop
+                if (idx < 0) idx = -idx;               // np.pad(mode="reflect"): edge sample not repeated
+                if (idx >= len) idx = 2 * (len - 1) - idx;
+                v[e] = win[2 * n + e] * y[idx];
+            }
+            const int r = (int)(__brev((unsigned)n) >> (32 - log2h));
+            re[r] = v[0];
+            im[r] = v[1];
         }
-        row[k] = v;  // padded lanes are zero: the mel projection contracts over the padded row
+        wave_lds_sync();
+        for (int s = 1; s <= log2h; ++s) {
+            const int mh = 1 << (s - 1), tstep = n_fft >> s;  // twiddle e^{-2 pi i pos / 2^s} = table[pos * n_fft / 2^s]
+            for (int j = lane; j < half / 2; j += 64) {
+                const int pos = j & (mh - 1);
+                const int i0 = ((j >> (s - 1)) << s) + pos;
+                const int i1 = i0 + mh;
+                const float wr = twr[pos * tstep], wi = twi[pos * tstep];
+                const float xr = re[i1], xi = im[i1];
+                const float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
+                const float ur = re[i0], ui = im[i0];
+                re[i0] = ur + tr;
+                im[i0] = ui + ti;
+                re[i1] = ur - tr;
+                im[i1] = ui - ti;
+            }
+            wave_lds_sync();
+        }
+        for (int k = lane; k < row_stride; k += 64) {
+            float v = 0.f;
+            if (k <= half) {
+                const int ka = k & (half - 1), kb = (half - k) & (half - 1);
+                const float ar = re[ka], ai = im[ka], br = re[kb], bi = -im[kb];  // Z[k], conj Z[N/2 - k]
+                const float er = 0.5f * (ar + br), ei = 0.5f * (ai + bi);
+                const float dr = 0.5f * (ar - br), di = 0.5f * (ai - bi);         // (Z[k] - conj Z[N/2-k]) / 2
+                const float orr = di, oi = -dr;                                     // times -i
+                const float wr = k == half ? -1.f : twr[ka], wi = k == half ? 0.f : twi[ka];
+                const float xr = er + wr * orr - wi * oi, xi = ei + wr * oi + wi * orr;
+                const float p = xr * xr + xi * xi;
+                v = p == 0.f ? min_db : fmaxf(10.f * log10f(p), min_db);
+            }
+            row[k] = v;  // padded lanes are zero: the mel projection contracts over the padded row
+        }
+        wave_lds_sync();  // the buffer is rewritten by the wave's next frame
     }
 }
 
@@ -106,9 +143,10 @@ __global__ __launch_bounds__(256) void znorm_partial_kernel(const float* __restr
     const double mean = PASS == 1 ? znorm_mean(part, b, n) : 0.0;
     const float* base = src + (long)b * batch_stride;
     double acc = 0.0;
-    const long m = (long)max(t1 - t0, 0) * f;
-    for (long i = threadIdx.x; i < m; i += 256) {
-        const double v = (double)base[(t0 + i / f) * (long)row_stride + (i % f)];
+    const int m = max(t1 - t0, 0) * f;  // (a chunk of one utterance: well inside 32 bits)
+    for (int i = threadIdx.x; i < m; i += 256) {
+        const int q = i / f, c = i - q * f;
+        const double v = (double)base[(long)(t0 + q) * row_stride + c];
         acc += PASS == 0 ? v : (v - mean) * (v - mean);
     }
     sh[threadIdx.x] = acc;
@@ -124,20 +162,29 @@ __global__ __launch_bounds__(256) void znorm_partial_kernel(const float* __restr
 __global__ __launch_bounds__(256) void znorm_apply_kernel(const float* __restrict__ src, const int* __restrict__ frames,
                                                           const double* __restrict__ part, float* __restrict__ dst,
                                                           int max_frames, int f, int row_stride, long batch_stride) {
+    __shared__ double stats[2];  // mean, 1 / standard deviation: once per work-group (they were 64 loads per ELEMENT)
     const int b = blockIdx.y;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)max_frames * f) return;
-    const int t = (int)(i / f), c = (int)(i % f);
-    float v = 0.f;
-    if (t < frames[b]) {
-        const long n = (long)frames[b] * f;
-        const double mean = znorm_mean(part, b, n);
+    const int rows = frames[b];
+    if (threadIdx.x == 0) {
+        const long n = (long)rows * f;
+        const double mean = n > 0 ? znorm_mean(part, b, n) : 0.0;
         double sq = 0.0;
         for (int j = 0; j < ZCH; ++j) sq += part[((long)b * 2 + 1) * ZCH + j];
-        const double sd = sqrt(sq / (double)n);
-        v = (float)(((double)src[(long)b * batch_stride + (long)t * row_stride + c] - mean) / sd);
+        stats[0] = mean;
+        stats[1] = n > 0 ? sqrt(sq / (double)n) : 1.0;
     }
-    dst[((long)b * max_frames + t) * f + c] = v;
+    __syncthreads();
+    const double mean = stats[0], sd = stats[1];
+    // work-group = ZROWS rows of the utterance; a thread walks its columns
+    constexpr int ZROWS = 8;
+    const int t0 = blockIdx.x * ZROWS;
+    const int nrows = min(ZROWS, max_frames - t0);
+    const float* sb = src + (long)b * batch_stride;
+    float* db = dst + (long)b * max_frames * f;
+    for (int i = threadIdx.x; i < nrows * f; i += 256) {
+        const int q = i / f, c = i - q * f, t = t0 + q;
+        db[(long)t * f + c] = t < rows ? (float)(((double)sb[(long)t * row_stride + c] - mean) / sd) : 0.f;
+    }
 }
 
 }  // namespace
@@ -153,8 +200,9 @@ extern "C" int sl_stft_power_db(const float* audio, const int64_t* offsets, cons
                  "sl_stft_power_db: n_fft = %d must be a power of two in [64, %d]", n_fft, FFT_MAX);
     SL_CHECK_ARG(row_stride >= n_fft / 2 + 1 && batch_stride >= (int64_t)max_frames * row_stride,
                  "sl_stft_power_db: output rows are too short for %d bins", n_fft / 2 + 1);
-    hipLaunchKernelGGL(stft_power_db_kernel, dim3(max_frames, batch), dim3(64), 0, (hipStream_t)stream, audio,
-                       (const long*)offsets, lengths, out, n_fft, log2n, hop, row_stride, (long)batch_stride, min_db);
+    hipLaunchKernelGGL(stft_power_db_kernel, dim3((max_frames + FRAMES_PER_WG - 1) / FRAMES_PER_WG, batch), dim3(256), 0,
+                       (hipStream_t)stream, audio, (const long*)offsets, lengths, out, n_fft, log2n, hop, row_stride,
+                       (long)batch_stride, min_db, max_frames);
     return sl_check_launch("sl_stft_power_db");
 }
 
@@ -179,8 +227,7 @@ extern "C" int sl_z_normalize(const float* src, const int32_t* frames, float* ds
                        src_row_stride, (long)src_batch_stride);
     int rc = sl_check_launch("sl_z_normalize(stats)");
     if (rc != SL_OK) return rc;
-    const long n = (long)max_frames * f;
-    hipLaunchKernelGGL(znorm_apply_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, s, src, frames,
+    hipLaunchKernelGGL(znorm_apply_kernel, dim3((unsigned)((max_frames + 7) / 8), batch), dim3(256), 0, s, src, frames,
                        (const double*)workspace, dst, max_frames, f, src_row_stride, (long)src_batch_stride);
     return sl_check_launch("sl_z_normalize(apply)");
 }
