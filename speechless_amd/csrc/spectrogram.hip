@@ -28,22 +28,24 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+__device__ __forceinline__ float2 cmul(float2 w, float2 x) { return make_float2(w.x * x.x - w.y * x.y, w.x * x.y + w.y * x.x); }
+
 __global__ __launch_bounds__(256) void stft_power_db_kernel(const float* __restrict__ audio,
                                                            const long* __restrict__ offsets,
                                                            const int* __restrict__ lengths, float* __restrict__ out,
                                                            int n_fft, int log2n, int hop, int row_stride,
                                                            long batch_stride, float min_db, int max_frames) {
-    __shared__ float win[FFT_MAX];          // periodic Hann window
-    __shared__ float twr[FFT_MAX / 2];      // e^{-2 pi i k / n_fft}, k < n_fft / 2
-    __shared__ float twi[FFT_MAX / 2];
-    __shared__ float zre[4][FFT_MAX / 2];   // one half-length complex buffer per wave
-    __shared__ float zim[4][FFT_MAX / 2];
+    // LDS (12 KB at n_fft = 512 -> eight work-groups = 32 waves per CU): tw float2[half] | z float2[4][half] | win float[n_fft]
+    extern __shared__ float2 stft_lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int len = lengths[b];
     const int n_frames = 1 + len / hop;
     const int half = n_fft / 2;  // length of the complex transform; bins = half + 1
+    float2* tw = stft_lds;                         // e^{-2 pi i k / n_fft}, k < n_fft / 2
+    float2* zbuf = tw + half;                      // one half-length complex buffer per wave
+    float* win = (float*)(zbuf + 4 * half);        // periodic Hann window
     const int log2h = log2n - 1;
     for (int n = tid; n < n_fft; n += 256) {
         float sn, cs;
@@ -53,13 +55,11 @@ __global__ __launch_bounds__(256) void stft_power_db_kernel(const float* __restr
     for (int k = tid; k < half; k += 256) {
         float sn, cs;
         sincospif(-2.f * (float)k / (float)n_fft, &sn, &cs);
-        twr[k] = cs;
-        twi[k] = sn;
+        tw[k] = make_float2(cs, sn);
     }
     __syncthreads();
     const float* y = audio + offsets[b];
-    float* re = zre[wave];
-    float* im = zim[wave];
+    float2* z = zbuf + wave * half;
     const int t_first = blockIdx.x * FRAMES_PER_WG;
     for (int q = wave; q < FRAMES_PER_WG; q += 4) {
         const int t = t_first + q;
@@ -78,25 +78,39 @@ __global__ __launch_bounds__(256) void stft_power_db_kernel(const float* __restr
                 if (idx >= len) idx = 2 * (len - 1) - idx;
                 v[e] = win[2 * n + e] * y[idx];
             }
-            const int r = (int)(__brev((unsigned)n) >> (32 - log2h));
-            re[r] = v[0];
-            im[r] = v[1];
+            z[(int)(__brev((unsigned)n) >> (32 - log2h))] = make_float2(v[0], v[1]);
         }
         wave_lds_sync();
-        for (int s = 1; s <= log2h; ++s) {
-            const int mh = 1 << (s - 1), tstep = n_fft >> s;  // twiddle e^{-2 pi i pos / 2^s} = table[pos * n_fft / 2^s]
+        // two radix-2 stages per pass over the buffer, the four points of a pair of butterflies held in registers (the
+        // arithmetic of the plain radix-2 recursion, half its LDS round trips and index arithmetic)
+        int s = 1;
+        for (; s + 1 <= log2h; s += 2) {
+            const int lq = s - 1, L = 1 << lq;  // quarter of the block this pass completes
+            const int st1 = n_fft >> s, st2 = n_fft >> (s + 1);
+            for (int j = lane; j < half / 4; j += 64) {
+                const int pos = j & (L - 1);
+                const int base = ((j >> lq) << (s + 1)) + pos;
+                const float2 a0 = z[base], a1 = z[base + L], a2 = z[base + 2 * L], a3 = z[base + 3 * L];
+                const float2 w1 = tw[pos * st1], w2 = tw[pos * st2], w3 = tw[(pos + L) * st2];
+                const float2 u1 = cmul(w1, a1), u3 = cmul(w1, a3);
+                const float2 b0 = make_float2(a0.x + u1.x, a0.y + u1.y), b1 = make_float2(a0.x - u1.x, a0.y - u1.y);
+                const float2 b2 = make_float2(a2.x + u3.x, a2.y + u3.y), b3 = make_float2(a2.x - u3.x, a2.y - u3.y);
+                const float2 v2 = cmul(w2, b2), v3 = cmul(w3, b3);
+                z[base] = make_float2(b0.x + v2.x, b0.y + v2.y);
+                z[base + 2 * L] = make_float2(b0.x - v2.x, b0.y - v2.y);
+                z[base + L] = make_float2(b1.x + v3.x, b1.y + v3.y);
+                z[base + 3 * L] = make_float2(b1.x - v3.x, b1.y - v3.y);
+            }
+            wave_lds_sync();
+        }
+        if (s <= log2h) {  // an odd number of stages: the last one alone
+            const int mh = 1 << (s - 1), tstep = n_fft >> s;
             for (int j = lane; j < half / 2; j += 64) {
                 const int pos = j & (mh - 1);
                 const int i0 = ((j >> (s - 1)) << s) + pos;
-                const int i1 = i0 + mh;
-                const float wr = twr[pos * tstep], wi = twi[pos * tstep];
-                const float xr = re[i1], xi = im[i1];
-                const float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
-                const float ur = re[i0], ui = im[i0];
-                re[i0] = ur + tr;
-                im[i0] = ui + ti;
-                re[i1] = ur - tr;
-                im[i1] = ui - ti;
+                const float2 u = z[i0], x = cmul(tw[pos * tstep], z[i0 + mh]);
+                z[i0] = make_float2(u.x + x.x, u.y + x.y);
+                z[i0 + mh] = make_float2(u.x - x.x, u.y - x.y);
             }
             wave_lds_sync();
         }
@@ -104,14 +118,15 @@ __global__ __launch_bounds__(256) void stft_power_db_kernel(const float* __restr
             float v = 0.f;
             if (k <= half) {
                 const int ka = k & (half - 1), kb = (half - k) & (half - 1);
-                const float ar = re[ka], ai = im[ka], br = re[kb], bi = -im[kb];  // Z[k], conj Z[N/2 - k]
-                const float er = 0.5f * (ar + br), ei = 0.5f * (ai + bi);
-                const float dr = 0.5f * (ar - br), di = 0.5f * (ai - bi);         // (Z[k] - conj Z[N/2-k]) / 2
+                const float2 a = z[ka], c = z[kb];                                  // Z[k]; conj Z[N/2 - k] = (c.x, -c.y)
+                const float er = 0.5f * (a.x + c.x), ei = 0.5f * (a.y - c.y);
+                const float dr = 0.5f * (a.x - c.x), di = 0.5f * (a.y + c.y);       // (Z[k] - conj Z[N/2-k]) / 2
                 const float orr = di, oi = -dr;                                     // times -i
-                const float wr = k == half ? -1.f : twr[ka], wi = k == half ? 0.f : twi[ka];
-                const float xr = er + wr * orr - wi * oi, xi = ei + wr * oi + wi * orr;
-                const float p = xr * xr + xi * xi;
-                v = p == 0.f ? min_db : fmaxf(10.f * log10f(p), min_db);
+                const float2 w = k == half ? make_float2(-1.f, 0.f) : tw[ka];
+                const float xr = er + w.x * orr - w.y * oi, xi = ei + w.x * oi + w.y * orr;
+                const float pw = xr * xr + xi * xi;
+                // 10 log10 p = (10 / log2 10) log2 p on the native base-2 logarithm
+                v = pw == 0.f ? min_db : fmaxf(3.0102999566398120f * __log2f(pw), min_db);
             }
             row[k] = v;  // padded lanes are zero: the mel projection contracts over the padded row
         }
@@ -200,7 +215,8 @@ extern "C" int sl_stft_power_db(const float* audio, const int64_t* offsets, cons
                  "sl_stft_power_db: n_fft = %d must be a power of two in [64, %d]", n_fft, FFT_MAX);
     SL_CHECK_ARG(row_stride >= n_fft / 2 + 1 && batch_stride >= (int64_t)max_frames * row_stride,
                  "sl_stft_power_db: output rows are too short for %d bins", n_fft / 2 + 1);
-    hipLaunchKernelGGL(stft_power_db_kernel, dim3((max_frames + FRAMES_PER_WG - 1) / FRAMES_PER_WG, batch), dim3(256), 0,
+    const size_t lds = (size_t)(n_fft / 2) * 5 * sizeof(float2) + (size_t)n_fft * sizeof(float);
+    hipLaunchKernelGGL(stft_power_db_kernel, dim3((max_frames + FRAMES_PER_WG - 1) / FRAMES_PER_WG, batch), dim3(256), lds,
                        (hipStream_t)stream, audio, (const long*)offsets, lengths, out, n_fft, log2n, hop, row_stride,
                        (long)batch_stride, min_db, max_frames);
     return sl_check_launch("sl_stft_power_db");
