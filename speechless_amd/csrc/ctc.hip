@@ -586,11 +586,11 @@ template <typename R>
 struct WaveReal;
 template <>
 struct WaveReal<double> {
-    static constexpr int TARGET = 500, RESCALE = 16, SHIFT_MAX = 400;
+    static constexpr int TARGET = 0, RESCALE = 16, SHIFT_MAX = 400, FLOOR = 180;
 };
 template <>
 struct WaveReal<float> {
-    static constexpr int TARGET = 8, RESCALE = 8, SHIFT_MAX = 126;
+    static constexpr int TARGET = 8, RESCALE = 8, SHIFT_MAX = 126, FLOOR = 1 << 20;  // (no floor: see above)
 };
 constexpr int WRESCALE = 16;   // frames of one straight-line block (two prefetch chunks)
 
@@ -738,10 +738,27 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
         // A lane that holds nothing yet takes over the exponent of the neighbour its first mass will come from -- once
         // per block, not per frame: in RB frames mass moves at most 2 RB states = RB / 4 lanes (skip transitions), so
         // RB / 4 + 1 rounds of "empty lane <- neighbour" cover every lane that can be reached before the next rescale.
+        // ... and a lane that holds SOMETHING, but more than 2^FLOOR below that neighbour's level, is lifted to within
+        // 2^FLOOR of it (its own values shrink accordingly, at worst to zero).  Behind a net that has learnt its labels
+        // the mass ahead of the alignment's front pays eps at every frame the front does not -- lanes ahead fall
+        // thousands of binades below the lane the front is in, and when the front crossed into them the exponent
+        // difference exceeded what a double holds (TARGET 500 / no floor: overflow four lanes on, NaN loss, every utterance
+        // through the repair pass at 0.9 ms per call from the first epoch that fits anything).  Legitimate spreads are
+        // bounded by the eps floor on the emissions: four labels per lane = 2^106 between neighbours; the front crosses
+        // at most RB / 4 + 1 lanes per block: 5 x 180 + 25 binades of growth stay inside a double above TARGET = 2^0.
+        // (Only a neighbour that holds mass sets a level: the lanes the recursion has left behind for good are zero and
+        // keep whatever exponent they had.)
+        const int e_own = E;
+        const int zsrc = DIR == 0 ? dpp_int_from_lower_lane(lane_zero ? 1 : 0, 1) : dpp_int_from_upper_lane(lane_zero ? 1 : 0, 1);
 #pragma unroll
         for (int round = 0; round < RB / 4 + 1; ++round) {
             const int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
-            E = lane_zero ? en : E;
+            E = lane_zero ? en : (zsrc ? E : max(E, en - WaveReal<R>::FLOOR));
+        }
+        if (WaveReal<R>::FLOOR < (1 << 19)) {
+            const int lift = lane_zero ? 0 : E - e_own;  // >= 0
+#pragma unroll
+            for (int j = 0; j < WNS; ++j) a[j] = wave_ldexp(a[j], -lift);
         }
         const int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
         fscale = wave_ldexp((R)1, max(min(en - E, WaveReal<R>::SHIFT_MAX), -4 * WaveReal<R>::SHIFT_MAX));
@@ -949,6 +966,9 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
         for (int t = lane; t < T; t += 64)
             csum += logq[((long)b * t_out + t) * k + blank] - logf(pr[(long)t * k + blank] + eps);
         csum = wave_sum(csum);
+        float repeats_f = 0.f;  // equal neighbours in the label: each needs a blank in between
+        for (int i = lane + 1; i < L; i += 64) repeats_f += lab[i] == lab[i - 1] ? 1.f : 0.f;
+        const int repeats = (int)wave_sum(repeats_f);
 #if defined(SL_PROBE_CTC_CLOCK)
         const long long probe_t0 = clock64();
 #endif
@@ -982,8 +1002,10 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
             zint[b] = xz + ez;
             // -ln Z_u in double: the integer part is in the tens of thousands for a long utterance
             loss[b] = z > 0.0 ? (float)(-((double)(xz + ez) + (double)frac) * 0.6931471805599453 - (double)csum) : INFINITY;
-            // no alignment at all, or every one of them underflowed: the log-domain repair pass tells which
-            flags[b] = (z > 0.0 && z < INFINITY) ? 0 : 1;  // (NaN / inf: the float lattice overflowed)
+            // Z = 0: no alignment at all (more labels, plus a blank between equal neighbours, than frames: known without
+            // any lattice, the loss is +inf and the gradient kernel's convention for it needs no lattice either), or every
+            // alignment underflowed: that one goes to the log-domain repair pass.  NaN / inf: the float lattice overflowed.
+            flags[b] = (z > 0.0 && z < INFINITY) ? 0 : (z == 0.0 && L + repeats > T ? 0 : 1);
 #if defined(SL_PROBE_CTC_CLOCK)  // timing probe: s_memtime ticks per frame of the alpha recursion instead of the loss
             loss[b] = (float)(clock64() - probe_t0) / (float)T;
 #endif

