@@ -1,3 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python tools/overfit_run.py 2>&1 | grep -v amdgpu | tee gpurun_out/r03_overfit_run.txt | tail -18
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu | tail -15 > gpurun_out/r03_gpu_tests.txt
+grep -n "passed\|failed" gpurun_out/r03_gpu_tests.txt
+bash tools/profile_round.sh r03h
+tail -8 gpurun_out/r03h_e2e.txt
