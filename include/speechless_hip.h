@@ -237,9 +237,11 @@ int sl_output_softmax(const void* x, const void* w, const float* bias, float* pr
  * Two lattice kernels: with labels of up to 255 graphemes and k <= 63 a probability-domain one (one wave per utterance
  * and direction, eight lattice states per lane, block floating point with one exponent per lane and 8 / 16 frames, no
  * transcendental, no LDS exchange and no barrier on the T'-long sequential path) in doubles; the gradient kernel then
- * checks every frame's posteriors against 1, and an utterance that lost mass to underflow is redone by the second kernel:
- * the log-domain one (one thread per lattice state, LDS row exchange + barrier per frame), which also serves longer
- * labels.  Results agree to fp32 round-off.
+ * checks every frame's posteriors against 1, and an utterance that lost mass to underflow is redone in the log domain by
+ * the last work-group of the same launch (no further launches; none of the regimes of a training run -- near-uniform
+ * start, blank collapse, a net that has learnt its labels -- needs it).  Labels beyond 255 graphemes go through the
+ * log-domain lattice kernel (one thread per lattice state, LDS row exchange + barrier per frame).  Results agree to fp32
+ * round-off.
  */
 size_t sl_ctc_workspace_bytes(int batch, int t_out, int l_max);
 int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* labels, const int32_t* label_len,
