@@ -183,17 +183,19 @@ class AudioBatchStager(BatchStager):
     reference-style LabeledExample objects (labeled_example.py:74-140: `.get_raw_audio()`, `.label`); the worker threads
     read the audio, the H2D copy moves SAMPLES (512 bytes per 128-sample hop: the same bytes per frame as a 128-mel float32
     spectrogram) and the front end -- STFT, power level, mel projection, z-normalisation (speechless_amd/spectrogram.py) --
-    runs on the copy stream right behind it, under the training step of the previous batch.  The spectrogram never exists
-    on the host.  pack(batch) -> (raw audio list, label_batch, label_lengths); prediction lengths follow from the frame
+    runs in HBM: by default on the compute stream in front of the step that consumes it (0.13 ms per 32 x 8 s since round 3:
+    92 % of the resident-input rate), optionally on the copy stream right behind the copy, beside the training step of the
+    previous batch (90 %: the step's kernels and the front end's then share the CUs and the power budget; it was the better
+    choice while the front end took 0.26 ms).  The spectrogram never exists on the host.  pack(batch) -> (raw audio list, label_batch, label_lengths); prediction lengths follow from the frame
     counts."""
 
     def __init__(self, batches, pack, extractor, length_ratio, device, blank, depth=3, workers=3, spare_slots=5,
-                 front_end_on_copy_stream=True):
+                 front_end_on_copy_stream=False):
         super().__init__(batches, pack, device, blank, depth=depth, workers=workers, spare_slots=spare_slots)
         self.extractor = extractor
         self.length_ratio = length_ratio
-        # False: only the samples travel on the copy stream; the front end runs on the COMPUTE stream in front of the step
-        # that consumes it (measurement variant: the big MFMA kernels leave a side stream's kernels no room on the CUs)
+        # False (default): only the samples travel on the copy stream; the front end runs on the COMPUTE stream in front of
+        # the step that consumes it.  True: on the copy stream, under the previous step.
         self.front_end_on_copy_stream = front_end_on_copy_stream
         self.front_end_events = []  # optional (start, stop) timing events per batch, see time_front_end
 

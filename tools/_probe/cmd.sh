@@ -1,6 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu | tail -15 > gpurun_out/r03_gpu_tests.txt
-grep -n "passed\|failed" gpurun_out/r03_gpu_tests.txt
-bash tools/profile_round.sh r03h
-tail -8 gpurun_out/r03h_e2e.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -4
+timeout 600 python -m pytest tests/test_spectrogram.py -m gpu -q 2>&1 | grep -v amdgpu | tail -2
+timeout 600 python tools/e2e_train_throughput.py --from-audio --steps 100 2>&1 | grep -v amdgpu | tail -4
