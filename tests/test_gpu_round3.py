@@ -108,8 +108,8 @@ def _aligned_logits(rng, labels_list, t, k, strength, noise=1.0):
     return lg
 
 
-@pytest.mark.parametrize("strength", [12.0, 20.0, 35.0])
-def test_ctc_wave_lattice_needs_no_repair_once_the_net_has_learnt_its_labels(hip_lib, strength):
+@pytest.mark.parametrize("strength,mismatch", [(12.0, 0.0), (20.0, 0.0), (35.0, 0.0), (20.0, 0.3), (35.0, 1.0)])
+def test_ctc_wave_lattice_needs_no_repair_once_the_net_has_learnt_its_labels(hip_lib, strength, mismatch):
     """The regime every successful training run ENDS in: p ~ 1 along one alignment, every other symbol at the eps floor.
     The mass ahead of the alignment's front then pays eps at every frame the front does not and falls thousands of binades
     below it; round 2's lattice (rows rescaled to 2^500, no bound between neighbouring lanes' exponents) overflowed when
@@ -117,9 +117,10 @@ def test_ctc_wave_lattice_needs_no_repair_once_the_net_has_learnt_its_labels(hip
     from the first epoch that fits anything (found with tools/e2e_train_throughput.py --steps 150: the resident step went
     from 2.1 to 2.9 ms once the loss had fallen).  With the exponent floor between neighbouring lanes (ctc.hip: FLOOR) the
     double lattice handles it alone: variant 2 (no repair pass at all) matches the float64 oracle, and the default gives
-    bit-identical results (the repair pass, had it run, would have replaced them with the fp32 log-domain lattice's)."""
+    bit-identical results (the repair pass, had it run, would have replaced them with the fp32 log-domain lattice's).
+    mismatch > 0: the net is sure of a transcript that disagrees with the label in that fraction of its graphemes."""
     from test_gpu_parity import run_ctc_kernel
-    rng = np.random.RandomState(int(strength))
+    rng = np.random.RandomState(int(strength) + int(100 * mismatch))
     k, t = 29, 500
     lab_len = [200, 150, 97, 20, 180, 1]
     labels_list = [list(rng.randint(0, 28, size=n)) for n in lab_len]
@@ -127,6 +128,12 @@ def test_ctc_wave_lattice_needs_no_repair_once_the_net_has_learnt_its_labels(hip
     labels = o.pack_label_batch(labels_list)
     input_len = [t] * len(lab_len)
     logits = _aligned_logits(rng, labels_list, t, k, strength)
+    if mismatch:  # ... and is WRONG about this fraction of the graphemes: sure of a transcript the label disagrees with
+        for lab in labels_list:
+            for j in range(len(lab)):
+                if rng.rand() < mismatch:
+                    lab[j] = int((lab[j] + 1 + rng.randint(0, 27)) % 28)
+        labels = o.pack_label_batch(labels_list)
     ref_p = o.softmax(logits.astype(np.float64))
     ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
     ref_dl = o.softmax_backward(ref_p, ref_dp)
@@ -146,7 +153,7 @@ def test_ctc_wave_lattice_needs_no_repair_once_the_net_has_learnt_its_labels(hip
         # op keeps them: absolute 2e-4 (+ relative 1e-5)
         assert np.all(np.abs(loss - ref_loss) < 2e-4 + 1e-5 * np.abs(ref_loss)), (variant, loss - ref_loss)
         assert np.abs(dl - ref_dl).max() < 2e-5, (variant, np.abs(dl - ref_dl).max())
-    _report("ctc_learnt_regime_strength_{}_loss_abs_err_and_gradient_max_abs_err".format(int(strength)),
+    _report("ctc_learnt_regime_strength_{}_mismatch_{}_loss_abs_err_and_gradient_max_abs_err".format(int(strength), mismatch),
             [float(np.abs(results[0][0] - ref_loss).max()), float(np.abs(results[0][1] - ref_dl).max()),
              float(np.abs(results[1][1] - ref_dl).max())])  # (last: the fp32 log-domain lattice, for comparison)
     assert np.array_equal(results[0][0], results[2][0]) and np.array_equal(results[0][1], results[2][1])

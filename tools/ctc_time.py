@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--aligned", type=float, default=0.0,
                     help="> 0: the regime of a net that has LEARNT its labels -- this is added to the logit of the symbol a "
                          "random valid alignment of each label puts on a frame (20: p ~ 1 on the path, 1e-9 elsewhere)")
+    ap.add_argument("--mismatch", type=float, default=0.0,
+                    help="with --aligned: this fraction of each label is replaced by other graphemes AFTER the logits were "
+                         "built -- the net is sure of a transcript that is partly wrong")
     ap.add_argument("--ragged", action="store_true", help="input lengths U{frames/4 .. frames} instead of all = frames")
     args = ap.parse_args()
     import torch
@@ -56,6 +59,10 @@ def main():
                 lg[i, lo, sym] += args.aligned
                 lg[i, lo + 1:hi, k - 1] += args.aligned  # hold with blanks
         logits = torch.tensor(lg, device=dev)
+        if args.mismatch > 0:
+            for i, n in enumerate(lab_len):
+                wrong = rng.rand(n) < args.mismatch
+                labels[i, :n] = np.where(wrong, (labels[i, :n] + 1 + rng.randint(0, k - 2, size=n)) % (k - 1), labels[i, :n])
     lab = torch.tensor(labels, device=dev)
     ll = torch.tensor(lab_len, device=dev)
     il = torch.full((b,), t, dtype=torch.int32, device=dev)
