@@ -1,2 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_round3.py -m gpu -q -k "learnt" 2>&1 | grep -v amdgpu | grep "^E  \|passed\|failed" | cut -c1-300 | tail -12
+mkdir -p gpurun_out
+timeout 600 python tools/power_probe.py 2>&1 | grep -v amdgpu | tee gpurun_out/r03_power_probe.txt | tail -20
