@@ -223,6 +223,10 @@ int sl_softmax_logq(const float* logits, float* probs, float* logq, int batch, i
  *   (otherwise use sl_conv1d_nt + sl_softmax_logq).
  */
 int sl_output_softmax_supported(const sl_conv_geom* geom, int k, int dtype);
+/* Measurement / test hook: which kernel sl_output_softmax runs.  0 (default) = automatic: the weights in REGISTERS (each of
+ * the four waves of a work-group owns a quarter of the input channels and its own LDS-DMA ring; cin = 256 ... 2048) where
+ * that applies, else in LDS; 1 = always the LDS kernel; 2 = as 0.  Process-wide. */
+int sl_output_softmax_select(int variant);
 int sl_output_softmax(const void* x, const void* w, const float* bias, float* probs, float* logq, float* logits,
                       const sl_conv_geom* geom, int k, int logit_stride, int64_t logit_batch_stride, float eps, int dtype,
                       void* stream);

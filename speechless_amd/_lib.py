@@ -64,6 +64,7 @@ SIGNATURES = {
     "sl_version": (c_int, []),
     "sl_profile_next_kernel": (c_int, [c_void_p, c_void_p]),
     "sl_output_softmax_supported": (c_int, [POINTER(ConvGeom), c_int, c_int]),
+    "sl_output_softmax_select": (c_int, [c_int]),
     "sl_output_softmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int,
                                   c_int, c_int64, c_float, c_int, c_void_p]),
     "sl_last_error": (c_char_p, []),

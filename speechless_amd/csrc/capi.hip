@@ -74,6 +74,12 @@ bool output_softmax_supported(const sl_conv_geom* g, int k);
 int output_softmax_bf16(const void* x, const void* w, const float* bias, float* probs, float* logq, float* logits,
                         const sl_conv_geom* g, int k, int logit_stride, long logit_batch_stride, float eps, hipStream_t s);
 
+int output_softmax_select(int variant);
+extern "C" int sl_output_softmax_select(int variant) {
+    SL_CHECK_ARG(variant >= 0 && variant <= 2, "sl_output_softmax_select: variant %d outside 0..2", variant);
+    return output_softmax_select(variant);
+}
+
 extern "C" int sl_output_softmax_supported(const sl_conv_geom* geom, int k, int dtype) {
     if (!geom || dtype != SL_BF16 || geom->batch <= 0 || geom->t_out <= 0 || geom->cin <= 0) return 0;
     return output_softmax_supported(geom, k) ? 1 : 0;

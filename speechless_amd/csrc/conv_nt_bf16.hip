@@ -1200,6 +1200,68 @@ __global__ __launch_bounds__(512, 2) void conv_nt_ks2_bf16_kernel(NtArgs a) {
     }
 }
 
+// Softmax tail shared by the two fused output-layer kernels.  Lane (g, i) holds, for time row t0 + wave * 16 + i, the logits
+// of classes tile * 16 + 4 g + r in acc[tile][r] (bias not yet added).
+__device__ __forceinline__ void output_softmax_finish(const f32x4 (&acc)[2], const float* __restrict__ bias,
+                                                      float* __restrict__ probs, float* __restrict__ logq,
+                                                      float* __restrict__ logits, int b, int t0, int wave, int lane, int g,
+                                                      int t_out, int k, int logit_stride, long logit_batch_stride,
+                                                      float eps) {
+    // ---- lane (g, i): time row t0 + wave*16 + i, classes tile*16 + 4g + r.  Softmax over the k valid classes of the row:
+    // 8 values here, the rest in the three lanes that differ in g (lane ^ 16, lane ^ 32).
+    const int t = t0 + wave * 16 + (lane & 15);
+    float z[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cls = j * 16 + 4 * g + r;
+            z[j * 4 + r] = cls < k ? acc[j][r] + bias[cls] : -INFINITY;
+            m = fmaxf(m, z[j * 4 + r]);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float e[8], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = z[i] == -INFINITY ? 0.f : expf(z[i] - m);
+        sum += e[i];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    // q = (p + eps) / sum_j (p_j + eps), computed the way TF does: log-softmax of u = log(p + eps)   (sl_softmax_logq)
+    float u[8], um = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = e[i] / sum;
+        u[i] = z[i] == -INFINITY ? -INFINITY : logf(e[i] + eps);
+        um = fmaxf(um, u[i]);
+    }
+    um = fmaxf(um, __shfl_xor(um, 16));
+    um = fmaxf(um, __shfl_xor(um, 32));
+    float usum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) usum += u[i] == -INFINITY ? 0.f : expf(u[i] - um);
+    usum += __shfl_xor(usum, 16);
+    usum += __shfl_xor(usum, 32);
+    const float lz = um + logf(usum);
+    if (t < t_out) {
+        const long f = (long)b * t_out + t;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cls = j * 16 + 4 * g + r;
+                if (cls < k) {
+                    probs[f * k + cls] = e[j * 4 + r];
+                    logq[f * k + cls] = u[j * 4 + r] - lz;
+                    if (logits) logits[(long)b * logit_batch_stride + (long)t * logit_stride + cls] = z[j * 4 + r];
+                }
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Output layer: 1x1 convolution onto k <= 32 classes fused with the softmax and the log(p + eps) re-normalisation that
 // sl_softmax_logq computes.  As an NT launch this layer is a 128x128 tile of which three quarters is channel padding
@@ -1293,59 +1355,120 @@ __global__ __launch_bounds__(256, 1) void output_softmax_kernel(const __bf16* __
         slot = (slot + 1 == SLOTS) ? 0 : slot + 1;
     }
 
-    // ---- lane (g, i): time row t0 + wave*16 + i, classes tile*16 + 4g + r.  Softmax over the k valid classes of the row:
-    // 8 values here, the rest in the three lanes that differ in g (lane ^ 16, lane ^ 32).
-    const int t = t0 + wave * 16 + (lane & 15);
-    float z[8];
-    float m = -INFINITY;
+    output_softmax_finish(acc, bias, probs, logq, logits, b, t0, wave, lane, g, t_out, k, logit_stride, logit_batch_stride, eps);
+}
+
+// The same layer with the WEIGHTS IN REGISTERS (round 3).  With the weight matrix in LDS (119 KiB of 160) the ring above is
+// five 8 KiB slots -- 32 KiB in flight per CU, one barrier per 64-channel step: 22.7 us for the 67 MB of config 3 = 3 TB/s.
+// Here the contraction is split over the four waves of the work-group: wave w owns input channels [w cin/4, (w+1) cin/4) of
+// all 64 time rows, its slice of the weights (32 classes x cin/4 bf16 = 32 KiB at cin = 2048) sits in 128 VGPRs as MFMA
+// fragments for the whole launch, and the wave streams exactly the activation bytes it consumes itself through its own
+// ring of four 8 KiB slots (LDS-DMA, counted vmcnt): no barrier in the loop, 128 KiB in flight per CU.  The four partial
+// 64 x 32 logit tiles meet once, in LDS, summed in wave order (deterministic); wave w then finishes rows 16 w .. 16 w + 15.
+// NSTEP = cin / 256 (64-channel steps per wave).
+template <int NSTEP>
+__global__ __launch_bounds__(256, 1) void output_softmax_regw_kernel(const __bf16* __restrict__ x,
+                                                                     const __bf16* __restrict__ w,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ probs, float* __restrict__ logq,
+                                                                     float* __restrict__ logits, int batch, int t_out,
+                                                                     int t_tiles, int w_rs, int x_row0, int x_rs, long x_bs,
+                                                                     int k, int logit_stride, long logit_batch_stride,
+                                                                     float eps) {
+    constexpr int BM = 64, SLOT_BYTES = BM * 128, SLOTS = NSTEP < 4 ? NSTEP : 4, DPS = 8;  // DMA instructions per step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const int b = blockIdx.x / t_tiles;
+    const int t0 = (blockIdx.x - b * t_tiles) * BM;
+    const int ch0 = wave * (NSTEP * 64);  // this wave's channel slice
+    char* ring = smem + wave * (SLOTS * SLOT_BYTES);
+    const __bf16* xbase = x + (long)b * x_bs + (long)(x_row0 + t0) * x_rs + ch0;
+    // DMA: instruction q of a step moves rows 8 q .. 8 q + 7 (lane >> 3 = row, lane & 7 = 16-byte slot holding logical
+    // piece (lane & 7) ^ row: the fragment reads below find piece p of row r at slot p ^ (r & 7))
+    const int xoff0 = (lane >> 3) * x_rs + (((lane & 7) ^ (lane >> 3)) << 3);
+    auto request = [&](int step, int slot) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < DPS; ++q)
+            glds16(xbase + step * 64 + q * 8 * x_rs + xoff0, ring + slot * SLOT_BYTES + q * 1024);
+    };
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cls = j * 16 + 4 * g + r;
-            z[j * 4 + r] = cls < k ? acc[j][r] + bias[cls] : -INFINITY;
-            m = fmaxf(m, z[j * 4 + r]);
+    for (int i = 0; i < SLOTS; ++i) request(i, i);
+    // weight fragments: class tile j, 32-channel piece q of the slice: lane holds w[16 j + (lane & 15)][ch0 + 32 q + 8 g ..+8]
+    bf16x8 wf[2][2 * NSTEP];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cls = j * 16 + (lane & 15);
+        const __bf16* wr = w + (long)(cls < k ? cls : 0) * w_rs + ch0 + g * 8;
+#pragma unroll
+        for (int q = 0; q < 2 * NSTEP; ++q) {
+            const u32x4 v = *(const u32x4*)(wr + q * 32);
+            const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
+            wf[j][q] = __builtin_bit_cast(bf16x8, cls < k ? v : z);
         }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float e[8], sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        e[i] = z[i] == -INFINITY ? 0.f : expf(z[i] - m);
-        sum += e[i];
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    // q = (p + eps) / sum_j (p_j + eps), computed the way TF does: log-softmax of u = log(p + eps)   (sl_softmax_logq)
-    float u[8], um = -INFINITY;
+    f32x4 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        e[i] = e[i] / sum;
-        u[i] = z[i] == -INFINITY ? -INFINITY : logf(e[i] + eps);
-        um = fmaxf(um, u[i]);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = (unsigned)(size_t)ring;
+    const unsigned boff = lds0 + (lane & 15) * 128 + ((g ^ (lane & 7)) << 4);  // + row tile * 2048, ^ 64 for the second k-half
+    // the weight loads are ordinary vector-memory loads in front of the younger DMA requests: vmcnt counts both in order,
+    // so waiting for a step's DMA also waits for them
+#if defined(SL_PROBE_SM_NOLOOP)  // timing probe (wrong results): prologue + exchange + softmax only
+    wait_vmcnt<0>();
+#else
+#pragma unroll
+    for (int c = 0; c < NSTEP; ++c) {
+        const int slot = c % SLOTS;
+        // requests issued so far: min(NSTEP, c + SLOTS) steps; step c has landed once at most (issued - c - 1) steps remain
+        const int after = (c + SLOTS < NSTEP ? c + SLOTS : NSTEP) - c - 1;
+        if (after == 3) wait_vmcnt<3 * DPS>();
+        else if (after == 2) wait_vmcnt<2 * DPS>();
+        else if (after == 1) wait_vmcnt<1 * DPS>();
+        else wait_vmcnt<0>();
+        bf16x8 bfr[8];
+        const unsigned b_addr = boff + slot * SLOT_BYTES;
+        ds_read128<0>(bfr[0], b_addr);
+        ds_read128<2048>(bfr[1], b_addr);
+        ds_read128<4096>(bfr[2], b_addr);
+        ds_read128<6144>(bfr[3], b_addr);
+        ds_read128<0>(bfr[4], b_addr ^ 64);
+        ds_read128<2048>(bfr[5], b_addr ^ 64);
+        ds_read128<4096>(bfr[6], b_addr ^ 64);
+        ds_read128<6144>(bfr[7], b_addr ^ 64);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]), "+v"(bfr[4]), "+v"(bfr[5]), "+v"(bfr[6]),
+                       "+v"(bfr[7]));
+        if (c + SLOTS < NSTEP) request(c + SLOTS, slot);  // the slot's bytes are in registers now
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2 * c + h], bfr[4 * h + i], acc[i][j], 0, 0, 0);
     }
-    um = fmaxf(um, __shfl_xor(um, 16));
-    um = fmaxf(um, __shfl_xor(um, 32));
-    float usum = 0.f;
+#endif
+    // ---- the four waves' partial tiles meet in LDS (the rings are drained): part[wave][row tile][class tile][lane] f32x4
+    __syncthreads();
+    f32x4* part = (f32x4*)smem;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) usum += u[i] == -INFINITY ? 0.f : expf(u[i] - um);
-    usum += __shfl_xor(usum, 16);
-    usum += __shfl_xor(usum, 32);
-    const float lz = um + logf(usum);
-    if (t < t_out) {
-        const long f = (long)b * t_out + t;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) part[((wave * 4 + i) * 2 + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+    f32x4 sum[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cls = j * 16 + 4 * g + r;
-                if (cls < k) {
-                    probs[f * k + cls] = e[j * 4 + r];
-                    logq[f * k + cls] = u[j * 4 + r] - lz;
-                    if (logits) logits[(long)b * logit_batch_stride + (long)t * logit_stride + cls] = z[j * 4 + r];
-                }
-            }
+    for (int j = 0; j < 2; ++j) {
+        sum[j] = part[((0 * 4 + wave) * 2 + j) * 64 + lane];
+#pragma unroll
+        for (int p = 1; p < 4; ++p) sum[j] += part[((p * 4 + wave) * 2 + j) * 64 + lane];
     }
+    output_softmax_finish(sum, bias, probs, logq, logits, b, t0, wave, lane, g, t_out, k, logit_stride, logit_batch_stride, eps);
 }
 
 // split-K tail: out = epi(sum_split partial), 8 channels per thread, fixed summation order
@@ -1781,8 +1904,39 @@ bool output_softmax_supported(const sl_conv_geom* g, int k) {
     return ((k * (g->cin * 2 + 16) + 127) & ~127) + 3 * 64 * 128 <= 160 * 1024;
 }
 
+static int g_output_softmax_variant = 0;  // sl_output_softmax_select: 0 = automatic, 1 = weights in LDS, 2 = weights in registers
+int output_softmax_select(int variant) {
+    g_output_softmax_variant = variant;
+    return SL_OK;
+}
+
+template <int NSTEP>
+static int launch_output_softmax_regw(const void* x, const void* w, const float* bias, float* probs, float* logq,
+                                      float* logits, const sl_conv_geom* g, int k, int logit_stride,
+                                      long logit_batch_stride, float eps, hipStream_t s) {
+    constexpr int SLOTS = NSTEP < 4 ? NSTEP : 4;
+    constexpr int LDS = (4 * SLOTS * 64 * 128) > 32768 ? (4 * SLOTS * 64 * 128) : 32768;  // rings; at least the 32 KiB exchange
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)output_softmax_regw_kernel<NSTEP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int t_tiles = (g->t_out + 63) / 64;
+    hipLaunchKernelGGL(output_softmax_regw_kernel<NSTEP>, dim3(g->batch * t_tiles), dim3(256), LDS, s, (const __bf16*)x,
+                       (const __bf16*)w, bias, probs, logq, logits, g->batch, g->t_out, t_tiles, g->taps * g->cin, g->x_row0,
+                       g->x_row_stride, (long)g->x_batch_stride, k, logit_stride, logit_batch_stride, eps);
+    return sl_check_launch("sl_output_softmax(register weights)");
+}
+
 int output_softmax_bf16(const void* x, const void* w, const float* bias, float* probs, float* logq, float* logits,
                         const sl_conv_geom* g, int k, int logit_stride, long logit_batch_stride, float eps, hipStream_t s) {
+    // weights in registers (one wave per quarter of the input channels, its own ring): cin = 256, 512, 1024 or 2048
+    if (g_output_softmax_variant != 1 && g->taps == 1) {
+        if (g->cin == 2048) return launch_output_softmax_regw<8>(x, w, bias, probs, logq, logits, g, k, logit_stride, logit_batch_stride, eps, s);
+        if (g->cin == 1024) return launch_output_softmax_regw<4>(x, w, bias, probs, logq, logits, g, k, logit_stride, logit_batch_stride, eps, s);
+        if (g->cin == 512) return launch_output_softmax_regw<2>(x, w, bias, probs, logq, logits, g, k, logit_stride, logit_batch_stride, eps, s);
+        if (g->cin == 256) return launch_output_softmax_regw<1>(x, w, bias, probs, logq, logits, g, k, logit_stride, logit_batch_stride, eps, s);
+    }
     const int wbytes = (k * (g->cin * 2 + 16) + 127) & ~127;
     const int slots = wbytes + 5 * 64 * 128 <= 160 * 1024 ? 5 : 3;  // ring depth the rest of the LDS allows
     const int lds = wbytes + slots * 64 * 128;

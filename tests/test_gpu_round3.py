@@ -89,6 +89,34 @@ def test_evicted_buffer_sets_are_released():
     assert first() is None, "the evicted buffer set is still referenced"
 
 
+# ------------------------------------------------------------------------------------------ output layer: weights in registers
+@pytest.mark.parametrize("out_filters,t", [(2000, 1000), (1000, 130), (500, 77), (250, 200)])
+def test_output_softmax_with_register_weights_matches_the_lds_kernel(hip_lib, out_filters, t):
+    """sl_output_softmax's two kernels -- the weight matrix in LDS behind one ring for the work-group, or a quarter of the
+    input channels per wave with its weights in registers and its own ring (cin = 2048 / 1024 / 512 / 256 after padding) --
+    and the two-launch path: the same probabilities and log q to the rounding of a different summation order over the
+    input channels (four partial sums added in wave order instead of one running sum)."""
+    import torch
+    case = make_case(b=3, t=t, seed=60 + t, sizes=dict(out_filter_count=out_filters))
+    outs = {}
+    try:
+        for name, fuse, variant in (("two launches", False, 0), ("lds", True, 1), ("registers", True, 2)):
+            hip_lib.call("sl_output_softmax_select", variant)
+            eng = make_engine(case, "bf16")
+            eng.fuse_output_softmax = fuse
+            probs = eng.forward(case["x"]).cpu().numpy().copy()
+            outs[name] = (probs, eng.cur.logq.cpu().numpy().copy())
+            torch.cuda.synchronize()
+    finally:
+        hip_lib.call("sl_output_softmax_select", 0)
+    for name in ("lds", "registers"):
+        np.testing.assert_allclose(outs[name][0], outs["two launches"][0], rtol=5e-6, atol=1e-9)
+        np.testing.assert_allclose(outs[name][1], outs["two launches"][1], rtol=5e-6, atol=5e-6)
+        np.testing.assert_allclose(outs[name][0].sum(-1), 1.0, atol=1e-5)
+    _report("output_softmax_register_weights_vs_lds_max_rel_prob_diff_cin_{}".format(out_filters),
+            float(np.max(np.abs(outs["registers"][0] - outs["lds"][0]) / outs["lds"][0])))
+
+
 # ------------------------------------------------------------------------------------------ CTC: the regime of a trained net
 def _aligned_logits(rng, labels_list, t, k, strength, noise=1.0):
     """logits of a net that has LEARNT its labels: a random monotone alignment of every label (blank between repeats, the
