@@ -232,53 +232,58 @@ __device__ __forceinline__ float log2_of_double(double x) {
 // LIN: the lattice comes from ctc_lattice_wave_kernel (doubles in linear units with one exponent per frame, emissions
 // u = p + eps instead of q) and is brought to log2 units on the fly; the sum of a frame's state posteriors must then be
 // ---- repair of one utterance inside the gradient kernel (see ctc_grad_kernel) ------------------------------------------
-// Log-domain alpha or beta lattice of utterance b by ONE work-group of 256 threads (two states per thread, S <= 512): the
+// Log-domain alpha and beta lattices of utterance b by ONE work-group of 256 threads (S <= 512): the
 // recursion of ctc_lattice_kernel, operation for operation (same results), without its tuning -- this runs only for an
 // utterance whose linear lattice lost mass, and then on one work-group while the rest of the chip goes on.
-template <int DIR>
-__device__ void repair_lattice(const float* __restrict__ lq_b, const int* s_lab, int L, int S, int T, int t_out, int k,
-                               int blank, int sp, float* __restrict__ out, float* rows, float* loss_b) {
-    constexpr int RS = 512 + 4;  // row stride in LDS: index s + 2, two pads either side
+// Both directions at once: threads 0..127 run alpha, threads 128..255 beta (up to four states per thread, one barrier per
+// frame for both).
+__device__ void repair_lattices(const float* __restrict__ lq_b, const int* s_lab, int L, int S, int T, int k, int blank,
+                                int sp, float* __restrict__ out_alpha, float* __restrict__ out_beta, float* rows,
+                                float* loss_b) {
+    constexpr int RS = 512 + 4;  // row stride in LDS: index s + 2, two pads either side; rows: [direction][2][RS]
     const int tid = threadIdx.x;
-    int my[2];
-    bool skip[2], live[2], mine[2];
+    const int dir = tid >> 7;    // wave-uniform
+    const int ht = tid & 127;
+    int my[4];
+    bool skip[4], live[4], mine[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int st = tid + 256 * i;
+    for (int i = 0; i < 4; ++i) {
+        const int st = ht + 128 * i;
         mine[i] = st < sp;
         live[i] = st < S;
         my[i] = blank;
         skip[i] = false;
         if (live[i] && (st & 1)) {
             my[i] = s_lab[st >> 1];
-            if (DIR == 0)
+            if (dir == 0)
                 skip[i] = (st >= 3) && (s_lab[(st >> 1) - 1] != my[i]);
             else
                 skip[i] = (st + 2 < S) && (s_lab[(st >> 1) + 1] != my[i]);
         }
     }
-    for (int i = tid; i < 2 * RS; i += 256) rows[i] = -INFINITY;
+    for (int i = tid; i < 4 * RS; i += 256) rows[i] = -INFINITY;
     __syncthreads();
-    float* prev = rows;
-    float* cur = rows + RS;
-    const int tstart = DIR == 0 ? 0 : T - 1;
-    const int tstep = DIR == 0 ? 1 : -1;
-    const int nb = DIR == 0 ? -1 : 1;
-    float e[2], en[2];
+    float* prev = rows + dir * 2 * RS;
+    float* cur = prev + RS;
+    float* out = dir == 0 ? out_alpha : out_beta;
+    const int tstart = dir == 0 ? 0 : T - 1;
+    const int tstep = dir == 0 ? 1 : -1;
+    const int nb = dir == 0 ? -1 : 1;
+    float e[4], en[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) e[i] = lq_b[(long)tstart * k + my[i]];
+    for (int i = 0; i < 4; ++i) e[i] = lq_b[(long)tstart * k + my[i]];
     for (int step = 0; step < T; ++step) {
         const int t = tstart + tstep * step;
         const int tn = tstart + tstep * (step + 1 < T ? step + 1 : step);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) en[i] = lq_b[(long)tn * k + my[i]];  // next frame's emission, a frame ahead
+        for (int i = 0; i < 4; ++i) en[i] = lq_b[(long)tn * k + my[i]];  // next frame's emission, a frame ahead
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int st = tid + 256 * i;
+        for (int i = 0; i < 4; ++i) {
+            const int st = ht + 128 * i;
             if (mine[i]) {
                 float v;
                 if (step == 0) {
-                    const bool init = DIR == 0 ? (st <= 1) : (st >= S - 2);
+                    const bool init = dir == 0 ? (st <= 1) : (st >= S - 2);
                     v = (live[i] && init) ? e[i] * LOG2E : -INFINITY;
                 } else {
                     const float a0 = prev[st + 2];
@@ -297,7 +302,7 @@ __device__ void repair_lattice(const float* __restrict__ lq_b, const int* s_lab,
         prev = cur;
         cur = tmp;
     }
-    if (DIR == 0 && tid == 0) {
+    if (tid == 0) {  // (dir 0: prev is alpha's last row)
         const float last = prev[S - 1 + 2];
         const float last2 = S >= 2 ? prev[S - 2 + 2] : -INFINITY;
         const float m = fmaxf(last, last2);
@@ -461,7 +466,7 @@ __device__ __forceinline__ void ctc_grad_frames(
 // frames are written; the work-group with the utterance's highest index waits for the others' slots, reads the utterance's flag
 // -- set by the lattice wave (no alignment / overflow) or by any work-group of this launch (a frame's posteriors did not
 // sum to 1) -- and, if it is set, redoes the whole utterance by itself: log-domain alpha and beta lattices into rep_alpha /
-// rep_beta (repair_lattice), the loss, then the gradient of every frame from them.  Normally no flag is set and it just
+// rep_beta (repair_lattices), the loss, then the gradient of every frame from them.  Normally no flag is set and it just
 // leaves: the two launches that used to follow (an empty log-domain lattice and an empty gradient pass, 5.5 + 5.3 us
 // every step) are gone.
 template <int NJ, int LIN>
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     if constexpr (LIN != 0) {
         if (tickets == nullptr) return;
         __shared__ int s_flag;
-        __shared__ float s_rows[2 * (512 + 4)];
+        __shared__ float s_rows[4 * (512 + 4)];
         // No fence, no shared counter and nobody waiting in the common path.  The gradient rows are device-scope stores and
         // the flag updates device-scope atomics, complete once acknowledged: every wave waits for its own, then one
         // thread of the work-group raises the work-group's OWN done slot (a device-scope release here writes back the
@@ -545,10 +550,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         }
         __threadfence();
         const float* lq_b = logq + (long)b * t_out * k;
-        repair_lattice<0>(lq_b, s_lab, L, S, T, t_out, k, blank, rep_sp, rep_alpha + (long)b * t_out * rep_sp, s_rows,
-                          &loss[b]);
-        repair_lattice<1>(lq_b, s_lab, L, S, T, t_out, k, blank, rep_sp, rep_beta + (long)b * t_out * rep_sp, s_rows,
-                          &loss[b]);
+        repair_lattices(lq_b, s_lab, L, S, T, k, blank, rep_sp, rep_alpha + (long)b * t_out * rep_sp,
+                        rep_beta + (long)b * t_out * rep_sp, s_rows, &loss[b]);
         __threadfence();  // the lattice rows and the loss, written by other threads of this work-group
         __syncthreads();
         const float nll = *(volatile float*)&loss[b];
