@@ -1,6 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu | tail -15 > gpurun_out/r03_gpu_tests.txt
-grep -n "passed\|failed" gpurun_out/r03_gpu_tests.txt
-bash tools/profile_round.sh r03i
-tail -8 gpurun_out/r03i_e2e.txt
+timeout 900 python tools/batch_sweep.py 2>&1 | grep -v amdgpu | tee gpurun_out/r03_batch_sweep.txt | tail -12
