@@ -12,6 +12,8 @@
 //                         frame), emission log-probs prefetched 8 frames ahead into registers.  The recursion is
 //                         sequential in t -> latency-bound by construction; running alpha and beta in separate
 //                         work-groups halves the critical path.
+//   ctc_lattice_wave_kernel (default for labels of up to 255 graphemes): the same two recursions in the probability domain,
+//                         ONE WAVE per utterance and direction, doubles with an exponent per lane (see further down).
 //   ctc_grad_kernel     : one wave per frame.  occupancy gamma_t(k) = sum_{s: l'_s = k} exp(alpha+beta-logq-logP) is
 //                         reduced in a FIXED order (blank: wave butterfly; graphemes: per-class position lists built
 //                         once per work-group) -> deterministic.  Chains through log(p+eps) and the output softmax and
@@ -80,12 +82,10 @@ __global__ __launch_bounds__(1024) void ctc_lattice_kernel(const float* __restri
                                                            const int32_t* __restrict__ input_len,
                                                            float* __restrict__ alpha, float* __restrict__ beta,
                                                            float* __restrict__ loss, int32_t* __restrict__ cls,
-                                                           int t_out, int k, int l_max, int sp, int blank,
-                                                           const int32_t* __restrict__ only_flagged) {
+                                                           int t_out, int k, int l_max, int sp, int blank) {
     extern __shared__ float rowbuf[];  // 2 x (blockDim + 4)   (list builder: l_max + k + 1 ints)
     const int b = blockIdx.x;
     const int dir = blockIdx.y;
-    if (only_flagged != nullptr && only_flagged[b] == 0) return;  // repair pass of the wave lattice: nothing to redo
     const int s = threadIdx.x;
     const int L = label_len[b];
     if (dir == 2) {
@@ -460,8 +460,6 @@ __device__ __forceinline__ void ctc_grad_frames(
 }
 
 // One wave per frame; work-group = 4 waves x frames_per_wg / 4 frames of one utterance.
-// only_flagged: this launch is the second pass behind the log-domain lattice of labels too long for the wave lattice -- never
-// set together with tickets.
 // tickets (with LIN): THE REPAIR PASS LIVES IN THIS KERNEL.  Every work-group of utterance b raises its done slot when its
 // frames are written; the work-group with the utterance's highest index waits for the others' slots, reads the utterance's flag
 // -- set by the lattice wave (no alignment / overflow) or by any work-group of this launch (a frame's posteriors did not
@@ -482,7 +480,6 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                        int t_out, int k, int l_max, int sp, int blank, int frames_per_wg,
                                                        int g_row0, int g_rs, long g_bs, int out_f32, float eps,
                                                        float grad_scale, int32_t* __restrict__ flags,
-                                                       const int32_t* __restrict__ only_flagged,
                                                        int32_t* __restrict__ tickets, float* __restrict__ rep_alpha,
                                                        float* __restrict__ rep_beta, int rep_sp) {
     // LDS: labels[l_max] | class_pos[l_max] | class_start[k+1] | lq[4][64] | gamma[4][l_max]
@@ -493,7 +490,6 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     float* s_lq = (float*)(s_start + (k + 1));
     float* s_gam = s_lq + 4 * 64;
     const int b = blockIdx.y;
-    if (only_flagged != nullptr && only_flagged[b] == 0) return;
     const int tid = threadIdx.x;
     const int L = label_len[b];
     const int S = 2 * L + 1;
@@ -1222,21 +1218,21 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
             hipLaunchKernelGGL((ctc_grad_kernel<8, 2>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
                                input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
                                l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
-                               eps, grad_scale, flags, nullptr, rep_tickets, alpha, beta, sp);
+                               eps, grad_scale, flags, rep_tickets, alpha, beta, sp);
         else
             hipLaunchKernelGGL((ctc_grad_kernel<8, 1>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
                                input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
                                l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
-                               eps, grad_scale, flags, nullptr, rep_tickets, alpha, beta, sp);
+                               eps, grad_scale, flags, rep_tickets, alpha, beta, sp);
         return sl_check_launch("sl_ctc_loss_grad(grad)");
     }
-    const int32_t* only = nullptr;  // labels beyond the wave lattice: the log-domain lattice for every utterance
+    // labels beyond the wave lattice: the log-domain lattice for every utterance
     const int threads = sp;  // multiple of 64, >= S
     size_t lds = 2 * (threads + 4) * sizeof(float);
     const size_t lds_lists = (size_t)(l_max + k + 1) * sizeof(int);
     if (lds < lds_lists) lds = lds_lists;
     hipLaunchKernelGGL(ctc_lattice_kernel, dim3(batch, 3), dim3(threads), lds, s, logq, labels, label_len, input_len,
-                       alpha, beta, loss, cls, t_out, k, l_max, sp, k - 1, only);
+                       alpha, beta, loss, cls, t_out, k, l_max, sp, k - 1);
     rc = sl_check_launch("sl_ctc_loss_grad(lattice)");
     if (rc != SL_OK) return rc;
 #define SL_CTC_GRAD(NJ_)                                                                                              \
@@ -1244,7 +1240,7 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
                        input_len, (const void*)alpha, (const void*)beta, nullptr, nullptr, nullptr, nullptr, loss, cls,   \
                        dlogits,                                                                                        \
                        t_out, k, l_max, sp, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,  \
-                       eps, grad_scale, nullptr, only, nullptr, nullptr, nullptr, 0)
+                       eps, grad_scale, nullptr, nullptr, nullptr, nullptr, 0)
     if (sp <= 256) {
         SL_CTC_GRAD(4);
     } else if (sp <= 512) {
