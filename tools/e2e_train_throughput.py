@@ -79,6 +79,8 @@ def main():
         32 * args.steps / serial, serial / args.steps * 1e3))
     print("staged (worker thread, copy stream): {:8.1f} utt/s ({:.2f} ms per batch)".format(
         32 * args.steps / piped, piped / args.steps * 1e3))
+    print("HBM: {:.2f} GB allocated now, {:.2f} GB at the peak, {:.2f} GB reserved by the allocator".format(
+        torch.cuda.memory_allocated() / 1e9, torch.cuda.max_memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9))
 
 
 def from_audio(args):
