@@ -117,6 +117,9 @@ int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* ma
  *   fits; otherwise (or for fp32 / ELU / dropout between the layers) use n_layers calls of sl_conv1d_nt.
  */
 int sl_conv1d_chain_supported(const sl_conv_geom* geom, int n_layers, int dtype);
+/* Measurement / test hook: output frames per work-group of sl_conv1d_chain.  0 (default) = chosen per launch (64, or 48 where
+ * that fills the chip's rounds of 256 work-groups better: long utterances in small batches), 48 / 64 = forced.  Process-wide. */
+int sl_conv1d_chain_select(int tile_rows);
 int sl_conv1d_chain(const void* x, void* const* ys, const void* const* ws, const float* const* biases,
                     const void* const* masks, const sl_conv_geom* geom, int n_layers, int epilogue, int dtype,
                     void* stream);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "sl_conv1d_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int, c_int,
                              c_int, c_void_p, c_size_t, c_void_p]),
     "sl_conv1d_chain_supported": (c_int, [POINTER(ConvGeom), c_int, c_int]),
+    "sl_conv1d_chain_select": (c_int, [c_int]),
     "sl_conv1d_chain": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                 POINTER(ConvGeom), c_int, c_int, c_int, c_void_p]),
     "sl_conv1d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int]),

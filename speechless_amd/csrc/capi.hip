@@ -97,6 +97,12 @@ extern "C" int sl_output_softmax(const void* x, const void* w, const float* bias
                                (hipStream_t)stream);
 }
 
+int conv_chain_select(int rows);
+extern "C" int sl_conv1d_chain_select(int tile_rows) {
+    SL_CHECK_ARG(tile_rows == 0 || tile_rows == 48 || tile_rows == 64, "sl_conv1d_chain_select: tile_rows must be 0, 48 or 64");
+    return conv_chain_select(tile_rows);
+}
+
 extern "C" int sl_conv1d_chain_supported(const sl_conv_geom* geom, int n_layers, int dtype) {
     return geom != nullptr && dtype == SL_BF16 && geom->batch > 0 && geom->t_out > 0 && conv_chain_bf16_supported(geom, n_layers);
 }

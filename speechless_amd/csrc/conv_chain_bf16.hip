@@ -31,7 +31,8 @@
 namespace {
 
 constexpr int CH = 256;          // channels in = out (padded)
-constexpr int TM = 64;           // output frames per work-group
+constexpr int TM = 64;           // output frames per work-group (TM_SMALL where that fills the chip's rounds better: chain_tile_rows)
+constexpr int TM_SMALL = 48;
 constexpr int MAX_LAYERS = 8;
 constexpr int ACT_ROWS = 120;    // >= 16 * 7 + taps - 1
 constexpr int ACT_CHUNK = ACT_ROWS * 128;
@@ -49,6 +50,7 @@ struct ChainArgs {
     const __bf16* mask[MAX_LAYERS];   // dgrad: the stored activation whose sign is the ReLU mask, same geometry
     int n_layers, taps, pad;          // pad = rows of left context per layer (forward: pad_left; dgrad: pad_right)
     int batch, t_out, t_tiles;
+    int tm;                           // output frames per work-group: TM or TM_SMALL
     int row0, rs;                     // halo rows in front of frame 0, elements per row
     long bs;                          // elements per utterance
 };
@@ -79,6 +81,13 @@ struct ChainReadRun<N, N> {
 // s_waitcnt lgkmcnt(CNT) that the MFMAs consuming these fragments cannot be hoisted above
 template <int MT>
 struct ChainWait;
+template <>
+struct ChainWait<3> {
+    template <int CNT>
+    static __device__ __forceinline__ void frags(bf16x8 (&w)[2], bf16x8 (&x)[3]) {
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : "n"(CNT));
+    }
+};
 template <>
 struct ChainWait<4> {
     template <int CNT>
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;
     const int b = tile / a.t_tiles;
-    const int t0 = (tile - b * a.t_tiles) * TM;
+    const int t0 = (tile - b * a.t_tiles) * a.tm;
     const int n = a.n_layers;
     const int taps = a.taps;
     const int pad = a.pad;
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
     // (piece = 8 rows of one 64-channel chunk = 1 KB; lane -> row 8 * group + lane / 8, physical slot lane % 8).  Frames
     // outside the utterance come from a zero row of the tensor itself: [-row0, 0) and [T', T' + 1) are halo / padding rows.
     {
-        const int groups = (TM + halo * n + 7) >> 3;
+        const int groups = (a.tm + halo * n + 7) >> 3;
         const __bf16* xb = a.x + (long)b * a.bs;
         for (int pc = wave; pc < 4 * groups; pc += 8) {
             const int c = pc & 3, rg = pc >> 2;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
         }
     };
     for (int l = 0; l < n; ++l) {
-        const int rows_out = TM + halo * (n - 1 - l);
+        const int rows_out = a.tm + halo * (n - 1 - l);
         const int mt = (rows_out + 15) >> 4;
         // this wave's bias values, requested before the layer's steps (a load in the epilogue is a full L2 round trip
         // with every MFMA pipe idle)
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
         }
 #endif
         switch (mt) {
+            case 3: run_steps(std::integral_constant<int, 3>{}); break;
             case 4: run_steps(std::integral_constant<int, 4>{}); break;
             case 5: run_steps(std::integral_constant<int, 5>{}); break;
             case 6: run_steps(std::integral_constant<int, 6>{}); break;
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void conv_chain_bf16_kernel(ChainArgs a) {
         // LDS copy: 16 bytes per lane, every line written / read once.
         const int t_first = t0 - pad * (n - 1 - l);
         __bf16* yb = a.y[l] + (long)b * a.bs;
-        const int jc0 = t0 - t_first, jc_n = min(TM, a.t_out - t0);                 // core rows: j - jc0 in [0, jc_n)
+        const int jc0 = t0 - t_first, jc_n = min(a.tm, a.t_out - t0);                 // core rows: j - jc0 in [0, jc_n)
         const int jl0 = max(0, -t_first), jl_n = min(16 * mt, a.t_out - t_first) - jl0;  // rows inside the utterance
         const bool edge = t_first < 0 || t_first + 16 * mt > a.t_out;
         // piece i of the row-contiguous view: row 16 i + 2 wave + lane / 32, 16-byte slot lane % 32 of the row's 512 bytes
@@ -444,6 +454,33 @@ extern "C" int sl_chain_probe_read(void* host_dst, size_t bytes) {
 }
 #endif
 
+static int g_chain_tile_rows = 0;  // sl_conv1d_chain_select: 0 = automatic, 48 / 64 = forced
+int conv_chain_select(int rows) {
+    g_chain_tile_rows = rows;
+    return SL_OK;
+}
+
+// Output frames per work-group.  A work-group fills a CU (160 KB of LDS), so the launch runs in rounds of 256; 64-frame
+// tiles recompute less halo (39 sixteen-row MFMA tiles per 64 frames at seven 7-tap layers) than 48-frame tiles (32 per
+// 48 frames = +9 %), but 8 utterances x 2500 frames (config 5) are 320 work-groups = two rounds, the second a quarter full:
+// 424 shorter work-groups make 1.66 rounds.  Minimise rounds x MFMA tiles per work-group.
+static int chain_tile_rows(int batch, int t_out, int taps, int n_layers) {
+    if (g_chain_tile_rows == TM || g_chain_tile_rows == TM_SMALL) return g_chain_tile_rows;
+    double best_cost = 1e30;
+    int best = TM;
+    for (int tm : {TM, TM_SMALL}) {
+        long tiles = 0;
+        for (int l = 0; l < n_layers; ++l) tiles += (tm + (taps - 1) * (n_layers - 1 - l) + 15) / 16;
+        const long wgs = (long)batch * ((t_out + tm - 1) / tm);
+        const double cost = (double)((wgs + 255) / 256) * (double)tiles;
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = tm;
+        }
+    }
+    return best;
+}
+
 int conv_chain_bf16(const void* x, void* const* ys, const void* const* ws, const float* const* biases,
                     const void* const* masks, const sl_conv_geom* g, int n_layers, int epilogue, hipStream_t s) {
     ChainArgs a;
@@ -459,7 +496,8 @@ int conv_chain_bf16(const void* x, void* const* ys, const void* const* ws, const
     a.pad = g->taps / 2;
     a.batch = g->batch;
     a.t_out = g->t_out;
-    a.t_tiles = (g->t_out + TM - 1) / TM;
+    a.tm = chain_tile_rows(g->batch, g->t_out, g->taps, n_layers);
+    a.t_tiles = (g->t_out + a.tm - 1) / a.tm;
     a.row0 = g->y_row0;
     a.rs = CH;
     a.bs = g->y_batch_stride;

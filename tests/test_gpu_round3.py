@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import w2l_oracle as o
-from test_gpu_parity import _report, make_case, make_engine, rel_l2
+from test_gpu_parity import _report, make_case, make_engine, rel_l2, run_loss_and_grads
 
 pytestmark = pytest.mark.gpu
 
@@ -87,6 +87,37 @@ def test_evicted_buffer_sets_are_released():
     torch.cuda.synchronize()
     gc.collect()
     assert first() is None, "the evicted buffer set is still referenced"
+
+
+# ------------------------------------------------------------------------------------------ fused inner layers: 48-frame tiles
+@pytest.mark.parametrize("b,t", [(3, 300), (2, 77), (8, 1200), (1, 96)])
+def test_fused_inner_layers_with_48_frame_tiles_are_bit_identical(hip_lib, b, t):
+    """sl_conv1d_chain picks 48 instead of 64 output frames per work-group where that fills the chip's rounds of 256
+    work-groups better (long utterances in small batches: config 5).  An output row is the same sequence of MFMA
+    accumulations whatever tile it sits in, so activations, gradients and losses must be BIT-identical between the two
+    tile sizes (and the automatic choice is one of them)."""
+    import torch
+    case = make_case(b=b, t=t, seed=80 + t)
+    res = {}
+    try:
+        for rows in (64, 48, 0):
+            hip_lib.call("sl_conv1d_chain_select", rows)
+            eng = make_engine(case, "bf16")
+            losses, grads = run_loss_and_grads(eng, case)
+            tags = [op[3] for ops in eng.cur.launch_lists.values() for op in ops if op[0] == 0]
+            assert tags.count("sl_conv1d_chain") == 2
+            res[rows] = (losses, [y.clone() for y in eng.cur.y[:8]], [g.clone() for g in eng.cur.g[:8]], grads)
+            torch.cuda.synchronize()
+    finally:
+        hip_lib.call("sl_conv1d_chain_select", 0)
+    for rows in (48, 0):
+        assert np.array_equal(res[rows][0], res[64][0])
+        for ya, yb in zip(res[rows][1], res[64][1]):
+            assert torch.equal(ya, yb)
+        for ga, gb in zip(res[rows][2], res[64][2]):
+            assert torch.equal(ga, gb)
+        for (wa, ba), (wb, bb) in zip(res[rows][3], res[64][3]):
+            assert np.array_equal(wa, wb) and np.array_equal(ba, bb)
 
 
 # ------------------------------------------------------------------------------------------ output layer: weights in registers
