@@ -353,6 +353,11 @@ int sl_split3_pack_input(const float* src, void* dst, int batch, int t_in, int f
                          int64_t dst_batch_stride, void* stream);
 int sl_split3_weights(const float* v, float* hi, float* lo, size_t n, void* stream);
 int sl_split3_assemble(const void* a, const void* b, void* dst, int64_t rows, int width, void* stream);
+/* The bf16x3 operand copies of one layer from its fp32 master [k][cin_pad][cout_pad] in one pass: w_fwd3 [cout][k][3 cin]
+ * = rows [w_hi | w_hi | w_lo], w_dgrad3 [cin][k-1-tap][3 cout] likewise (or NULL); what sl_split3_weights + 2 x
+ * sl_pack_weights + 2 x sl_split3_assemble produce, bit for bit. */
+int sl_split3_pack_weights(const float* w_master, void* w_fwd3, void* w_dgrad3, int k, int cin_pad, int cout_pad,
+                           void* stream);
 int sl_split3_wgrad_combine(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out, int frames,
                             int fstride, int ra_cin, int rb_cin, void* stream);
 size_t sl_split3_bias_grad_workspace_bytes(int channels);

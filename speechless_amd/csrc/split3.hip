@@ -29,28 +29,42 @@ __global__ __launch_bounds__(256) void split3_act_kernel(const float* __restrict
                                                          const unsigned short* __restrict__ mask, int t_out, int c,
                                                          long src_bs, int dst_row0, long dst_bs) {
     const int b = blockIdx.y;
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;  // 4 channels per thread
-    if (i >= (long)t_out * c) return;
-    const int t = (int)(i / c), ch = (int)(i % c);
-    const f32x4 v4 = *(const f32x4*)(src + (long)b * src_bs + i);
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 8;  // 8 channels per thread: 32 bytes in, three 16-byte stores out
+    if (i >= t_out * c) return;                           // (t_out * c < 2^31: checked by the host function)
+    const int t = i / c, ch = i - t * c;
+    const float* sp = src + (long)b * src_bs + i;
+    const f32x4 va = *(const f32x4*)sp, vb = *(const f32x4*)(sp + 4);
     const long row = (long)b * dst_bs + (long)(dst_row0 + t) * (3 * c);
-    unsigned short hi[4], lo[4];
+    float y[8];
+    if (MODE == 3 || MODE == 4) {
+        const u32x4 mh = *(const u32x4*)(mask + row + ch);
+        u32x4 ml = (u32x4){0u, 0u, 0u, 0u};
+        if (MODE == 4) ml = *(const u32x4*)(mask + row + c + ch);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float v = v4[j];
+        for (int j = 0; j < 4; ++j) {
+            y[2 * j] = __uint_as_float(mh[j] << 16) + (MODE == 4 ? __uint_as_float(ml[j] << 16) : 0.f);
+            y[2 * j + 1] = __uint_as_float(mh[j] & 0xFFFF0000u) + (MODE == 4 ? __uint_as_float(ml[j] & 0xFFFF0000u) : 0.f);
+        }
+    }
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = j < 4 ? va[j] : vb[j - 4];
         if (MODE == 1) v = fmaxf(v, 0.f);
         if (MODE == 2) v = v > 0.f ? v : expm1f(v);
-        if (MODE == 3 || MODE == 4) {
-            const float y = bf16_bits_to_f32(mask[row + ch + j]) + (MODE == 4 ? bf16_bits_to_f32(mask[row + c + ch + j]) : 0.f);
-            v = MODE == 3 ? (y > 0.f ? v : 0.f) : (y > 0.f ? v : v * (y + 1.f));
-        }
+        if (MODE == 3) v = y[j] > 0.f ? v : 0.f;
+        if (MODE == 4) v = y[j] > 0.f ? v : v * (y[j] + 1.f);
         split2(v, hi[j], lo[j]);
     }
-    const u32x2 h = {(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
-    const u32x2 l = {(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
-    *(u32x2*)(dst + row + ch) = h;
-    *(u32x2*)(dst + row + c + ch) = l;
-    *(u32x2*)(dst + row + 2 * c + ch) = h;
+    u32x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (unsigned)hi[2 * j] | ((unsigned)hi[2 * j + 1] << 16);
+        l[j] = (unsigned)lo[2 * j] | ((unsigned)lo[2 * j + 1] << 16);
+    }
+    *(u32x4*)(dst + row + ch) = h;
+    *(u32x4*)(dst + row + c + ch) = l;
+    *(u32x4*)(dst + row + 2 * c + ch) = h;
 }
 
 // input packing (sl_pack_input for planes): src float[B][t_in][f] -> dst [B][rows][3 * c] at row dst_row0 + t, channels >= f zero
@@ -77,6 +91,45 @@ __global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict_
     const float h = bf16_bits_to_f32(f32_to_bf16_bits(x));
     hi[i] = h;
     lo[i] = x - h;
+}
+
+// master [k][cin][cout] fp32 -> the two packed bf16x3 operand copies in ONE pass (what sl_split3_weights + 2 x sl_pack_weights
+// + 2 x sl_split3_assemble produce in five: 55 launches per optimisation step for the eleven layers):
+//   w_fwd3 [cout][k][3 cin]   rows [w_hi | w_hi | w_lo] over cin        w_dgrad3 [cin][k-1-tap][3 cout]  likewise over cout
+// with w_hi = bf16(v), w_lo = bf16(v - float(w_hi)).  32 x 32 LDS transpose per tap, as pack_weights_kernel.
+__global__ __launch_bounds__(256) void pack_weights3_kernel(const float* __restrict__ wm, unsigned short* __restrict__ wf,
+                                                            unsigned short* __restrict__ wd, int k, int cin, int cout) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.y * 32;
+    const int co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + ty + r * 8;
+        const float v = wm[((long)tap * cin + ci) * cout + co0 + tx];
+        tile[ty + r * 8][tx] = v;
+        if (wd) {
+            const unsigned short h = f32_to_bf16_bits(v);
+            const unsigned short l = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+            unsigned short* o = wd + ((long)ci * k + (k - 1 - tap)) * 3 * cout + co0 + tx;
+            o[0] = h;
+            o[cout] = h;
+            o[2 * cout] = l;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co0 + ty + r * 8;
+        const float v = tile[tx][ty + r * 8];
+        const unsigned short h = f32_to_bf16_bits(v);
+        const unsigned short l = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+        unsigned short* o = wf + ((long)co * k + tap) * 3 * cin + ci0 + tx;
+        o[0] = h;
+        o[cin] = h;
+        o[2 * cin] = l;
+    }
 }
 
 // rows of `width` bf16: dst[r] = [a[r] | a[r] | b[r]]   (packed weight rows [w_hi | w_hi | w_lo])
@@ -142,10 +195,12 @@ __global__ __launch_bounds__(256) void bias_grad3_final_kernel(const float* __re
 
 extern "C" int sl_split3(const float* src, void* dst, const void* mask, int batch, int t_out, int channels,
                          int64_t src_batch_stride, int dst_row0, int64_t dst_batch_stride, int mode, void* stream) {
-    SL_CHECK_ARG(src && dst && batch > 0 && t_out > 0 && channels > 0 && channels % 4 == 0, "sl_split3: bad arguments");
+    SL_CHECK_ARG(src && dst && batch > 0 && t_out > 0 && channels > 0 && channels % 8 == 0 &&
+                     (long)t_out * channels < (1L << 31),
+                 "sl_split3: channels must be a multiple of 8, t_out * channels below 2^31");
     SL_CHECK_ARG(mode >= 0 && mode <= 4 && (mode < 3 || mask), "sl_split3: mode 0..4, modes 3 / 4 need the mask tensor");
-    const long n4 = ((long)t_out * channels + 3) / 4;
-    const dim3 grid((unsigned)((n4 + 255) / 256), batch);
+    const long n8 = ((long)t_out * channels + 7) / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256), batch);
     hipStream_t s = (hipStream_t)stream;
 #define SL_SPLIT3(M_)                                                                                                  \
     hipLaunchKernelGGL(split3_act_kernel<M_>, grid, dim3(256), 0, s, src, (unsigned short*)dst, (const unsigned short*)mask, \
@@ -175,6 +230,15 @@ extern "C" int sl_split3_weights(const float* v, float* hi, float* lo, size_t n,
     hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, hi, lo,
                        (long)n);
     return sl_check_launch("sl_split3_weights");
+}
+
+extern "C" int sl_split3_pack_weights(const float* w_master, void* w_fwd3, void* w_dgrad3, int k, int cin_pad, int cout_pad,
+                                      void* stream) {
+    SL_CHECK_ARG(w_master && w_fwd3 && k > 0 && cin_pad > 0 && cout_pad > 0 && cin_pad % 32 == 0 && cout_pad % 32 == 0,
+                 "sl_split3_pack_weights: channel counts must be multiples of 32");
+    hipLaunchKernelGGL(pack_weights3_kernel, dim3(cout_pad / 32, cin_pad / 32, k), dim3(256), 0, (hipStream_t)stream, w_master,
+                       (unsigned short*)w_fwd3, (unsigned short*)w_dgrad3, k, cin_pad, cout_pad);
+    return sl_check_launch("sl_split3_pack_weights");
 }
 
 extern "C" int sl_split3_assemble(const void* a, const void* b, void* dst, int64_t rows, int width, void* stream) {

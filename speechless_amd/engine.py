@@ -451,7 +451,6 @@ class Engine:
         if self.planes > 1:  # the fused launches read and write single-plane bf16 tensors
             self.use_chain = self.fuse_output_softmax = self.fuse_output_backward = self.group_wgrad = False
             self.use_launch_lists = False
-            self._x3_tmp = None
             self._x3_bias_ws = None
         self._rec = None
         self._adam_tables = {}
@@ -653,29 +652,15 @@ class Engine:
         self._dropout_steps = int(state.get("dropout_steps", 0))
 
     def _repack_weights_x3(self):
-        """bf16x3 operand copies: masters -> (float(hi), v - float(hi)) -> sl_pack_weights of each (its own rounding yields
-        hi and lo exactly) -> rows [w_hi | w_hi | w_lo] in both operand layouts."""
+        """bf16x3 operand copies: rows [w_hi | w_hi | w_lo] in both operand layouts, w_hi = bf16(w), w_lo = bf16(w - w_hi),
+        one launch per layer (sl_split3_pack_weights; the five-launch sequence it replaces -- split, two packs, two
+        assembles -- was 55 launches and 0.45 ms of a 7.1 ms optimisation step)."""
         st = self._stream()
-        n_max = max(p.w_numel for p in self.plans)
-        if self._x3_tmp is None:
-            f32 = dict(dtype=torch.float32, device=self.device)
-            b16 = dict(dtype=torch.bfloat16, device=self.device)
-            self._x3_tmp = (torch.empty((n_max,), **f32), torch.empty((n_max,), **f32),
-                            [torch.empty((n_max,), **b16) for _ in range(4)])
-        hi32, lo32, (fh, fl, dh, dl) = self._x3_tmp
         for p in self.plans:
             wv, _ = self.layer_param_views(self.params, p)
-            k, wd = p.spec.kernel_size, self.w_dgrad[p.index]
-            self._launch("split:" + p.spec.name, "sl_split3_weights", wv.data_ptr(), hi32.data_ptr(), lo32.data_ptr(),
-                         p.w_numel, st)
-            for src, (f, d) in ((hi32, (fh, dh)), (lo32, (fl, dl))):
-                self._launch("pack:" + p.spec.name, "sl_pack_weights", src.data_ptr(), f.data_ptr(),
-                             d.data_ptr() if wd is not None else None, k, p.cin_pad, p.cout_pad, self.dtype_code, st)
-            self._launch("assemble:" + p.spec.name, "sl_split3_assemble", fh.data_ptr(), fl.data_ptr(),
-                         self.w_fwd[p.index].data_ptr(), p.cout_pad * k, p.cin_pad, st)
-            if wd is not None:
-                self._launch("assemble:" + p.spec.name, "sl_split3_assemble", dh.data_ptr(), dl.data_ptr(), wd.data_ptr(),
-                             p.cin_pad * k, p.cout_pad, st)
+            wd = self.w_dgrad[p.index]
+            self._launch("pack3:" + p.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
+                         wd.data_ptr() if wd is not None else None, p.spec.kernel_size, p.cin_pad, p.cout_pad, st)
         self._packed_dirty = False
 
     def repack_weights(self):

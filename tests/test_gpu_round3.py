@@ -89,6 +89,35 @@ def test_evicted_buffer_sets_are_released():
     assert first() is None, "the evicted buffer set is still referenced"
 
 
+def test_bf16x3_weight_pack_in_one_launch_equals_the_five_launch_sequence(hip_lib):
+    """sl_split3_pack_weights (master -> both [w_hi | w_hi | w_lo] operand copies in one pass) against sl_split3_weights +
+    2 x sl_pack_weights + 2 x sl_split3_assemble, the sequence it replaces in the bf16x3 optimisation step: bit for bit,
+    with and without the dgrad copy, for a first-layer and a 2048-channel shape."""
+    import torch
+    from speechless_amd import _lib
+    rng = np.random.RandomState(3)
+    st = torch.cuda.current_stream().cuda_stream
+    for k, cin, cout, with_dgrad in ((7, 256, 256, True), (48, 128, 256, False), (1, 2048, 64, True), (32, 256, 2048, True)):
+        w = torch.from_numpy((rng.randn(k, cin, cout) * 10 ** rng.uniform(-6, 1, size=(1, 1, cout))).astype(np.float32)).cuda()
+        hi32, lo32 = torch.empty_like(w), torch.empty_like(w)
+        b16 = dict(dtype=torch.bfloat16, device="cuda")
+        fh, fl, dh, dl = (torch.empty((w.numel(),), **b16) for _ in range(4))
+        f_old, d_old = torch.zeros((3 * w.numel(),), **b16), torch.zeros((3 * w.numel(),), **b16)
+        f_new, d_new = torch.zeros_like(f_old), torch.zeros_like(d_old)
+        hip_lib.call("sl_split3_weights", w.data_ptr(), hi32.data_ptr(), lo32.data_ptr(), w.numel(), st)
+        for src, (f, d) in ((hi32, (fh, dh)), (lo32, (fl, dl))):
+            hip_lib.call("sl_pack_weights", src.data_ptr(), f.data_ptr(), d.data_ptr() if with_dgrad else None, k, cin, cout,
+                         _lib.SL_BF16, st)
+        hip_lib.call("sl_split3_assemble", fh.data_ptr(), fl.data_ptr(), f_old.data_ptr(), cout * k, cin, st)
+        if with_dgrad:
+            hip_lib.call("sl_split3_assemble", dh.data_ptr(), dl.data_ptr(), d_old.data_ptr(), cin * k, cout, st)
+        hip_lib.call("sl_split3_pack_weights", w.data_ptr(), f_new.data_ptr(), d_new.data_ptr() if with_dgrad else None, k,
+                     cin, cout, st)
+        torch.cuda.synchronize()
+        assert torch.equal(f_new.view(torch.int16), f_old.view(torch.int16)), (k, cin, cout)
+        assert torch.equal(d_new.view(torch.int16), d_old.view(torch.int16)), (k, cin, cout)
+
+
 # ------------------------------------------------------------------------------------------ fused inner layers: 48-frame tiles
 @pytest.mark.parametrize("b,t", [(3, 300), (2, 77), (8, 1200), (1, 96)])
 def test_fused_inner_layers_with_48_frame_tiles_are_bit_identical(hip_lib, b, t):
