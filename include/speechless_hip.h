@@ -358,6 +358,10 @@ int sl_split3_assemble(const void* a, const void* b, void* dst, int64_t rows, in
  * sl_pack_weights + 2 x sl_split3_assemble produce, bit for bit. */
 int sl_split3_pack_weights(const float* w_master, void* w_fwd3, void* w_dgrad3, int k, int cin_pad, int cout_pad,
                            void* stream);
+/* sl_adam_pack_layers for the bf16x3 path: Keras-2.0 Adam on the fp32 masters of up to SL_ADAM_MAX_LAYERS layers and their
+ * [w_hi | w_hi | w_lo] operand copies (layers[i].w_fwd / .w_dgrad = the 3-plane tensors) rewritten in the same pass. */
+int sl_split3_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers, int n_layers,
+                               int step, float lr, float beta1, float beta2, float eps, void* stream);
 int sl_split3_wgrad_combine(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out, int frames,
                             int fstride, int ra_cin, int rb_cin, void* stream);
 size_t sl_split3_bias_grad_workspace_bytes(int channels);

@@ -158,7 +158,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 //   w_fwd [cout][k][cin]   (32x64 tile transposed through LDS)   and   w_dgrad[cin][k-1-tap][cout]
 // 4 fp32 reads + 3 fp32 writes + 2 narrow writes per parameter instead of Adam (4r+3w) followed by pack (1r+2w).
 // grid (cout/64, cin/32, k + 1): z == k is the bias block (only y == 0 works there).
-template <typename T, bool ADAM = true>
+// PLANES = 3 (bf16x3, T = unsigned short): the operand rows are [w_hi | w_hi | w_lo], w_hi = bf16(w), w_lo = bf16(w - w_hi).
+__device__ __forceinline__ u32x2 pack_lo4(float a0, float a1, float a2, float a3) {
+    auto lo = [](float v) { return v - bf16_bits_to_f32(f32_to_bf16_bits(v)); };
+    return (u32x2){pack_bf16x2(lo(a0), lo(a1)), pack_bf16x2(lo(a2), lo(a3))};
+}
+template <typename T, bool ADAM = true, int PLANES = 1>
 __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __restrict__ p, const float* __restrict__ g,
                                                 float* __restrict__ m, float* __restrict__ v, T* __restrict__ wf,
                                                 T* __restrict__ wd, int k, int cin, int cout, float lr_t, float b1,
@@ -194,8 +199,13 @@ __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[cil][tx * 4 + j] = pv[j];
         if (wd) {
-            T* o = wd + ((long)(ci0 + cil) * k + (k - 1 - tap)) * cout + co0 + tx * 4;
-            if (sizeof(T) == 2) {
+            T* o = wd + ((long)(ci0 + cil) * k + (k - 1 - tap)) * (PLANES * cout) + co0 + tx * 4;
+            if (PLANES == 3) {
+                const u32x2 h = (u32x2){pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+                *(u32x2*)o = h;
+                *(u32x2*)(o + cout) = h;
+                *(u32x2*)(o + 2 * cout) = pack_lo4(pv[0], pv[1], pv[2], pv[3]);
+            } else if (sizeof(T) == 2) {
                 *(u32x2*)o = (u32x2){pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
             } else {
                 *(f32x4*)o = pv;
@@ -208,9 +218,14 @@ __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __
     for (int r = 0; r < 2; ++r) {
         const int col = (threadIdx.x >> 3) + r * 32;
         const int ci4 = (threadIdx.x & 7) * 4;
-        T* o = wf + ((long)(co0 + col) * k + tap) * cin + ci0 + ci4;
+        T* o = wf + ((long)(co0 + col) * k + tap) * (PLANES * cin) + ci0 + ci4;
         const float a0 = tile[ci4][col], a1 = tile[ci4 + 1][col], a2 = tile[ci4 + 2][col], a3 = tile[ci4 + 3][col];
-        if (sizeof(T) == 2) {
+        if (PLANES == 3) {
+            const u32x2 h = (u32x2){pack_bf16x2(a0, a1), pack_bf16x2(a2, a3)};
+            *(u32x2*)o = h;
+            *(u32x2*)(o + cin) = h;
+            *(u32x2*)(o + 2 * cin) = pack_lo4(a0, a1, a2, a3);
+        } else if (sizeof(T) == 2) {
             *(u32x2*)o = (u32x2){pack_bf16x2(a0, a1), pack_bf16x2(a2, a3)};
         } else {
             *(f32x4*)o = (f32x4){a0, a1, a2, a3};
@@ -238,7 +253,7 @@ struct AdamTable {
     int k[SL_ADAM_MAX_LAYERS], cin[SL_ADAM_MAX_LAYERS], cout[SL_ADAM_MAX_LAYERS];
 };
 
-template <typename T, bool ADAM = true>
+template <typename T, bool ADAM = true, int PLANES = 1>
 __global__ __launch_bounds__(256) void adam_pack_multi_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ m, float* __restrict__ v, AdamTable t,
                                                               float lr_t, float b1, float b2, float eps) {
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(256) void adam_pack_multi_kernel(float* __restrict_
     const int bx = local % nx, by = (local / nx) % ny, bz = local / (nx * ny);
     const long off = t.offset[layer];
     if (!ADAM && bz == k) return;  // (the bias block has no operand copy)
-    adam_pack_block<T, ADAM>(tile, p + off, ADAM ? g + off : nullptr, ADAM ? m + off : nullptr, ADAM ? v + off : nullptr,
+    adam_pack_block<T, ADAM, PLANES>(tile, p + off, ADAM ? g + off : nullptr, ADAM ? m + off : nullptr, ADAM ? v + off : nullptr,
                              (T*)t.wf[layer], (T*)t.wd[layer], k, cin, cout, lr_t, b1, b2, eps, bx, by, bz);
 }
 
@@ -298,6 +313,21 @@ extern "C" int sl_adam_pack_layers(float* param, const float* grad, float* m, fl
         hipLaunchKernelGGL((adam_pack_multi_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m,
                            v, t, (float)lr_t, beta1, beta2, eps);
     return sl_check_launch("sl_adam_pack_layers");
+}
+
+extern "C" int sl_split3_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers,
+                                          int n_layers, int step, float lr, float beta1, float beta2, float eps, void* stream) {
+    SL_CHECK_ARG(param && grad && m && v && layers, "sl_split3_adam_pack_layers: null pointer");
+    SL_CHECK_ARG(n_layers >= 1 && n_layers <= SL_ADAM_MAX_LAYERS && step >= 1, "sl_split3_adam_pack_layers: 1..%d layers per call",
+                 SL_ADAM_MAX_LAYERS);
+    AdamTable t;
+    int blocks = 0;
+    const int rc = adam_table_from(layers, n_layers, "sl_split3_adam_pack_layers", &t, &blocks);
+    if (rc != SL_OK) return rc;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    hipLaunchKernelGGL((adam_pack_multi_kernel<unsigned short, true, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, param,
+                       grad, m, v, t, (float)lr_t, beta1, beta2, eps);
+    return sl_check_launch("sl_split3_adam_pack_layers");
 }
 
 extern "C" int sl_pack_layers(const float* param, const sl_adam_layer* layers, int n_layers, int dtype, void* stream) {

@@ -1237,7 +1237,6 @@ class Engine:
         elementwise launch, operands repacked lazily by the next forward()."""
         self.adam_iterations += 1
         st = self._stream()
-        fused = fused and self.planes == 1  # bf16x3: elementwise Adam, the plane operands are rebuilt by the next forward
         if not fused:
             self._launch("adam", "sl_adam_step", self.params.data_ptr(), self.grads.data_ptr(),
                          self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.param_numel, self.adam_iterations,
@@ -1269,10 +1268,15 @@ class Engine:
         for lo in range(0, len(layers), 16):
             chunk = layers[lo:lo + 16]
             table = self._adam_table(chunk)
-            self._launch("adam:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name),
-                         "sl_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
-                         self.adam_v.data_ptr(), table, len(chunk), self.dtype_code, self.adam_iterations, self.lr,
-                         self.beta_1, self.beta_2, self.adam_epsilon, st)
+            tag = "adam:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name)
+            if self.planes == 3:  # bf16x3: the [w_hi | w_hi | w_lo] operand rows are rewritten in the same pass
+                self._launch(tag, "sl_split3_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(),
+                             self.adam_m.data_ptr(), self.adam_v.data_ptr(), table, len(chunk), self.adam_iterations,
+                             self.lr, self.beta_1, self.beta_2, self.adam_epsilon, st)
+            else:
+                self._launch(tag, "sl_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(),
+                             self.adam_m.data_ptr(), self.adam_v.data_ptr(), table, len(chunk), self.dtype_code,
+                             self.adam_iterations, self.lr, self.beta_1, self.beta_2, self.adam_epsilon, st)
 
     def train_step(self, input_batch, label_batch, label_lengths, prediction_lengths, reducer=None):
         """One full optimisation step (forward, CTC, backward, [gradient all-reduce], Adam, weight repack).
@@ -1321,6 +1325,14 @@ class Engine:
 
     def _pack_layers(self, layers, st):
         """both operand copies of the given layers rewritten from the fp32 masters: one launch (sl_pack_layers)"""
+        if self.planes == 3:  # bf16x3: one launch per layer
+            for i in layers:
+                p = self.plans[i]
+                wv, _ = self.layer_param_views(self.params, p)
+                wd = self.w_dgrad[p.index]
+                self._launch("pack3:" + p.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
+                             wd.data_ptr() if wd is not None else None, p.spec.kernel_size, p.cin_pad, p.cout_pad, st)
+            return
         layers = list(layers)
         for lo in range(0, len(layers), 16):
             chunk = layers[lo:lo + 16]

@@ -118,6 +118,33 @@ def test_bf16x3_weight_pack_in_one_launch_equals_the_five_launch_sequence(hip_li
         assert torch.equal(d_new.view(torch.int16), d_old.view(torch.int16)), (k, cin, cout)
 
 
+def test_bf16x3_fused_adam_equals_the_elementwise_update_and_a_repack():
+    """sl_split3_adam_pack_layers (Adam on the masters and the [w_hi | w_hi | w_lo] operand rows in one pass) against
+    sl_adam_step + sl_split3_pack_weights per layer: masters, moments and both operand copies bit for bit, over three steps."""
+    import torch
+    case = make_case(b=2, t=96, seed=44)
+    engines = []
+    for fused in (True, False):
+        eng = make_engine(case, "bf16x3", lr=1e-3)
+        eng.load_input(case["x"])
+        eng.set_labels(case["labels"], np.array(case["label_lengths"]), np.array(case["prediction_lengths"]))
+        for _ in range(3):
+            eng.forward(training=True)
+            eng.ctc(grad_scale=0.5)
+            eng.backward()
+            eng.adam_step(fused=fused)
+            if not fused:
+                eng.repack_weights()
+        torch.cuda.synchronize()
+        engines.append(eng)
+    a, b = engines
+    assert torch.equal(a.params, b.params) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    for i in range(len(a.plans)):
+        assert torch.equal(a.w_fwd[i].view(torch.int16), b.w_fwd[i].view(torch.int16)), i
+        if a.w_dgrad[i] is not None:
+            assert torch.equal(a.w_dgrad[i].view(torch.int16), b.w_dgrad[i].view(torch.int16)), i
+
+
 # ------------------------------------------------------------------------------------------ fused inner layers: 48-frame tiles
 @pytest.mark.parametrize("b,t", [(3, 300), (2, 77), (8, 1200), (1, 96)])
 def test_fused_inner_layers_with_48_frame_tiles_are_bit_identical(hip_lib, b, t):
