@@ -159,8 +159,9 @@ def test_labeled_example_drop_in_feeds_the_net():
 @pytest.mark.gpu
 @pytest.mark.parametrize("mel", [128, None])
 def test_training_from_audio_in_hbm_equals_training_on_the_returned_spectrograms(tmp_path, mel):
-    """Wav2Letter.train(..., from_audio=True): raw audio is staged, the front end runs on the copy stream and the conv
-    stack reads its output in HBM (pipeline.AudioBatchStager) -- labeled_example.py:136-140 feeding net.py:593 without a
+    """Wav2Letter.train(..., from_audio=True): raw audio is staged, the front end runs in HBM (on the compute stream in
+    front of the step, or on the copy stream beside the previous one: both stager variants checked) and the conv
+    stack reads its output there (pipeline.AudioBatchStager) -- labeled_example.py:136-140 feeding net.py:593 without a
     host spectrogram.  The weights after the run must equal, bit for bit, those of the same run fed by
     LabeledExample.z_normalized_transposed_spectrogram() (GPU -> numpy -> host packer -> GPU), for the mel input of
     configuration 3 and the 257-bin linear input of configuration 5."""
@@ -190,3 +191,23 @@ def test_training_from_audio_in_hbm_equals_training_on_the_returned_spectrograms
     with pytest.raises(ValueError, match="prefetch_depth"):
         net.train(batches, preview_labeled_spectrogram_batch=batches[0][:2], tensor_board_log_directory=None,
                   net_directory=tmp_path / "x", batches_per_epoch=3, from_audio=True, prefetch_depth=0)
+    # the two places the front end can run: the same spectrograms, bit for bit
+    import torch
+    from speechless_amd.pipeline import AudioBatchStager
+    staged = {}
+    for on_copy in (False, True):
+        stager = AudioBatchStager(batches[:4], net._pack_audio_for_staging, net._audio_extractor(batches[0][0]),
+                                  net.input_to_prediction_length_ratio, net.engine.device,
+                                  blank=net.grapheme_encoding.grapheme_set_size - 1, depth=2, workers=1,
+                                  front_end_on_copy_stream=on_copy)
+        out = []
+        for item in stager:
+            torch.cuda.current_stream().wait_event(item.ready)
+            out.append(item.x_dev.clone())
+            stager.release(item)
+        torch.cuda.synchronize()
+        stager.close()
+        staged[on_copy] = out
+    assert len(staged[True]) == len(staged[False]) == 4
+    for a, b in zip(staged[True], staged[False]):
+        assert torch.equal(a, b)
