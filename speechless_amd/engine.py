@@ -202,7 +202,7 @@ class _Buffers:
                 if g is not None:
                     g.t_out = t_out
         for table in self.multi_tables.values():
-            for job in table:
+            for job in (table[0] if isinstance(table, tuple) else table):  # (bf16x3: (table, partial buffers, ...))
                 job.geom.t_out = t_out
         if t_out not in self._ws_sized_fwd:  # split counts (hence workspace sizes) depend on the number of time tiles
             self._ws_sized_fwd.add(t_out)
@@ -1070,23 +1070,46 @@ class Engine:
         first = self.frozen_layer_count
         pl = self.planes
         ones_in = self._ones_input_layers(first)
+        # the runs of identical layers (inner_conv_1..7): their 2 x 7 partial weight gradients (x planes against g_hi, against
+        # g_lo) in ONE balanced launch (sl_conv1d_wgrad_multi, a job per partial) at the lowest layer of the run -- they
+        # were 14 launches of 31 us + their reductions, 0.6 ms of the 6.8 ms step
+        multi = {}
+        if self.use_wgrad_multi:
+            for (s0, e0) in self.runs:
+                lo = max(s0, first)
+                layers = list(range(lo, e0 + 1))
+                if len(layers) >= 2 and 2 * len(layers) <= 16 and all(
+                        buf.wgrad_geom[i].cin % 256 == 0 and buf.wgrad_geom_b[i].cin % 256 == 0 and
+                        self.plans[i].cout_pad % 256 == 0 and self.plans[i].spec.stride == 1 and
+                        ("wgrad", self.specs[i].name) not in self.nt_cfg for i in layers):
+                    for i in layers:
+                        multi[i] = layers
+
+        def combine(p, ra, rb):
+            dw, _ = self.layer_param_views(self.grads, p)
+            frames = 2 if p.spec.stride == 2 else 1
+            self._launch("combine:" + p.spec.name, "sl_split3_wgrad_combine", ra.data_ptr(), rb.data_ptr(), dw.data_ptr(),
+                         p.spec.kernel_size, p.cin_pad, p.cout_pad, frames, pl * p.cin_pad if frames == 2 else 0,
+                         buf.wgrad_geom[p.index].cin, buf.wgrad_geom_b[p.index].cin, st)
+
         for p in reversed(self.plans[first:]):
             i = p.index
             x = buf.x0 if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
             wa, wb = buf.wgrad_geom[i], buf.wgrad_geom_b[i]
-            ra = buf.wgrad_r
-            rb = buf.wgrad_r[p.taps_view * wa.cin * p.cout_pad:]
-            g_lo = buf.g[i].data_ptr() + p.cout_pad * 2  # plane P1 of every row
-            cfg = self.nt_cfg.get(("wgrad", p.spec.name), 0)
-            self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), ra.data_ptr(),
-                         ctypes.byref(wa), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
-            self._launch("wgrad_lo:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), g_lo, rb.data_ptr(),
-                         ctypes.byref(wb), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
-            frames = 2 if p.spec.stride == 2 else 1
-            self._launch("combine:" + p.spec.name, "sl_split3_wgrad_combine", ra.data_ptr(), rb.data_ptr(), dw.data_ptr(),
-                         p.spec.kernel_size, p.cin_pad, p.cout_pad, frames, pl * p.cin_pad if frames == 2 else 0, wa.cin,
-                         wb.cin, st)
+            if i in multi:
+                if i == multi[i][0]:  # every gradient tensor of the run is complete here
+                    self._launch_wgrad_multi_x3(buf, multi[i], st, combine)
+            else:
+                ra = buf.wgrad_r
+                rb = buf.wgrad_r[p.taps_view * wa.cin * p.cout_pad:]
+                g_lo = buf.g[i].data_ptr() + p.cout_pad * 2  # plane P1 of every row
+                cfg = self.nt_cfg.get(("wgrad", p.spec.name), 0)
+                self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), ra.data_ptr(),
+                             ctypes.byref(wa), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+                self._launch("wgrad_lo:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), g_lo, rb.data_ptr(),
+                             ctypes.byref(wb), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+                combine(p, ra, rb)
             if i not in ones_in:
                 if self._x3_bias_ws is None:
                     self._x3_bias_ws = torch.empty((self.lib.raw("sl_split3_bias_grad_workspace_bytes")(
@@ -1103,6 +1126,38 @@ class Engine:
                              buf.rows * p.cin_pad * pl, 4 if self.specs[i - 1].activation == "elu" else 3, st)
         if ones_in:
             self._bias_grads_from_wgrad(ones_in, True, torch.cuda.current_stream(self.device))
+
+    def _launch_wgrad_multi_x3(self, buf, layers, st, combine):
+        """bf16x3: the partial weight gradients RA (x planes [hi | lo] against g_hi) and RB (x plane hi against g_lo) of
+        every layer of a run as jobs of one sl_conv1d_wgrad_multi launch, then sl_split3_wgrad_combine per layer"""
+        key = ("x3",) + tuple(layers)
+        entry = buf.multi_tables.get(key)
+        if entry is None:
+            sizes = [(self.plans[i].taps_view * buf.wgrad_geom[i].cin * self.plans[i].cout_pad,
+                      self.plans[i].taps_view * buf.wgrad_geom_b[i].cin * self.plans[i].cout_pad) for i in layers]
+            scratch = torch.empty((sum(a + b for a, b in sizes),), dtype=torch.float32, device=self.device)
+            table = (_lib.WgradJob * (2 * len(layers)))()
+            parts, off = [], 0
+            for n, (i, (na, nb)) in enumerate(zip(layers, sizes)):
+                ra, rb = scratch[off:off + na], scratch[off + na:off + na + nb]
+                off += na + nb
+                parts.append((ra, rb))
+                x = buf.y[i - 1]
+                for job, (g_ptr, out, geom) in zip((table[2 * n], table[2 * n + 1]),
+                                                   ((buf.g[i].data_ptr(), ra, buf.wgrad_geom[i]),
+                                                    (buf.g[i].data_ptr() + self.plans[i].cout_pad * 2, rb,
+                                                     buf.wgrad_geom_b[i]))):
+                    job.x, job.g, job.dw = x.data_ptr(), g_ptr, out.data_ptr()
+                    for name, _ in ConvGeom._fields_:
+                        setattr(job.geom, name, getattr(geom, name))
+            need = self.lib.raw("sl_conv1d_wgrad_multi_workspace_bytes")(table, len(table), self.dtype_code)
+            ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=self.device)
+            entry = buf.multi_tables[key] = (table, parts, scratch, ws)
+        table, parts, _, ws = entry
+        self._launch("wgrad:{}..{}".format(self.specs[layers[0]].name, self.specs[layers[-1]].name),
+                     "sl_conv1d_wgrad_multi", table, len(table), self.dtype_code, ws.data_ptr(), ws.numel(), st)
+        for i, (ra, rb) in zip(layers, parts):
+            combine(self.plans[i], ra, rb)
 
     def _wgrad_multi_layers(self, first, grouped=None):
         """layers whose weight gradients go into ONE sl_conv1d_wgrad_multi launch (at the lowest of them): the runs of

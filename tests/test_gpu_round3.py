@@ -145,6 +145,27 @@ def test_bf16x3_fused_adam_equals_the_elementwise_update_and_a_repack():
             assert torch.equal(a.w_dgrad[i].view(torch.int16), b.w_dgrad[i].view(torch.int16)), i
 
 
+def test_bf16x3_inner_layer_weight_gradients_in_one_balanced_launch():
+    """bf16x3 backward: the 2 x 7 partial weight gradients of inner_conv_1..7 as jobs of one sl_conv1d_wgrad_multi launch
+    against the fourteen sl_conv1d_wgrad launches they replace: the same fp32 sums in another split order (1e-6), every
+    other tensor bit-identical."""
+    import torch
+    case = make_case(b=3, t=300, seed=46)
+    res = {}
+    for multi in (True, False):
+        eng = make_engine(case, "bf16x3")
+        eng.use_wgrad_multi = multi
+        losses, grads = run_loss_and_grads(eng, case)
+        res[multi] = (losses, grads)
+        torch.cuda.synchronize()
+    assert np.array_equal(res[True][0], res[False][0])
+    for i, ((wa, ba), (wb, bb)) in enumerate(zip(res[True][1], res[False][1])):
+        if 1 <= i <= 7:
+            assert rel_l2(wa, wb) < 2e-6 and rel_l2(ba, bb) < 2e-6, (i, rel_l2(wa, wb), rel_l2(ba, bb))
+        else:
+            assert np.array_equal(wa, wb) and np.array_equal(ba, bb), i
+
+
 # ------------------------------------------------------------------------------------------ fused inner layers: 48-frame tiles
 @pytest.mark.parametrize("b,t", [(3, 300), (2, 77), (8, 1200), (1, 96)])
 def test_fused_inner_layers_with_48_frame_tiles_are_bit_identical(hip_lib, b, t):
