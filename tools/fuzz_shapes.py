@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Random shapes through the whole step (forward, CTC, backward, Adam) on the bf16 and the fp32 path of the REAL topology:
+batch 1..6, 20..1400 input frames (odd and even, across the 256-frame buffer buckets), ragged input lengths, labels from
+empty to the longest the frames allow.  Checks per case: finite losses and gradients, bf16 loss within 2e-3 of fp32, the
+same step twice = the same bits, rows outside the utterances untouched.  A geometry bug shows up here as a NaN, a mismatch
+or a library error long before it shows up in a benchmark.
+
+    python tools/fuzz_shapes.py [--cases 60] [--seed 0]"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    from speechless_amd.engine import Engine, wav2letter_layer_specs
+    from speechless_amd.net import Wav2Letter
+    specs = wav2letter_layer_specs(128, 29)
+    weights = Wav2Letter._glorot_uniform(specs, 2)
+    engines = {}
+    for dtype in ("bf16", "f32"):
+        eng = engines[dtype] = Engine(specs, 29, dtype=dtype)
+        eng.max_cached_shapes = 4
+    rng = np.random.RandomState(args.seed)
+    worst = 0.0
+    for case in range(args.cases):
+        b = int(rng.randint(1, 7))
+        t = int(rng.choice([rng.randint(20, 80), rng.randint(80, 600), rng.randint(600, 1400)]))
+        t_out = -(-t // 2)
+        x = rng.randn(b, t, 128).astype(np.float32)
+        pred_len = np.array([int(rng.randint(max(1, t_out // 3), t_out + 1)) for _ in range(b)], dtype=np.int32)
+        lab_len = np.array([int(rng.randint(0, max(1, min(200, p // 2)) + 1)) for p in pred_len], dtype=np.int32)
+        labels = -np.ones((b, max(1, int(lab_len.max()))), dtype=np.int32)
+        for i, n in enumerate(lab_len):
+            labels[i, :n] = rng.randint(0, 28, size=n)
+        out = {}
+        for dtype, eng in engines.items():
+            runs = []
+            for rep in range(2):
+                eng.set_weights(weights)
+                eng.adam_iterations = 0
+                eng.adam_m.zero_()
+                eng.adam_v.zero_()
+                loss = eng.train_step(x, labels, lab_len, pred_len).cpu().numpy().copy()
+                torch.cuda.synchronize()
+                runs.append((loss, eng.grads.clone(), eng.params.clone()))
+            assert np.array_equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and \
+                torch.equal(runs[0][2], runs[1][2]), ("not deterministic", dtype, b, t)
+            loss, grads, params = runs[0]
+            assert np.isfinite(loss).all(), (dtype, b, t, loss)
+            assert bool(torch.isfinite(grads).all()) and bool(torch.isfinite(params).all()), (dtype, b, t)
+            out[dtype] = loss
+        rel = float(np.max(np.abs(out["bf16"] - out["f32"]) / np.maximum(np.abs(out["f32"]), 1.0)))
+        worst = max(worst, rel)
+        assert rel < 2e-3, (b, t, pred_len, lab_len, out)
+        print("case %3d  b %d  t %4d  labels %s  loss %s  bf16 vs f32 %.1e" % (
+            case, b, t, lab_len.tolist(), np.round(out["f32"], 2).tolist(), rel), flush=True)
+    print("all %d cases passed; worst bf16-vs-f32 loss difference %.2e" % (args.cases, worst))
+
+
+if __name__ == "__main__":
+    main()
