@@ -133,6 +133,35 @@ def test_gpu_power_levels_and_floor():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_fft", [64, 128, 256, 1024])
+def test_gpu_power_levels_at_other_window_lengths(n_fft):
+    """sl_stft_power_db at every window length it accepts besides the reference's 512: the half-length complex transform
+    has an odd number of radix-2 stages for 64, 256 and 1024 (a lone last stage behind the paired ones) and an even one
+    for 128; levels against the float64 restatement as in the test above."""
+    import torch
+    from speechless_amd import _lib
+    hop = n_fft // 4
+    y = synthetic_audio(0.6, 17 + n_fft)
+    n_frames = 1 + len(y) // hop
+    bins = n_fft // 2 + 1
+    stride = (bins + 63) // 64 * 64
+    rows = n_frames + 5
+    dev = torch.device("cuda:0")
+    out = torch.full((1, rows, stride), 7.0, dtype=torch.float32, device=dev)
+    audio = torch.from_numpy(y).to(dev)
+    off = torch.zeros(1, dtype=torch.int64, device=dev)
+    length = torch.tensor([len(y)], dtype=torch.int32, device=dev)
+    _lib.lib().call("sl_stft_power_db", audio.data_ptr(), off.data_ptr(), length.data_ptr(), out.data_ptr(), 1, rows,
+                    n_fft, hop, stride, rows * stride, -150.0, torch.cuda.current_stream().cuda_stream)
+    got = out.cpu().numpy()[0]
+    want = so.power_level_from_power(np.abs(so.stft(y.astype(np.float64), n_fft=n_fft, hop_length=hop)) ** 2).T
+    assert want.shape == (n_frames, bins)
+    assert not got[n_frames:].any() and not got[:, bins:].any()
+    loud = want > want.max(axis=1, keepdims=True) - 60
+    assert np.abs(got[:n_frames, :bins] - want)[loud].max() < 5e-3
+
+
+@pytest.mark.gpu
 def test_labeled_example_drop_in_feeds_the_net():
     """speechless_amd.spectrogram.LabeledExample (duck type of labeled_example.py:74-140) through Wav2Letter: the same
     transcription and loss whether the net gets the GPU-made spectrogram or the restatement's."""
