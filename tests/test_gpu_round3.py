@@ -624,6 +624,27 @@ def test_wgrad_multi_against_the_per_layer_launches(b, t, f):
         assert not full[:, :, p.spec.cout:].any() and not full[:, p.spec.cin:p.cin_pad, :].any(), p.spec.name
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_pack_input_for_any_bin_count(hip_lib, dtype):
+    """sl_pack_input (a wave per input row, eight 64-bin loads in flight, a tail loop beyond 512 bins) for bin counts that are
+    not multiples of anything and for more than 512, odd row counts: every element where it belongs, nothing else touched."""
+    import torch
+    from speechless_amd import _lib
+    rng = np.random.RandomState(8)
+    st = torch.cuda.current_stream().cuda_stream
+    code, tdt = (_lib.SL_BF16, torch.bfloat16) if dtype == "bf16" else (_lib.SL_F32, torch.float32)
+    for b, t, f in ((1, 1, 3), (2, 7, 64), (3, 33, 257), (2, 5, 513), (1, 9, 700), (5, 130, 128)):
+        row_stride = (f + 63) // 64 * 64
+        rows = t + 6
+        x = torch.from_numpy(rng.randn(b, t, f).astype(np.float32)).cuda()
+        dst = torch.full((b, rows, row_stride), 7.0, dtype=tdt, device="cuda")
+        hip_lib.call("sl_pack_input", x.data_ptr(), dst.data_ptr(), b, t, f, 2, row_stride, rows * row_stride, code, st)
+        torch.cuda.synchronize()
+        want = torch.full((b, rows, row_stride), 7.0, dtype=tdt, device="cuda")
+        want[:, 2:2 + t, :f] = x.to(tdt)
+        assert torch.equal(dst, want), (b, t, f)
+
+
 # ------------------------------------------------------------------------------------------ random shapes
 def test_random_shapes_through_both_paths():
     """tools/fuzz_shapes.py, twelve cases: random batch sizes, frame counts across the buffer buckets, ragged input lengths,
