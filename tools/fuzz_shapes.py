@@ -19,11 +19,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--bins", type=int, default=128, help="input bins (257: the long-form configuration)")
+    ap.add_argument("--max-frames", type=int, default=1400)
+    ap.add_argument("--max-batch", type=int, default=6)
     args = ap.parse_args()
     import torch
     from speechless_amd.engine import Engine, wav2letter_layer_specs
     from speechless_amd.net import Wav2Letter
-    specs = wav2letter_layer_specs(128, 29)
+    specs = wav2letter_layer_specs(args.bins, 29)
     weights = Wav2Letter._glorot_uniform(specs, 2)
     engines = {}
     for dtype in ("bf16", "f32"):
@@ -32,10 +35,10 @@ def main():
     rng = np.random.RandomState(args.seed)
     worst = 0.0
     for case in range(args.cases):
-        b = int(rng.randint(1, 7))
-        t = int(rng.choice([rng.randint(20, 80), rng.randint(80, 600), rng.randint(600, 1400)]))
+        b = int(rng.randint(1, args.max_batch + 1))
+        t = int(rng.choice([rng.randint(20, 80), rng.randint(80, 600), rng.randint(600, max(601, args.max_frames))]))
         t_out = -(-t // 2)
-        x = rng.randn(b, t, 128).astype(np.float32)
+        x = rng.randn(b, t, args.bins).astype(np.float32)
         pred_len = np.array([int(rng.randint(max(1, t_out // 3), t_out + 1)) for _ in range(b)], dtype=np.int32)
         lab_len = np.array([int(rng.randint(0, max(1, min(200, p // 2)) + 1)) for p in pred_len], dtype=np.int32)
         labels = -np.ones((b, max(1, int(lab_len.max()))), dtype=np.int32)
