@@ -89,7 +89,10 @@ int sl_profile_next_kernel(void* start_event, void* stop_event);
  *   w      : packed weights [cout][taps][cin] dtype (see sl_pack_weights)
  *   bias   : float[cout] or NULL (SL_EPI_BIAS*)
  *   mask   : same geometry as y, dtype (SL_EPI_RELU_MASK) or NULL
- *   y      : [B][rows][y_row_stride]; dtype, or float when out_f32 != 0
+ *   y      : [B][rows][y_row_stride]; dtype, or float when out_f32 = 1.  out_f32 = 2 (bf16 only; epilogues NONE, BIAS,
+ *            BIAS_RELU, RELU_MASK): the result leaves the kernel as bf16x3 planes -- rows [hi | lo | hi] of 3 x cout
+ *            channels (y_row_stride >= 3 cout), hi = bf16(v), lo = bf16(v - hi) of the fp32 value v after the epilogue;
+ *            RELU_MASK then reads the mask's hi plane in y's geometry (what sl_split3 does in a second pass over HBM).
  *   cfg    : 0 = library picks the tile shape / pipeline depth / split-K for this geometry (measured table);
  *            otherwise (tuner / tests) wm | wn<<4 | stages<<8 | ksplit<<12 | it<<20 | m32<<24 | (1+log2 gm)<<25 |
  *            slab<<29 | interleaved<<30: wm x wn waves, each a (16*it) x 64 patch (it = 0 means 4; it = 5: the it = 4
@@ -334,7 +337,7 @@ int sl_adam_pack_layer(float* param, const float* grad, float* m, float* v, void
  * north_star: greedy-decoded indices bit-exact against the reference's fp32 CPU path (net.py:417-436 on Keras / TF float32),
  * gradients within 1e-3.  Every fp32 value is carried as two bf16 numbers (hi = bf16(v), lo = bf16(v - hi)) in THREE planes
  * per tensor row, [hi | lo | hi] (3 x channels), against packed weight rows [w_hi | w_hi | w_lo]: the unchanged
- * sl_conv1d_nt over 3 x channels then computes x_hi w_hi + x_lo w_hi + x_hi w_lo in fp32 (out_f32 into a staging buffer),
+ * sl_conv1d_nt over 3 x channels then computes x_hi w_hi + x_lo w_hi + x_hi w_lo in fp32 (out_f32 = 1 into a staging buffer, or out_f32 = 2 straight into planes),
  * and these HBM-bound helpers move between the fp32 staging form and the planes.  See csrc/split3.hip.
  *   sl_split3            fp32 [B][src rows][channels] (valid rows t < t_out) -> planes [B][rows][3 * channels] at row
  *                        dst_row0 + t.  mode 0: copy; 1: relu; 2: elu (Conv1D activations, net.py:304); 3 / 4: multiply by the

@@ -57,6 +57,7 @@ struct NtArgs {
     int y_row0, y_rs;
     long y_bs;
     int cout;
+    int out_planes;  // fp32-output kernels only: 0 = fp32 store; bf16x3 planes [hi | lo | hi] instead: 1 = after ReLU, 2 = as is, 3 = after the ReLU mask
     int w_rs;    // taps * cin
     int taps, cin;
     int nsteps;  // taps * cin / 64
@@ -160,6 +161,45 @@ __device__ __forceinline__ void store_run16(const NtArgs& a, float (&v)[16], con
         }
     }
     if (OUT_F32) {
+        if (a.out_planes) {
+            // bf16x3 (split3.hip): what sl_split3 would do to the fp32 tile in a second pass over HBM -- activation, then
+            // v = hi + lo in two bf16 planes, rows [hi | lo | hi] of 3 x cout channels.  A wave-uniform run-time branch
+            // inside the two fp32-output instantiations (BIAS, NONE): the bf16 kernels of the benchmarked path do not see it.
+            if (a.out_planes == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            if (a.out_planes == 3) {  // mask = the stored activation's hi plane, same geometry as y
+                const u32x4 m0 = *(const u32x4*)(a.mask + yidx);
+                const u32x4 m1 = *(const u32x4*)(a.mask + yidx + 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned int lo0 = m0[i] & 0xFFFFu, hi0 = m0[i] >> 16;
+                    const unsigned int lo1 = m1[i] & 0xFFFFu, hi1 = m1[i] >> 16;
+                    if (!(lo0 != 0 && lo0 < 0x8000u)) v[i * 2] = 0.f;
+                    if (!(hi0 != 0 && hi0 < 0x8000u)) v[i * 2 + 1] = 0.f;
+                    if (!(lo1 != 0 && lo1 < 0x8000u)) v[8 + i * 2] = 0.f;
+                    if (!(hi1 != 0 && hi1 < 0x8000u)) v[8 + i * 2 + 1] = 0.f;
+                }
+            }
+            u32x4 h0, h1, l0, l1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a0 = v[i * 2], a1 = v[i * 2 + 1], b0 = v[8 + i * 2], b1 = v[8 + i * 2 + 1];
+                h0[i] = pack_bf16x2(a0, a1);
+                h1[i] = pack_bf16x2(b0, b1);
+                l0[i] = pack_bf16x2(a0 - __uint_as_float(h0[i] << 16), a1 - __uint_as_float(h0[i] & 0xFFFF0000u));
+                l1[i] = pack_bf16x2(b0 - __uint_as_float(h1[i] << 16), b1 - __uint_as_float(h1[i] & 0xFFFF0000u));
+            }
+            __bf16* yo = (__bf16*)a.y + yidx;
+            *(u32x4*)(yo) = h0;
+            *(u32x4*)(yo + 8) = h1;
+            *(u32x4*)(yo + a.cout) = l0;
+            *(u32x4*)(yo + a.cout + 8) = l1;
+            *(u32x4*)(yo + 2 * a.cout) = h0;
+            *(u32x4*)(yo + 2 * a.cout + 8) = h1;
+            return;
+        }
         float* yo = (float*)a.y + yidx;
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(f32x4*)(yo + i * 4) = (f32x4){v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
@@ -1532,6 +1572,32 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
         }
     }
     if (OUT_F32) {
+        if (a.out_planes) {  // bf16x3 planes (see store_run16)
+            if (a.out_planes == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (a.out_planes == 3) {
+                const u32x4 m = *(const u32x4*)(a.mask + yidx);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned int lo = m[j] & 0xFFFFu, hi = m[j] >> 16;
+                    if (!(lo != 0 && lo < 0x8000u)) v[2 * j] = 0.f;
+                    if (!(hi != 0 && hi < 0x8000u)) v[2 * j + 1] = 0.f;
+                }
+            }
+            u32x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+                l[j] = pack_bf16x2(v[2 * j] - __uint_as_float(h[j] << 16), v[2 * j + 1] - __uint_as_float(h[j] & 0xFFFF0000u));
+            }
+            __bf16* yo = (__bf16*)a.y + yidx;
+            *(u32x4*)yo = h;
+            *(u32x4*)(yo + a.cout) = l;
+            *(u32x4*)(yo + 2 * a.cout) = h;
+            return;
+        }
         float* yo = (float*)a.y + yidx;
         *(f32x4*)yo = (f32x4){v[0], v[1], v[2], v[3]};
         *(f32x4*)(yo + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -1781,6 +1847,22 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
         return SL_ERR_INVALID_ARGUMENT;
     }
     NtArgs a;
+    a.out_planes = 0;
+    if (out_f32 == 2) {  // bf16x3 planes out of the fp32-output kernels: the activation moves from the template to a.out_planes
+        if (epilogue == SL_EPI_BIAS_RELU) {
+            a.out_planes = 1;
+            epilogue = SL_EPI_BIAS;
+        } else if (epilogue == SL_EPI_BIAS || epilogue == SL_EPI_NONE) {
+            a.out_planes = 2;
+        } else if (epilogue == SL_EPI_RELU_MASK) {
+            a.out_planes = 3;
+            epilogue = SL_EPI_NONE;
+        } else {
+            sl_set_error("sl_conv1d_nt(bf16): out_f32 = 2 (bf16x3 planes) goes with the epilogues NONE, BIAS, BIAS_RELU, RELU_MASK");
+            return SL_ERR_UNSUPPORTED;
+        }
+        out_f32 = 1;
+    }
     a.x = (const __bf16*)x;
     a.w = (const __bf16*)w;
     a.bias = bias;

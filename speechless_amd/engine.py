@@ -159,6 +159,7 @@ class _Buffers:
         # bf16x3: fp32 staging buffer of a layer's pre-activations / input gradients (sl_conv1d_nt out_f32 -> sl_split3)
         self.stage32 = torch.empty((batch * self.tt_pad * max(p.cout_pad for p in eng.plans),), dtype=torch.float32,
                                    device=dev) if pl > 1 else None
+        self.plane_geoms = {}  # bf16x3: (kind, layer) -> geometry whose output side describes a plane tensor
         self.wgrad_r = None  # bf16x3: the two partial weight gradients (RA | RB) in front of sl_split3_wgrad_combine
         self.wgrad_geom_b = [None] * n
         self.wgrad_geom = [None] * n
@@ -204,6 +205,8 @@ class _Buffers:
         for table in self.multi_tables.values():
             for job in (table[0] if isinstance(table, tuple) else table):  # (bf16x3: (table, partial buffers, ...))
                 job.geom.t_out = t_out
+        for g in self.plane_geoms.values():
+            g.t_out = t_out
         if t_out not in self._ws_sized_fwd:  # split counts (hence workspace sizes) depend on the number of time tiles
             self._ws_sized_fwd.add(t_out)
             self.size_nt_workspace(eng, self.fwd_geom, "fwd")
@@ -437,6 +440,7 @@ class Engine:
         # launch + a 128 x 128-tile launch with utterance-granular batch splits.  SL_WGRAD_MULTI=0: those launches.
         self.use_wgrad_multi = os.environ.get("SL_WGRAD_MULTI", "1") != "0"
         self.small_bias_pass_on_main = os.environ.get("SL_BIAS_MAIN", "1") != "0"  # A/B knob
+        self.x3_fused_epilogue = os.environ.get("SL_X3_FUSED_EPILOGUE", "1") != "0"  # bf16x3: activation + plane split in the NT epilogue
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
         # Launch lists: the ~60 C-ABI calls and 4 stream hand-overs of a step are recorded the first time a buffer set
         # runs them and replayed afterwards with their arguments already marshalled -- the Python around each launch
@@ -769,18 +773,40 @@ class Engine:
         finally:
             self._rec = None
 
+    def _plane_geom(self, buf, kind, i, channels):
+        """the NT geometry of layer i (kind 'fwd' / 'dgrad') with its OUTPUT side describing a bf16x3 plane tensor of
+        `channels` padded channels (rows of 3 x channels behind HALO halo rows) instead of the fp32 staging buffer"""
+        g = buf.plane_geoms.get((kind, i))
+        if g is None:
+            src = (buf.fwd_geom if kind == "fwd" else buf.dgrad_geom)[i]
+            g = ConvGeom()
+            for name, _ in ConvGeom._fields_:
+                setattr(g, name, getattr(src, name))
+            g.y_row0, g.y_row_stride, g.y_batch_stride = HALO, self.planes * channels, buf.rows * channels * self.planes
+            buf.plane_geoms[(kind, i)] = g
+        return g
+
     def _forward_x3(self, buf, st):
-        """bf16x3: every layer = the unchanged NT kernel over the three planes (fp32 into the staging buffer) + sl_split3
-        (activation, back to planes); the last layer's fp32 logits go to the softmax as on the other paths."""
+        """bf16x3: every layer = the unchanged NT kernel over the three planes.  ReLU layers: bias, ReLU and the split into
+        planes in the kernel's own epilogue (out_f32 = 2); ELU layers: fp32 into the staging buffer + sl_split3.  The last
+        layer's fp32 logits go to the softmax as on the other paths."""
         n = len(self.plans)
         x = buf.x0
         for p in self.plans:
             last = p.index == n - 1
             _, bias = self.layer_param_views(self.params, p)
+            cfg = self.nt_cfg.get(("fwd", p.spec.name), 0)
+            if not last and p.spec.activation == "relu" and self.x3_fused_epilogue:
+                y = buf.y[p.index]
+                self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(),
+                             bias.data_ptr(), None, y.data_ptr(), ctypes.byref(self._plane_geom(buf, "fwd", p.index, p.cout_pad)),
+                             _lib.EPI_BIAS_RELU, self.dtype_code, 2, cfg, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+                x = y
+                continue
             out = buf.logits if last else buf.stage32
             self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(),
                          None, out.data_ptr(), ctypes.byref(buf.fwd_geom[p.index]), _lib.EPI_BIAS, self.dtype_code, 1,
-                         self.nt_cfg.get(("fwd", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+                         cfg, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
             if not last:
                 y = buf.y[p.index]
                 self._launch("split:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), y.data_ptr(), None, buf.batch,
@@ -1117,7 +1143,13 @@ class Engine:
                 self._launch("bgrad:" + p.spec.name, "sl_split3_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), buf.batch,
                              buf.t_out, p.cout_pad, HALO, buf.rows * p.cout_pad * pl, self._x3_bias_ws.data_ptr(),
                              self._x3_bias_ws.numel(), st)
-            if i > first:
+            if i > first and self.specs[i - 1].activation == "relu" and self.x3_fused_epilogue:
+                # the ReLU mask (the hi plane of the stored activation) and the split into planes in the NT kernel's epilogue
+                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
+                             buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(),
+                             ctypes.byref(self._plane_geom(buf, "dgrad", i, p.cin_pad)), _lib.EPI_RELU_MASK, self.dtype_code,
+                             2, self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+            elif i > first:
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
                              None, buf.stage32.data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_NONE, self.dtype_code, 1,
                              self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)

@@ -166,6 +166,28 @@ def test_bf16x3_inner_layer_weight_gradients_in_one_balanced_launch():
             assert np.array_equal(wa, wb) and np.array_equal(ba, bb), i
 
 
+@pytest.mark.parametrize("b,t", [(3, 300), (2, 77), (4, 1000)])
+def test_bf16x3_activation_and_plane_split_in_the_kernel_epilogue(b, t):
+    """bf16x3: bias + ReLU (forward) resp. the ReLU mask (input gradients) and the split into [hi | lo | hi] planes inside the
+    NT kernel's epilogue (sl_conv1d_nt with out_f32 = 2; also behind split K) against the fp32 staging buffer + sl_split3 it
+    replaces: the same operations in the same order -- every activation, gradient, loss and weight gradient bit for bit."""
+    import torch
+    case = make_case(b=b, t=t, seed=47 + t)
+    res = {}
+    for fused in (True, False):
+        eng = make_engine(case, "bf16x3")
+        eng.x3_fused_epilogue = fused
+        losses, grads = run_loss_and_grads(eng, case)
+        res[fused] = (losses, [y.clone() for y in eng.cur.y[:-1]], [g.clone() for g in eng.cur.g], grads)
+        torch.cuda.synchronize()
+    assert np.array_equal(res[True][0], res[False][0])
+    for k in (1, 2):
+        for i, (a, c) in enumerate(zip(res[True][k], res[False][k])):
+            assert torch.equal(a.view(torch.int16), c.view(torch.int16)), (k, i)
+    for (wa, ba), (wb, bb) in zip(res[True][3], res[False][3]):
+        assert np.array_equal(wa, wb) and np.array_equal(ba, bb)
+
+
 # ------------------------------------------------------------------------------------------ fused inner layers: 48-frame tiles
 @pytest.mark.parametrize("b,t", [(3, 300), (2, 77), (8, 1200), (1, 96)])
 def test_fused_inner_layers_with_48_frame_tiles_are_bit_identical(hip_lib, b, t):
