@@ -370,6 +370,14 @@ int sl_split3_wgrad_combine(const float* ra, const float* rb, float* dw, int tap
 size_t sl_split3_bias_grad_workspace_bytes(int channels);
 int sl_split3_bias_grad(const void* g, float* db, int batch, int t_out, int channels, int g_row0, int64_t g_batch_stride,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* Dropout on a plane tensor of `rows` rows of [hi | lo | hi] over `channels` channels (Keras Dropout, net.py:301-303, on the
+ * bf16x3 path).  The keep decision of (row r, channel c) is the one sl_dropout draws for element r * channels + c of the
+ * single-plane tensor of the same logical shape, so a seed means the same masks on every path; values are re-split after the
+ * arithmetic.  mode 0: dst = keep ? v / (1 - rate) : 0 (forward);  mode 1: dst = v / (1 - rate) (what is left of
+ * d dropout / dx behind a ReLU, cf. sl_scale);  mode 2: dst = keep ? v / (1 - rate) * elu'(z) : 0 with y the stored
+ * post-dropout activation (cf. sl_elu_dropout_backward).  dst may be src. */
+int sl_split3_dropout(const void* src, void* dst, const void* y, int64_t rows, int channels, int mode, float rate,
+                      uint64_t seed, void* stream);
 
 /* ---- audio front end (speechless/labeled_example.py:99-160, 28-29) ---------------------------
  * sl_stft_power_db: librosa.stft(y, n_fft, hop_length) with its defaults (periodic Hann window of n_fft samples,

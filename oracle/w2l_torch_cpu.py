@@ -28,13 +28,17 @@ def to_torch_weights(weights, requires_grad=True):
     return out
 
 
-def forward_probs(specs, tweights, input_batch):
-    """input_batch: torch (B,T,F) float32.  Returns probabilities (B,T',K)."""
+def forward_probs(specs, tweights, input_batch, masks=None):
+    """input_batch: torch (B,T,F) float32.  Returns probabilities (B,T',K).  masks: optional list that receives, per
+    hidden layer, the bool tensor (B,T',C) of pre-activations > 0 (the ReLU decisions; bench.py `parity` counts how many
+    of them each float32 implementation takes differently from the float64 run, oracle/w2l_float64.py)."""
     x = input_batch.transpose(1, 2)  # (B,C,T)
     for spec, (w, b) in zip(specs, tweights):
         t_in = x.shape[2]
         _, pad_l, pad_r = same_padding(t_in, spec.kernel_size, spec.stride)
         x = F.conv1d(F.pad(x, (pad_l, pad_r)), w, b, stride=spec.stride)
+        if masks is not None and spec.activation in ("relu", "elu"):
+            masks.append((x.detach() > 0).transpose(1, 2).contiguous())
         if spec.activation == "relu":
             x = F.relu(x)
         elif spec.activation == "softmax":
@@ -104,11 +108,12 @@ def timed_training_steps(specs, weights, input_batch, labels, prediction_lengths
         t0 = time.perf_counter()
         for p in params:
             p.grad = None
-        probs = forward_probs(specs, tweights, x)
+        masks = [] if (record_first and it == 0) else None
+        probs = forward_probs(specs, tweights, x, masks)
         losses = per_utterance_ctc(probs, labels, prediction_lengths, label_lengths, eps)
         losses.mean().backward()
         if record_first and it == 0:
-            record = dict(losses=losses.detach().numpy().copy(), probs=probs.detach().numpy().copy(),
+            record = dict(masks=masks, losses=losses.detach().numpy().copy(), probs=probs.detach().numpy().copy(),
                           grads=[(np.ascontiguousarray(np.transpose(w.grad.numpy(), (2, 1, 0))), b.grad.numpy().copy())
                                  for (w, b) in tweights])
         keras_adam_update(params, state, it + 1, lr=lr)

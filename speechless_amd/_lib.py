@@ -123,6 +123,7 @@ SIGNATURES = {
     "sl_split3_wgrad_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),
     "sl_split3_bias_grad_workspace_bytes": (c_size_t, [c_int]),
+    "sl_split3_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, ctypes.c_uint64, c_void_p]),
     "sl_split3_bias_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t, c_void_p]),
     "sl_conv1d_wgrad_multi_workspace_bytes": (c_size_t, [POINTER(WgradJob), c_int, c_int]),
     "sl_conv1d_wgrad_multi": (c_int, [POINTER(WgradJob), c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -63,6 +63,16 @@ __device__ __forceinline__ unsigned int pack_bf16x2_hw(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
 
+// dropout: counter-based generator, one 64-bit mix (splitmix64 finaliser) of (seed, element index) -> 32 uniform bits.  The
+// mask of an element depends only on (seed, index), so a step is reproducible from its seed and no state is kept.
+__device__ __forceinline__ unsigned int dropout_bits(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned int)(z >> 32);
+}
+
 // XCD-aware work-group remap: the dispatcher places block b on XCD b % 8 (speed only, never correctness).
 // Gives each XCD a contiguous range of logical ids so that neighbouring tiles share the XCD's private L2.
 __device__ __forceinline__ int xcd_remap(int bid, int total) {

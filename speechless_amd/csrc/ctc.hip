@@ -515,6 +515,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         // thread of the work-group raises the work-group's OWN done slot (a device-scope release here writes back the
         // whole L2 -- 2000 of them cost 60 us; tickets added to one counter per utterance serialise at 0.2-0.4 us each
         // across the XCDs -- 11 us with returning adds, what the two launches had cost, 25 us polled).
+        // (gfx9-family ISA, gfx950 included: vmcnt counts loads AND stores, so vmcnt(0) means this wave's gradient stores
+        // were acknowledged by L2; gfx10+ moved stores to vscnt -- this file is built for gfx950 only.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int siblings = (int)gridDim.x - 1;
@@ -541,6 +543,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         __syncthreads();
         if (s_flag == 0 || T <= 0) return;
         if (s_flag < 0) {
+            // the host-visible error: the utterance's loss is NaN (and so is the batch mean Wav2Letter.train logs and the
+            // value train_on_batch returns), never a plausible number next to a stale gradient
             if (tid == 0) loss[b] = NAN;
             return;
         }

@@ -461,16 +461,6 @@ extern "C" int sl_bias_grad(const void* g, float* db, const sl_conv_geom* geom, 
 
 namespace {
 
-// counter-based generator: one 64-bit mix (splitmix64 finaliser) of (seed, element index) -> 32 uniform bits.  The
-// mask of an element depends only on (seed, index), so a step is reproducible from its seed and no state is kept.
-__device__ __forceinline__ unsigned int dropout_bits(unsigned long long seed, unsigned long long idx) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned int)(z >> 32);
-}
-
 // y = keep ? x * 1/(1-rate) : 0   (Keras inverted dropout, training phase).  4 elements per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ src, T* __restrict__ dst, long n,

@@ -191,7 +191,83 @@ __global__ __launch_bounds__(256) void bias_grad3_final_kernel(const float* __re
     db[ch] = s;
 }
 
+// Dropout on a plane tensor (rows of [hi | lo | hi] over c channels).  The keep decision of the element in row r, channel ch
+// is dropout_bits(seed, r * c + ch): the index misc.hip's dropout_kernel uses on the single-plane tensor of the same logical
+// shape, so a seed draws the same masks on every path.  The value is re-split after the arithmetic (scaling the two planes
+// separately would round each to bf16 and leave 2^-9, not 2^-17).
+//   MODE 0  forward:   dst = keep ? (hi + lo) * scale : 0                       (Keras inverted dropout, training phase)
+//   MODE 1  scale:     dst = (hi + lo) * scale                                  (the 1 / (1 - rate) left of d dropout / dx
+//                                                                                behind a ReLU: its mask epilogue saw the
+//                                                                                post-dropout activation)
+//   MODE 2  ELU bwd:   dst = keep ? (hi + lo) * scale * elu'(z) : 0, elu'(z) = m > 0 ? 1 : m * keep_prob + 1 with m the stored
+//                      post-dropout activation y (planes, same geometry)
+template <int MODE>
+__global__ __launch_bounds__(256) void split3_dropout_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                                             const unsigned short* __restrict__ y, long n, int c,
+                                                             unsigned int threshold, float scale, float keep_prob,
+                                                             unsigned long long seed) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;  // logical element index (row * c + channel), 8 per thread
+    if (i >= n) return;
+    const long r = i / c;
+    const int ch = (int)(i - r * c);
+    const long row = r * 3 * c;
+    const u32x4 sh = *(const u32x4*)(src + row + ch), sl = *(const u32x4*)(src + row + c + ch);
+    u32x4 yh = (u32x4){0u, 0u, 0u, 0u}, yl = yh;
+    if (MODE == 2) {
+        yh = *(const u32x4*)(y + row + ch);
+        yl = *(const u32x4*)(y + row + c + ch);
+    }
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned hw = sh[j >> 1], lw = sl[j >> 1];
+        float v = (j & 1) ? __uint_as_float(hw & 0xFFFF0000u) + __uint_as_float(lw & 0xFFFF0000u)
+                          : __uint_as_float(hw << 16) + __uint_as_float(lw << 16);
+        const bool keep = MODE == 1 || dropout_bits(seed, (unsigned long long)(i + j)) >= threshold;
+        float d = scale;
+        if (MODE == 2) {
+            const unsigned a = yh[j >> 1], b = yl[j >> 1];
+            const float m = (j & 1) ? __uint_as_float(a & 0xFFFF0000u) + __uint_as_float(b & 0xFFFF0000u)
+                                    : __uint_as_float(a << 16) + __uint_as_float(b << 16);
+            d = m > 0.f ? scale : scale * (m * keep_prob + 1.f);
+        }
+        v = keep ? v * d : 0.f;
+        split2(v, hi[j], lo[j]);
+    }
+    u32x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (unsigned)hi[2 * j] | ((unsigned)hi[2 * j + 1] << 16);
+        l[j] = (unsigned)lo[2 * j] | ((unsigned)lo[2 * j + 1] << 16);
+    }
+    *(u32x4*)(dst + row + ch) = h;
+    *(u32x4*)(dst + row + c + ch) = l;
+    *(u32x4*)(dst + row + 2 * c + ch) = h;
+}
+
 }  // namespace
+
+extern "C" int sl_split3_dropout(const void* src, void* dst, const void* y, int64_t rows, int channels, int mode, float rate,
+                                 uint64_t seed, void* stream) {
+    SL_CHECK_ARG(src && dst && rows > 0 && channels > 0 && channels % 8 == 0, "sl_split3_dropout: channels must be a multiple of 8");
+    SL_CHECK_ARG(mode >= 0 && mode <= 2 && (mode != 2 || y), "sl_split3_dropout: mode 0..2, mode 2 needs the stored activation");
+    SL_CHECK_ARG(rate >= 0.f && rate < 1.f, "sl_split3_dropout: rate %f outside [0, 1)", (double)rate);
+    const unsigned int threshold = (unsigned int)((double)rate * 4294967296.0);
+    const float scale = 1.f / (1.f - rate);
+    const long n = (long)rows * channels;
+    const dim3 grid((unsigned)((n / 8 + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+#define SL_DROP3(M_)                                                                                                       \
+    hipLaunchKernelGGL(split3_dropout_kernel<M_>, grid, dim3(256), 0, s, (const unsigned short*)src, (unsigned short*)dst, \
+                       (const unsigned short*)y, n, channels, threshold, scale, 1.f - rate, (unsigned long long)seed)
+    switch (mode) {
+        case 0: SL_DROP3(0); break;
+        case 1: SL_DROP3(1); break;
+        default: SL_DROP3(2); break;
+    }
+#undef SL_DROP3
+    return sl_check_launch("sl_split3_dropout");
+}
 
 extern "C" int sl_split3(const float* src, void* dst, const void* mask, int batch, int t_out, int channels,
                          int64_t src_batch_stride, int dst_row0, int64_t dst_batch_stride, int mode, void* stream) {

@@ -454,10 +454,10 @@ class Engine:
         self.use_launch_lists = os.environ.get("SL_LAUNCH_LISTS", "1") != "0"
         if self.planes > 1:  # the fused launches read and write single-plane bf16 tensors
             self.use_chain = self.fuse_output_softmax = self.fuse_output_backward = self.group_wgrad = False
-            self.use_launch_lists = False
             self._x3_bias_ws = None
         self._rec = None
         self._adam_tables = {}
+        self._sharded_reducer = None  # the reducer of the last step, if that step ran Adam on this rank's slices only
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -568,8 +568,13 @@ class Engine:
         # one launch writes the weight gradients of the striding layer and of the run above it: one bucket
         multi = self._wgrad_multi_layers(first)
         if multi and multi[0] == 0:
-            merged = sorted(set(l for g in groups for l in g if l in multi))
-            groups = [g for g in groups if not set(g) & set(multi)] + [merged]
+            # every bucket that holds a layer of the launch becomes part of ONE bucket closed at the launch (its lowest
+            # layer) -- whole buckets, so that with several runs a layer between them is neither left out of the merged
+            # range nor reduced twice; the merged layers are then contiguous from layer 0 up
+            span = set(range(multi[0], multi[-1] + 1))
+            merged = sorted(set(l for g in groups if set(g) & span for l in g))
+            groups = [g for g in groups if not set(g) & span] + [merged]
+            assert merged == list(range(merged[0], merged[-1] + 1)), merged
         plan = []
         for layers in groups:
             if layers:
@@ -634,11 +639,22 @@ class Engine:
         return self._unpad(self.params)
 
     def get_gradients(self):
+        """The gradients of the last backward pass in the Keras layout.  (After a data-parallel step with a sharded
+        optimizer only this rank's slice of every bucket holds the reduced gradient: reduce-scatter, not all-reduce.)"""
         return self._unpad(self.grads)
 
     def get_optimizer_state(self):
         """Adam moments in the Keras layout (per layer (m_W, m_b), (v_W, v_b)), the step count and the dropout step
-        counter: everything beyond the weights that the next step depends on."""
+        counter: everything beyond the weights that the next step depends on.
+        After a step with a sharded optimizer (GradBucketReducer(shard_optimizer=True)) every rank holds the moments of its
+        own slice of each bucket only: they are all-gathered here first, bucket by bucket with the slices of gather_bucket --
+        a COLLECTIVE call in that case (every rank must make it; Wav2Letter.train does, each rank saves at the same epoch)."""
+        reducer = self._sharded_reducer
+        if reducer is not None and (reducer.world_size > 1 or reducer.force):
+            for flat in (self.adam_m, self.adam_v):
+                for b in range(len(reducer.ranges)):
+                    reducer.gather_bucket(b, flat)
+            reducer.wait_all()
         return {"m": self._unpad(self.adam_m), "v": self._unpad(self.adam_v), "iterations": int(self.adam_iterations),
                 "dropout_steps": int(self._dropout_steps)}
 
@@ -786,12 +802,32 @@ class Engine:
             buf.plane_geoms[(kind, i)] = g
         return g
 
-    def _forward_x3(self, buf, st):
+    def _dropout_x3(self, tag, src, dst, y, channels, mode, seed, st):
+        """sl_split3_dropout over a whole plane tensor (halo rows and padding included: zeros stay zeros)"""
+        self._launch(tag, "sl_split3_dropout", src.data_ptr(), dst.data_ptr(), y.data_ptr() if y is not None else None,
+                     src.numel() // (self.planes * channels), channels, mode, self.dropout_rate, seed, st)
+
+    def _forward_x3(self, buf, st, rate=None):
         """bf16x3: every layer = the unchanged NT kernel over the three planes.  ReLU layers: bias, ReLU and the split into
         planes in the kernel's own epilogue (out_f32 = 2); ELU layers: fp32 into the staging buffer + sl_split3.  The last
-        layer's fp32 logits go to the softmax as on the other paths."""
+        layer's fp32 logits go to the softmax as on the other paths.  Dropout (training, net.py:301-303): sl_split3_dropout
+        on the packed input (into a second buffer) and in place on every activation that feeds a layer with a Dropout in
+        front of it -- the same (seed, element) keep decisions as sl_dropout draws on the single-plane paths."""
         n = len(self.plans)
         x = buf.x0
+        if rate:
+            self._dropout_steps += 1
+            seed0 = buf.dropout_seed0 = (self.dropout_seed * 1000003 + self._dropout_steps) * 64
+            if buf.x0_dropped is None:
+                buf.x0_dropped = torch.zeros_like(buf.x0)
+            self._dropout_x3("dropout:input", buf.x0, buf.x0_dropped, None, self.plans[0].cin_pad, 0, seed0, st)
+            x = buf.x0_dropped
+
+        def drop(p):
+            if rate and (p.index + 1) in self._dropout_layers():
+                y = buf.y[p.index]
+                self._dropout_x3("dropout:" + p.spec.name, y, y, None, p.cout_pad, 0, seed0 + p.index + 1, st)
+
         for p in self.plans:
             last = p.index == n - 1
             _, bias = self.layer_param_views(self.params, p)
@@ -801,6 +837,7 @@ class Engine:
                 self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(),
                              bias.data_ptr(), None, y.data_ptr(), ctypes.byref(self._plane_geom(buf, "fwd", p.index, p.cout_pad)),
                              _lib.EPI_BIAS_RELU, self.dtype_code, 2, cfg, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+                drop(p)
                 x = y
                 continue
             out = buf.logits if last else buf.stage32
@@ -812,6 +849,7 @@ class Engine:
                 self._launch("split:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), y.data_ptr(), None, buf.batch,
                              buf.t_out, p.cout_pad, buf.tt_pad * p.cout_pad, HALO, buf.rows * p.cout_pad * self.planes,
                              2 if p.spec.activation == "elu" else 1, st)
+                drop(p)
                 x = y
         self._launch("softmax", "sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
                      buf.t_out, self.grapheme_set_size, self.plans[-1].cout_pad, buf.tt_pad * self.plans[-1].cout_pad,
@@ -820,9 +858,7 @@ class Engine:
 
     def _forward_eager(self, buf, rate, fuse_out, st):
         if self.planes > 1:
-            if rate:
-                raise NotImplementedError("dropout is not implemented on the bf16x3 path")
-            return self._forward_x3(buf, st)
+            return self._forward_x3(buf, st, rate)
         n = len(self.plans)
         x = buf.x0
         if rate:
@@ -979,7 +1015,8 @@ class Engine:
         key = None if buf.dropped else ("bwd", main.cuda_stream, on_bucket_ready is not None, self.ones_channel,
                                         self.frozen_layer_count, self.group_wgrad, self.use_chain, self.fuse_output_backward,
                                         self.use_wgrad_multi, self.small_bias_pass_on_main,
-                                        tuple(sorted(self.nt_cfg.items())))
+                                        tuple(sorted(self.nt_cfg.items())),
+                                        buf.t_out if self.planes > 1 else None)  # (bf16x3 helpers take it by value)
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
             self._replay(ops, on_bucket_ready)
@@ -1089,13 +1126,22 @@ class Engine:
             self._launch("dropout_scale:" + p.spec.name, "sl_scale", buf.g[i - 1].data_ptr(), buf.g[i - 1].numel(),
                          self.dtype_code, 1.0 / (1.0 - self.dropout_rate), st)
 
-    def _backward_x3(self, buf, st):
+    def _backward_x3(self, buf, st, on_bucket_ready=None):
         """bf16x3 backward: per layer the weight gradient of the [hi | lo] prefixes + sl_split3_wgrad_combine, the input
         gradient through the unchanged NT kernel (fp32 staging) + sl_split3 with the activation mask.  Bias gradients:
-        row cin_pad - 1 of dW where the input carries the ones channel (hi = 1, lo = 0), sl_split3_bias_grad elsewhere."""
+        row cin_pad - 1 of dW where the input carries the ones channel (hi = 1, lo = 0), sl_split3_bias_grad elsewhere (and
+        everywhere when dropout touched the ones).  Everything runs on ONE stream, so a gradient bucket (bucket_plan) is
+        complete the moment the launches of its lowest layer are enqueued: on_bucket_ready(b) is called there, exactly as
+        _backward_eager does for the single-plane paths."""
         first = self.frozen_layer_count
         pl = self.planes
         ones_in = self._ones_input_layers(first)
+        ones_db = set() if buf.dropped else set(ones_in)  # rows that hold a bias gradient (else: only to be zeroed)
+        main = torch.cuda.current_stream(self.device)
+        bucket_at = {}
+        if on_bucket_ready is not None:
+            for b, (layers, _) in enumerate(self.bucket_plan()):
+                bucket_at[layers[0]] = (b, layers)
         # the runs of identical layers (inner_conv_1..7): their 2 x 7 partial weight gradients (x planes against g_hi, against
         # g_lo) in ONE balanced launch (sl_conv1d_wgrad_multi, a job per partial) at the lowest layer of the run -- they
         # were 14 launches of 31 us + their reductions, 0.6 ms of the 6.8 ms step
@@ -1120,7 +1166,7 @@ class Engine:
 
         for p in reversed(self.plans[first:]):
             i = p.index
-            x = buf.x0 if i == 0 else buf.y[i - 1]
+            x = (buf.x0_dropped if buf.dropped else buf.x0) if i == 0 else buf.y[i - 1]
             dw, db = self.layer_param_views(self.grads, p)
             wa, wb = buf.wgrad_geom[i], buf.wgrad_geom_b[i]
             if i in multi:
@@ -1136,13 +1182,34 @@ class Engine:
                 self._launch("wgrad_lo:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), g_lo, rb.data_ptr(),
                              ctypes.byref(wb), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
                 combine(p, ra, rb)
-            if i not in ones_in:
+            if i not in ones_db:
                 if self._x3_bias_ws is None:
                     self._x3_bias_ws = torch.empty((self.lib.raw("sl_split3_bias_grad_workspace_bytes")(
                         max(q.cout_pad for q in self.plans)),), dtype=torch.uint8, device=self.device)
                 self._launch("bgrad:" + p.spec.name, "sl_split3_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), buf.batch,
                              buf.t_out, p.cout_pad, HALO, buf.rows * p.cout_pad * pl, self._x3_bias_ws.data_ptr(),
                              self._x3_bias_ws.numel(), st)
+            if i in bucket_at:
+                b, layers = bucket_at[i]
+                rows = [j for j in layers if j in ones_in]
+                if rows:
+                    self._bias_grads_from_wgrad(rows, bool(ones_db), main)
+                on_bucket_ready(b)
+                if self._rec is not None:
+                    self._rec.append((2, b))
+            dropped_in = buf.dropped and i in self._dropout_layers()  # a Dropout sits between y[i - 1] and layer i
+            if i > first and self.specs[i - 1].activation == "elu" and dropped_in:
+                # a stored zero is ambiguous behind an ELU: plain input gradient, then both factors of the chain rule with the
+                # keep decisions recomputed from the step's seed (cf. sl_elu_dropout_backward)
+                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
+                             None, buf.stage32.data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_NONE, self.dtype_code, 1,
+                             self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+                self._launch("split:dgrad:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
+                             None, buf.batch, buf.t_out, p.cin_pad, buf.tt_pad * p.cin_pad, HALO,
+                             buf.rows * p.cin_pad * pl, 0, st)
+                self._dropout_x3("dropout_elu_bwd:" + p.spec.name, buf.g[i - 1], buf.g[i - 1], buf.y[i - 1], p.cin_pad, 2,
+                                 buf.dropout_seed0 + i, st)
+                continue
             if i > first and self.specs[i - 1].activation == "relu" and self.x3_fused_epilogue:
                 # the ReLU mask (the hi plane of the stored activation) and the split into planes in the NT kernel's epilogue
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
@@ -1156,8 +1223,12 @@ class Engine:
                 self._launch("split:dgrad:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
                              buf.y[i - 1].data_ptr(), buf.batch, buf.t_out, p.cin_pad, buf.tt_pad * p.cin_pad, HALO,
                              buf.rows * p.cin_pad * pl, 4 if self.specs[i - 1].activation == "elu" else 3, st)
-        if ones_in:
-            self._bias_grads_from_wgrad(ones_in, True, torch.cuda.current_stream(self.device))
+            if i > first and dropped_in:
+                # the ReLU mask (stored activation > 0) already applied the keep mask: the stored activation is the
+                # post-dropout one; what is left of d dropout / dx is the factor 1 / (1 - rate)
+                self._dropout_x3("dropout_scale:" + p.spec.name, buf.g[i - 1], buf.g[i - 1], None, p.cin_pad, 1, 0, st)
+        if on_bucket_ready is None and ones_in:
+            self._bias_grads_from_wgrad(ones_in, bool(ones_db), main)
 
     def _launch_wgrad_multi_x3(self, buf, layers, st, combine):
         """bf16x3: the partial weight gradients RA (x planes [hi | lo] against g_hi) and RB (x plane hi against g_lo) of
@@ -1231,9 +1302,7 @@ class Engine:
 
     def _backward_eager(self, buf, main, side, on_bucket_ready):
         if self.planes > 1:
-            if on_bucket_ready is not None or buf.dropped:
-                raise NotImplementedError("the bf16x3 path has no data-parallel hooks / dropout (it is the parity path)")
-            return self._backward_x3(buf, main.cuda_stream)
+            return self._backward_x3(buf, main.cuda_stream, on_bucket_ready)
         first = self.frozen_layer_count
         grouped = self._grouped_wgrad_runs(first)
         dchain, dchain_skip = self._dgrad_chains(buf, first)
@@ -1377,6 +1446,7 @@ class Engine:
         self.forward(training=True)
         dp = reducer is not None and (reducer.world_size > 1 or reducer.force)
         world = reducer.world_size if reducer is not None else 1
+        self._sharded_reducer = reducer if (dp and reducer.shard_optimizer) else None
         loss = self.ctc(grad_scale=1.0 / (self.cur.batch * world))
         if not dp:
             self.backward()

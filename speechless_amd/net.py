@@ -529,7 +529,17 @@ class Wav2Letter:
         n_fft = getattr(example, "fourier_window_length", 512)
         hop = getattr(example, "hop_length", 128)
         rate = getattr(example, "sample_rate", 16000)
-        mel = None if self.input_size_per_time_step == 1 + n_fft // 2 else self.input_size_per_time_step
+        # z_normalized_transposed_spectrogram() is always the MEL spectrogram of the example's own mel_frequency_count
+        # (labeled_example.py:136-140): a net whose input size differs from it cannot be fed from this corpus
+        # (speechless_amd.spectrogram.LabeledExample(mel_frequency_count=None) asks for the linear 1 + n_fft / 2 bins)
+        if hasattr(example, "mel_frequency_count"):
+            mel = example.mel_frequency_count
+            bins = mel if mel is not None else 1 + n_fft // 2
+            if bins != self.input_size_per_time_step:
+                raise ValueError("the examples yield {} {} bins per frame, the net expects {} inputs per time step".format(
+                    bins, "mel" if mel is not None else "linear", self.input_size_per_time_step))
+        else:  # not a LabeledExample: the net's input size decides
+            mel = None if self.input_size_per_time_step == 1 + n_fft // 2 else self.input_size_per_time_step
         return shared_extractor(rate, n_fft, hop, mel, self.device)
 
     def train_on_staged_batch(self, staged, stager, reducer=None):
@@ -551,9 +561,10 @@ class Wav2Letter:
         save_optimizer_state: also write weights-epoch{N}.opt.npz (Adam moments + step count) with every checkpoint,
         for Wav2Letter(..., load_optimizer_state=True) to resume exactly where the run stopped.
         from_audio: the batches hold reference-style LabeledExample objects (labeled_example.py:74-140) and the spectrograms
-        are computed on the GPU from their raw audio (`get_raw_audio()`), on the copy stream under the previous step
-        (pipeline.AudioBatchStager) -- labeled_example.py:136-140 feeding net.py:593 without the spectrogram ever
-        existing on the host.  Needs prefetch_depth > 0."""
+        are computed on the GPU from their raw audio (`get_raw_audio()`): the samples arrive on the copy stream under the
+        previous step, the front end runs on the compute stream in front of the step that consumes it
+        (pipeline.AudioBatchStager, front_end_on_copy_stream=False) -- labeled_example.py:136-140 feeding net.py:593
+        without the spectrogram ever existing on the host.  Needs prefetch_depth > 0."""
         def print_preview_batch():
             log(self.test_and_predict_batch(preview_labeled_spectrogram_batch))
 

@@ -919,8 +919,9 @@ def test_every_wgrad_tile_configuration_against_float64(hip_lib, taps, t_out, ba
             assert (outs[0][:, taps * cin * cout:] == 3.0).all(), "wrote past a group's weight block"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("shard_optimizer", [False, True])
-def test_data_parallel_step_through_rccl_single_rank(shard_optimizer):
+def test_data_parallel_step_through_rccl_single_rank(shard_optimizer, dtype):
     """The data-parallel step (bucketed exchange on the communication stream, overlapped with backward; with
     shard_optimizer: reduce-scatter, Adam on the rank's slice, all-gather of the masters, operand rewrite) on ONE rank
     through the real RCCL backend: a sum over a world of one is the identity, so weights and losses must equal the plain
@@ -938,7 +939,7 @@ def test_data_parallel_step_through_rccl_single_rank(shard_optimizer):
         dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         for use_reducer in (False, True):
-            eng = make_engine(case, "bf16")
+            eng = make_engine(case, dtype)
             reducer = None
             if use_reducer:
                 reducer = GradBucketReducer(eng.grads, eng.bucket_ranges(), force=True, shard_optimizer=shard_optimizer)

@@ -258,3 +258,28 @@ def test_bf16_storage_noise_is_in_the_activations_not_in_g():
     assert np.all(np.abs(err[True] - err["fp32_g"]) < 0.1 * err[True] + 1e-4), (err[True], err["fp32_g"])
     assert err[True][-1] < 5e-3 and err[True][0] > 5e-2
     assert np.all(err[True][:-1] > err[True][1:] * 0.8)  # grows from the output layer downwards
+
+
+def test_float64_torch_realisation_against_the_numpy_oracle():
+    """oracle/w2l_float64.py (per-tap matmul + F.ctc_loss in float64: the exact corner of bench.py's parity triangle)
+    against the numpy restatement on a shrunken stack with ragged lengths and repeated labels: losses, every gradient and
+    the ReLU decisions agree to float64 rounding."""
+    from oracle import w2l_float64 as f64
+    specs = o.layer_specs(12, 6, main_filter_count=10, out_filter_count=16, inner_count=2, striding_kernel=6,
+                          inner_kernel=3, big_kernel=4)
+    weights = o.glorot_uniform_weights(specs, 1, dtype=np.float64)
+    rng = np.random.RandomState(0)
+    weights = [(w, rng.uniform(-0.1, 0.1, size=b.shape)) for w, b in weights]
+    x = rng.randn(3, 21, 12)
+    labels = o.pack_label_batch([[0, 1, 1], [2], [3, 4, 0, 0]])
+    pred_len, lab_len = [11, 9, 11], [3, 1, 4]
+    a = o.loss_and_gradients(specs, weights, x, labels, pred_len, lab_len)
+    b = f64.loss_and_gradients(specs, weights, x, labels, pred_len, lab_len)
+    np.testing.assert_allclose(b["losses"], a["losses"], rtol=1e-12)
+    np.testing.assert_allclose(b["probs"], a["probs"], atol=1e-14)
+    for (aw, ab), (bw, bb) in zip(a["grads"], b["grads"]):
+        np.testing.assert_allclose(bw, aw, atol=1e-13 * np.abs(aw).max())
+        np.testing.assert_allclose(bb, ab, atol=1e-13 * max(np.abs(ab).max(), 1e-300))
+    _, _, zs = o.forward_stack(specs, weights, x, keep=True)
+    for z, m in zip(zs[:-1], b["masks"]):
+        assert np.array_equal(z > 0, m.numpy())

@@ -152,14 +152,14 @@ def _engine_case():
     return specs, weights, x, labels, lab_len, pred_len
 
 
-def _engine_worker(rank, world, port, out_dir, shard=False):
+def _engine_worker(rank, world, port, out_dir, shard=False, dtype="f32"):
     from speechless_amd.engine import Engine
     from speechless_amd.parallel import GradBucketReducer, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share cuda:0: gloo moves the bytes
     specs, weights, x, labels, lab_len, pred_len = _engine_case()
-    eng = Engine(specs, 29, dtype="f32", device="cuda:0", lr=1e-3)
+    eng = Engine(specs, 29, dtype=dtype, device="cuda:0", lr=1e-3)
     eng.set_weights(weights)
     ranges = eng.bucket_ranges()
     assert len(ranges) == 4 and sum(hi - lo for lo, hi in ranges) == eng.param_numel  # (fp32 path: 4 buckets) cover every parameter
@@ -169,20 +169,28 @@ def _engine_worker(rank, world, port, out_dir, shard=False):
         eng.train_step(x[lo:hi], labels[lo:hi], lab_len[lo:hi], pred_len[lo:hi], reducer)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), *[w for w, _ in eng.get_weights()])
+    # the optimizer state as Wav2Letter.save_optimizer_state would write it: with the sharded optimizer a collective that
+    # gathers every rank's slices of the moments
+    state = eng.get_optimizer_state()
+    np.savez(os.path.join(out_dir, "opt{}.npz".format(rank)), *([m for m, _ in state["m"]] + [v for v, _ in state["v"]]))
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
 @pytest.mark.parametrize("shard", [False, True])
-def test_two_engine_ranks_equal_one_rank_on_the_global_batch(tmp_path, shard):
+def test_two_engine_ranks_equal_one_rank_on_the_global_batch(tmp_path, shard, dtype):
     """Two processes, each running the real HIP engine on its utterance shard with the bucketed, overlapped gradient
     all-reduce (gloo transport, both on the one GPU of the test box), must end up with the weights of a single process
-    that trained on the global batch: same gradient scale (1 / (B_local * world)), same bucket ranges, same Adam."""
+    that trained on the global batch: same gradient scale (1 / (B_local * world)), same bucket ranges, same Adam -- on
+    the exact-fp32 path and (round 4) on the bf16x3 path, the fast path that meets the gradient bar.  With the sharded
+    optimizer the optimizer state each rank would save (get_optimizer_state: a collective then) is the full state, equal
+    on both ranks and to the single process's."""
     from speechless_amd.engine import Engine
     world = 2
-    mp.spawn(_engine_worker, args=(world, _free_port(), str(tmp_path), shard), nprocs=world, join=True)
+    mp.spawn(_engine_worker, args=(world, _free_port(), str(tmp_path), shard, dtype), nprocs=world, join=True)
     specs, weights, x, labels, lab_len, pred_len = _engine_case()
-    eng = Engine(specs, 29, dtype="f32", device="cuda:0", lr=1e-3)
+    eng = Engine(specs, 29, dtype=dtype, device="cuda:0", lr=1e-3)
     eng.set_weights(weights)
     for _ in range(2):
         eng.train_step(x, labels, lab_len, pred_len)
@@ -203,6 +211,13 @@ def test_two_engine_ranks_equal_one_rank_on_the_global_batch(tmp_path, shard):
             assert diff.max() <= 2e-2 * step_size and np.mean(diff > 1e-3 * step_size) < 1e-3, (rank, i, diff.max())
             moved = max(moved, float(np.abs(r - weights[i][0]).max()))
     assert moved > 1e-4  # the steps did change the weights
+    state = eng.get_optimizer_state()
+    want = [m for m, _ in state["m"]] + [v for v, _ in state["v"]]
+    opts = [np.load(str(tmp_path / "opt{}.npz".format(rank))) for rank in range(world)]
+    for i, w in enumerate(want):
+        a, b = opts[0]["arr_{}".format(i)], opts[1]["arr_{}".format(i)]
+        assert np.array_equal(a, b), i                                # every rank holds (and would save) the same state
+        assert np.linalg.norm(a.astype(np.float64) - w) <= 1e-4 * np.linalg.norm(w) + 1e-30, i   # ... the FULL state
 
 
 @pytest.mark.gpu
