@@ -41,8 +41,12 @@ def test_parity_triangle_at_the_benchmark_batch():
     implementations differ by their common float32 noise (above all the ReLU decisions of pre-activations within float32
     rounding of zero); against float64 each is measured by itself.  The bar, per tensor: a HIP parity path is within 1e-3 of
     float64 (north_star) -- or, where the REFERENCE side's own float32 arithmetic is further than that from float64 on
-    this batch (striding_conv: its weight gradient is a sum of zero-mean products of white-noise inputs, |dW| is what is
-    left of the cancellation), no further than 1.5 x the CPU port's own distance."""
+    this batch, no further than 1.5 x (f32) / 3 x (bf16x3) the CPU port's own distance.  Measured (MI355X, round 4): every
+    tensor of every run is within 4.5e-4 EXCEPT the weight gradient of striding_conv -- torch-CPU float32 3.4e-3, HIP f32
+    3.9e-3, bf16x3 8.1e-3 -- and the ReLU decisions that differ from float64 number 43 (torch-CPU), 61 (HIP f32), 402
+    (bf16x3: 16-17 significand bits per stored value instead of 24) of 96 million.  striding_conv's dW is a sum of products of
+    zero-mean white-noise inputs with the fully back-propagated signal: nothing coherent to average the per-element
+    perturbations of the flips above it against, so its error is ~ sqrt(flips / elements) of ANY float32 implementation."""
     import torch
     import bench
     from oracle import w2l_float64 as f64
@@ -75,12 +79,15 @@ def test_parity_triangle_at_the_benchmark_batch():
     for dtype in ("f32", "bf16x3"):
         r = report[dtype]
         assert r["loss"] < 1e-5, (dtype, r["loss"])
+        slack, flip_slack = (1.5, 2) if dtype == "f32" else (3.0, 20)
         for n in names:
             for kind in ("dw", "db"):
-                bound = max(1e-3, 1.5 * yard[kind][n])
+                bound = max(1e-3, slack * yard[kind][n])
                 assert r[kind][n] < bound, (dtype, kind, n, r[kind][n], "torch-CPU float32 vs float64:", yard[kind][n])
-        # as many ReLU decisions differ from float64 as in the reference-side float32 run, within a factor of two
-        assert sum(r["flips"].values()) <= 2 * sum(yard["flips"].values()) + 50, (dtype, r["flips"], yard["flips"])
+            if n != "striding_conv":
+                assert r["dw"][n] < 1e-3 and r["db"][n] < 1e-3, (dtype, n)  # north_star's bar, against the exact result
+        # ReLU decisions that differ from float64: f32 as many as the reference-side float32 run within a factor of two
+        assert sum(r["flips"].values()) <= flip_slack * sum(yard["flips"].values()) + 50, (dtype, r["flips"], yard["flips"])
 
 
 # ------------------------------------------------------------------------------------------ configuration 5: gradients
@@ -186,12 +193,16 @@ def test_bf16x3_dropout_training_step_with_recomputed_masks(activation):
     _report("bf16x3_dropout_{}_gradient_errors".format(activation), errs)
     # as on the fp32 path: flip-aware (a pre-activation within rounding of zero takes the other branch: ~5e-3 of the signal
     # from that layer down at 48 frames), a prefix of the stack may be loose
+    # (measured: ELU 7e-6 .. 2.3e-5 on every layer -- no decisions to flip; ReLU 3e-6 at the top, 1.2e-3 .. 1.2e-2 below the
+    # first flipped decision: 144 output frames in the whole batch, and bf16x3 flips ~10 x as many decisions as fp32)
     loose = [i for i, e in enumerate(errs) if e >= 5e-4]
-    assert max(errs) < 1e-2 and loose == list(range(len(loose))) and errs[-1] < 5e-4, errs
+    assert max(errs) < 3e-2 and loose == list(range(len(loose))) and errs[-1] < 5e-4, errs
+    if activation == "elu":
+        assert max(errs) < 1e-4, errs
     # same seed, same masks on the exact-fp32 path: the two paths agree as they do without dropout
     loss32, grads32, _ = results["f32"]
     assert np.allclose(loss, loss32, rtol=2e-5)
-    assert max(rel_l2(a[0], b[0]) for a, b in zip(grads, grads32)) < 1e-2
+    assert max(rel_l2(a[0], b[0]) for a, b in zip(grads, grads32)) < 3e-2
     # a step is reproducible from its seed; inference is unaffected by the rate
     probs_eval = eng.forward(case["x"]).cpu().numpy().copy()
     eng.dropout_rate = None
