@@ -325,7 +325,7 @@ class Bench:
         return {tag: float(np.sum(v)) / n_steps for tag, v in per_tag.items()}
 
     def kernel_pass(self, tags):
-        """ms per launch of the MAIN kernel behind each tag: events recorded by the library immediately around that
+        """ms per step of the MAIN kernel(s) behind each tag: events recorded by the library immediately around that
         kernel on its stream (sl_profile_next_kernel), nothing else instrumented"""
         eng = self.eng
         eng.kernel_timeline = (set(tags), [])
@@ -337,7 +337,8 @@ class Bench:
         for tag, start, stop in eng.kernel_timeline[1]:
             per_tag.setdefault(tag, []).append(start.elapsed_time(stop))
         eng.kernel_timeline = None
-        return {tag: float(np.mean(v)) for tag, v in per_tag.items()}
+        # per STEP: the top layers' forward / input-gradient launches come in two half-batch launches per step (Engine.split_top)
+        return {tag: float(np.sum(v)) / n_steps for tag, v in per_tag.items()}
 
     def other_forward_leg(self, dtype):
         """config 2: another storage scheme timed beside the fp32 path, its disagreements with it counted.  bf16 = the

@@ -172,6 +172,13 @@ size_t sl_conv1d_backward_1x1_workspace_bytes(const sl_conv_geom* geom, int k_re
 int sl_conv1d_backward_1x1(const void* x, const void* g, const void* w_dgrad, void* dx, float* dw, const sl_conv_geom* geom,
                            int epilogue, int k_real, int dtype, int cfg, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* The same for ONE PART of the batch (x, g, dx point at the part's first utterance, geom->batch = its utterances):
+ * accumulate = 0 writes dw (the first part), accumulate = 1 adds this part's sum to what dw holds (later parts; same stream,
+ * fixed order: deterministic).  The engine runs the top of the step by half-batches so that the CTC lattice of one half
+ * (net.py:402-406, a handful of latency-bound waves) runs under the top layers of the other half (Engine.split_top). */
+int sl_conv1d_backward_1x1_part(const void* x, const void* g, const void* w_dgrad, void* dx, float* dw,
+                                const sl_conv_geom* geom, int epilogue, int k_real, int dtype, int cfg, int accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the weight gradients of SEVERAL layers in one balanced launch (bf16) ------------------------------------------------
  * Replaces a sequence of sl_conv1d_wgrad / sl_conv1d_wgrad_grouped calls (TF Conv2DBackpropFilter of several Conv1D layers,

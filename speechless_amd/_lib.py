@@ -113,6 +113,8 @@ SIGNATURES = {
     "sl_conv1d_backward_1x1_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int, c_int]),
     "sl_conv1d_backward_1x1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int,
                                        c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "sl_conv1d_backward_1x1_part": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int,
+                                            c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "sl_split3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
     "sl_split3_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "sl_split3_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -183,6 +183,13 @@ extern "C" size_t sl_conv1d_backward_1x1_workspace_bytes(const sl_conv_geom* geo
 extern "C" int sl_conv1d_backward_1x1(const void* x, const void* g, const void* w_dgrad, void* dx, float* dw,
                                       const sl_conv_geom* geom, int epilogue, int k_real, int dtype, int cfg,
                                       void* workspace, size_t workspace_bytes, void* stream) {
+    return sl_conv1d_backward_1x1_part(x, g, w_dgrad, dx, dw, geom, epilogue, k_real, dtype, cfg, 0, workspace, workspace_bytes,
+                                       stream);
+}
+
+extern "C" int sl_conv1d_backward_1x1_part(const void* x, const void* g, const void* w_dgrad, void* dx, float* dw,
+                                           const sl_conv_geom* geom, int epilogue, int k_real, int dtype, int cfg,
+                                           int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     SL_CHECK_ARG(x && g && w_dgrad && dx && dw && geom, "sl_conv1d_backward_1x1: null pointer");
     SL_CHECK_ARG(epilogue == SL_EPI_RELU_MASK || epilogue == SL_EPI_ELU_MASK,
                  "sl_conv1d_backward_1x1: epilogue must be SL_EPI_RELU_MASK or SL_EPI_ELU_MASK");
@@ -194,7 +201,8 @@ extern "C" int sl_conv1d_backward_1x1(const void* x, const void* g, const void* 
     SL_CHECK_ARG(geom->x_row0 >= 0 && geom->y_row0 >= 0 && geom->x_row_stride >= geom->cin && geom->y_row_stride >= 32,
                  "sl_conv1d_backward_1x1: bad geometry");
     SL_CHECK_ARG(cfg >= 0, "sl_conv1d_backward_1x1: cfg must be >= 0");
-    return conv1x1_bwd_bf16(x, g, w_dgrad, dx, dw, geom, epilogue, cfg, workspace, workspace_bytes, (hipStream_t)stream);
+    return conv1x1_bwd_bf16(x, g, w_dgrad, dx, dw, geom, epilogue, cfg, accumulate ? 1 : 0, workspace, workspace_bytes,
+                            (hipStream_t)stream);
 }
 
 extern "C" size_t sl_conv1d_wgrad_grouped_workspace_bytes(const sl_conv_geom* geom, int groups, int cfg) {

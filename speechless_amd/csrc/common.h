@@ -73,6 +73,16 @@ __device__ __forceinline__ unsigned int dropout_bits(unsigned long long seed, un
     return (unsigned int)(z >> 32);
 }
 
+// Wave priority of the MFMA kernels that may share the chip with a latency-bound side-stream kernel (the CTC lattice of the
+// other half-batch, Engine.split_top): a hand-scheduled work-group is as slow as its slowest wave, and a default-priority
+// lattice wave on the same SIMD otherwise takes issue slots from it (big_conv_2 forward of a half batch: 94 instead of 59 us
+// next to the lattice waves, rocprofv3 kernel trace).  -DSL_NO_MFMA_PRIORITY: leave the priority alone (A/B builds).
+#if defined(SL_NO_MFMA_PRIORITY)
+#define SL_MFMA_KERNEL_PRIORITY() ((void)0)
+#else
+#define SL_MFMA_KERNEL_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#endif
+
 // XCD-aware work-group remap: the dispatcher places block b on XCD b % 8 (speed only, never correctness).
 // Gives each XCD a contiguous range of logical ids so that neighbouring tiles share the XCD's private L2.
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
@@ -102,6 +112,6 @@ int wgrad_f32_tile(const sl_conv_geom* g, int cfg);
 bool conv1x1_bwd_bf16_supported(const sl_conv_geom* g, int k_real);
 size_t conv1x1_bwd_bf16_workspace_bytes(const sl_conv_geom* g, int cfg);
 int conv1x1_bwd_bf16(const void* x, const void* gr, const void* w_dgrad, void* dx, float* dw, const sl_conv_geom* g,
-                     int epilogue, int cfg, void* ws, size_t ws_bytes, hipStream_t s);
+                     int epilogue, int cfg, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t wgrad_multi_bf16_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs);
 int wgrad_multi_bf16(const sl_wgrad_job* jobs, int n_jobs, void* ws, size_t ws_bytes, hipStream_t s);

@@ -92,6 +92,7 @@ __device__ __forceinline__ float through_act(float d, float y) {
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(BwdArgs a) {
+    SL_MFMA_KERNEL_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(BwdArgs a) {
 // work-group combines for free (measured: release fence + ticket + one combining work-group per channel block 29 us, more
 // than the main kernel's 25), so the combine happens at the launch boundary (cdna_hip_programming.md, in-launch split-K).
 __global__ __launch_bounds__(256) void conv1x1_bwd_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                                 int cin, int cout_pad, int splits) {
+                                                                 int cin, int cout_pad, int splits, int accumulate) {
     const int e = blockIdx.x * 256 + threadIdx.x;  // float4 index: ci = e / 8, co = (e % 8) * 4
     if (e >= cin * (KC / 4)) return;
     const int ci = e >> 3, co = (e & 7) * 4;
@@ -294,6 +295,10 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_reduce_kernel(const float* __
         }
     }
     float* out = dw + (long)ci * cout_pad;
+    if (accumulate) {  // a later part of the batch (sl_conv1d_backward_1x1_part): dw = dw_of_the_parts_before + this part's sum
+        *(f32x4*)(out + co) = *(const f32x4*)(out + co) + s;
+        return;
+    }
     *(f32x4*)(out + co) = s;
     for (int z = KC + co; z < cout_pad; z += KC) *(f32x4*)(out + z) = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
@@ -327,7 +332,7 @@ size_t conv1x1_bwd_bf16_workspace_bytes(const sl_conv_geom* g, int cfg) {
 }
 
 int conv1x1_bwd_bf16(const void* x, const void* gr, const void* w_dgrad, void* dx, float* dw, const sl_conv_geom* g,
-                     int epilogue, int cfg, void* ws, size_t ws_bytes, hipStream_t s) {
+                     int epilogue, int cfg, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
     BwdArgs a;
     a.x = (const __bf16*)x;
     a.g = (const __bf16*)gr;
@@ -365,6 +370,6 @@ int conv1x1_bwd_bf16(const void* x, const void* gr, const void* w_dgrad, void* d
     if (rc != SL_OK) return rc;
     const int n4 = g->cin * (KC / 4);
     hipLaunchKernelGGL(conv1x1_bwd_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, a.slabs, dw, g->cin, g->cout,
-                       a.splits);
+                       a.splits, accumulate);
     return sl_check_launch("sl_conv1d_backward_1x1(reduce)");
 }

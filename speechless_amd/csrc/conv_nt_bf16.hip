@@ -273,6 +273,7 @@ struct IlvPhase<IT, G, NQ, NQ, RPG> {
 // read from LDS while the MFMAs of the current tile's second half run, see the loop)
 template <bool M32, int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_bf16_kernel(NtArgs a) {
+    SL_MFMA_KERNEL_PRIORITY();
     constexpr int STAGES = STAGES_P & 7;
     constexpr bool PIPE = (STAGES_P & 8) != 0;
     constexpr bool ILV = (STAGES_P & 16) != 0;  // hand-interleaved variant of the pipelined loop
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
 //   the instructions that may stay in flight.
 template <int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32, bool ILV>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_slab_bf16_kernel(NtArgs a) {
+    SL_MFMA_KERNEL_PRIORITY();
     constexpr int STAGES = STAGES_P & 7;
     constexpr bool PIPE = (STAGES_P & 8) != 0;
     static_assert(!ILV || PIPE, "the interleaved schedule is a variant of the register-pipelined loop");
@@ -1060,6 +1062,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
 // wave has finished reading before the barrier) interleaved.  Tap-major contraction, branch-free request stream.
 template <int STAGES, int MODE, bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void conv_nt_ks2_bf16_kernel(NtArgs a) {
+    SL_MFMA_KERNEL_PRIORITY();
     constexpr int IT = 4, WN = 2, NW = 8;
     constexpr int WROWS = 64, BM = 128, BN = 128;
     constexpr int X_BYTES = BM * 128;

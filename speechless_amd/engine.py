@@ -160,6 +160,10 @@ class _Buffers:
         self.stage32 = torch.empty((batch * self.tt_pad * max(p.cout_pad for p in eng.plans),), dtype=torch.float32,
                                    device=dev) if pl > 1 else None
         self.plane_geoms = {}  # bf16x3: (kind, layer) -> geometry whose output side describes a plane tensor
+        self.half_geoms = {}   # split top (Engine.split_top): (kind, layer) -> the layer's geometry for half the batch
+        self.ctc_done = [None, None]  # split top: events behind the CTC launches of the two half-batches
+        self.ctc_half_bytes = 0
+        self.split_pending = False    # the last forward ran the CTC by half-batches; backward() consumes it
         self.wgrad_r = None  # bf16x3: the two partial weight gradients (RA | RB) in front of sl_split3_wgrad_combine
         self.wgrad_geom_b = [None] * n
         self.wgrad_geom = [None] * n
@@ -206,6 +210,8 @@ class _Buffers:
             for job in (table[0] if isinstance(table, tuple) else table):  # (bf16x3: (table, partial buffers, ...))
                 job.geom.t_out = t_out
         for g in self.plane_geoms.values():
+            g.t_out = t_out
+        for g in self.half_geoms.values():
             g.t_out = t_out
         if t_out not in self._ws_sized_fwd:  # split counts (hence workspace sizes) depend on the number of time tiles
             self._ws_sized_fwd.add(t_out)
@@ -331,6 +337,10 @@ class _Buffers:
         """CTC workspace for label rows of up to l_max graphemes: sized in BYTES and never shrunk (the library's need
         is monotonic in l_max since round 3, but a buffer set that has served long labels keeps its allocation)."""
         need = lib().raw("sl_ctc_workspace_bytes")(self.batch, self.tt_pad, l_max)  # covers every length
+        if eng.split_top and self.batch % 2 == 0:  # two half-batches at a time, each with its own half of the workspace
+            half = _round_up(lib().raw("sl_ctc_workspace_bytes")(self.batch // 2, self.tt_pad, l_max), 256)
+            self.ctc_half_bytes = max(self.ctc_half_bytes, half)
+            need = max(need, 2 * self.ctc_half_bytes)
         if self.ctc_ws is None or self.ctc_ws.numel() < need:
             self.ctc_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=eng.device)
             self.launch_lists = {}
@@ -455,6 +465,16 @@ class Engine:
         if self.planes > 1:  # the fused launches read and write single-plane bf16 tensors
             self.use_chain = self.fuse_output_softmax = self.fuse_output_backward = self.group_wgrad = False
             self._x3_bias_ws = None
+        # Split top: the CTC lattice is a handful of latency-bound waves (one per utterance and direction, T' sequential
+        # frames: 0.106 ms at config 3, 0.39 ms at config 5) with the rest of the chip idle, and it sits between forward and
+        # backward.  The training step therefore runs its TOP by half-batches: big_conv_1 / big_conv_2 / output_conv forward of
+        # half A, then A's CTC on a side stream UNDER the same layers of half B; B's CTC under the input gradients of A's top
+        # layers.  Per-utterance results do not depend on the half an utterance is in; weight gradients stay whole-batch
+        # launches (sl_conv1d_backward_1x1_part accumulates the output layer's).  Used where it pays (_split_top_pays: long
+        # utterances in small batches, i.e. configuration 5); SL_SPLIT_TOP=0: the whole-batch sequence everywhere.
+        self.split_top = os.environ.get("SL_SPLIT_TOP", "1") != "0"
+        self.split_min_tiles = None
+        self._ctc_streams = None
         self._rec = None
         self._adam_tables = {}
         self._sharded_reducer = None  # the reducer of the last step, if that step ran Adam on this rank's slices only
@@ -507,8 +527,21 @@ class Engine:
             elif kind == 1:
                 op[1].record(op[2])
                 op[3].wait_event(op[1])
-            else:
+            elif kind == 2:
                 callback(op[1])
+            else:  # a step of the sequence that has to be marshalled afresh every time (pointers / sizes that change per batch)
+                op[1](*op[2])
+
+    def _eager_op(self, fn, *args):
+        """fn(*args) now; while a launch list is being recorded it becomes ONE op of the list that calls fn again at
+        replay (the launches inside are not recorded: their arguments change from batch to batch)"""
+        rec, self._rec = self._rec, None
+        try:
+            fn(*args)
+        finally:
+            self._rec = rec
+        if rec is not None:
+            rec.append((3, fn, args))
 
     def _launch_list(self, buf, key):
         """The recorded launch list of `key` for this buffer set, or None (then the caller runs eagerly; with
@@ -755,11 +788,14 @@ class Engine:
         """Indices of the layers with a Dropout in front of them (all but the last three, net.py:326-330)."""
         return range(0, max(len(self.plans) - 3, 0))
 
-    def forward(self, input_batch=None, training=False):
+    def forward(self, input_batch=None, training=False, split_ctc=None):
         """Runs the 11 conv layers + softmax.  Returns the probability tensor (B,T',K) fp32 in HBM.
         training=True applies dropout (if self.dropout_rate) to the inputs of the first n-3 layers: the packed input
         goes through sl_dropout into a second buffer, every other activation is dropped in place right after the
-        layer that produced it (so the stored activation is the post-dropout one the backward pass needs)."""
+        layer that produced it (so the stored activation is the post-dropout one the backward pass needs).
+        split_ctc=grad_scale (train_step_resident, when split_top_ok()): the top three layers run by half-batches and each
+        half's CTC loss + gradient (ctc(grad_scale)) is launched on a side stream as soon as its probabilities exist;
+        backward() picks the halves up (see self.split_top)."""
         buf = self.load_input(input_batch) if input_batch is not None else self.cur
         if self._packed_dirty:
             self.repack_weights()
@@ -767,27 +803,180 @@ class Engine:
         n = len(self.plans)
         rate = self.dropout_rate if training else None
         buf.dropped = bool(rate)
+        buf.split_pending = False
         fuse_out = self.fuse_output_softmax and self.dtype == "bf16" and bool(self.lib.raw("sl_output_softmax_supported")(
             ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size, self.dtype_code))
         # launch list (no dropout): everything below takes its frame count from the geometries, except the unfused
         # softmax, which gets it by value -> then the list is per length
         key = None if rate else ("fwd", st, fuse_out, self.use_chain, tuple(sorted(self.nt_cfg.items())),
-                                 None if fuse_out else buf.t_out)
+                                 None if fuse_out else buf.t_out, split_ctc)
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
             self._replay(ops)
+            buf.split_pending = split_ctc is not None
             return buf.probs
         record = key is not None and self.use_launch_lists and self.timeline is None and \
             self.kernel_timeline is None and self._rec is None
         if not record:
-            return self._forward_eager(buf, rate, fuse_out, st)
+            return self._forward_eager(buf, rate, fuse_out, st, split_ctc)
         self._rec = []
         try:
-            probs = self._forward_eager(buf, rate, fuse_out, st)
+            probs = self._forward_eager(buf, rate, fuse_out, st, split_ctc)
             buf.launch_lists[key] = self._rec
             return probs
         finally:
             self._rec = None
+
+    # ------------------------------------------------------------------ split top (see self.split_top)
+    def split_top_ok(self, buf):
+        """whether the training step on `buf` can run its top three layers and the CTC by half-batches"""
+        state = (self.split_top, bool(self.dropout_rate), self.frozen_layer_count, self.fuse_output_softmax,
+                 self.fuse_output_backward, tuple(sorted(self.nt_cfg)), buf.bwd_ready, buf.bwd1x1_ws is not None,
+                 buf.labels is not None)
+        if getattr(buf, "_split_ok", (None, None))[0] != state:
+            buf._split_ok = (state, self._split_top_ok(buf))
+        return buf._split_ok[1] and self._split_top_pays(buf)
+
+    def _split_top_pays(self, buf):
+        """Measured rule (MI355X, tools/split_by_bucket.py, rocprofv3 kernel traces under profiles/r04_trace_*): the top
+        layers run 256 x 256 tiles, ONE work-group per CU, and a CTC lattice wave cannot share a CU with such a work-group
+        (its registers fill the SIMDs) -- so while a half's lattice runs, 3 waves per utterance hold CUs of their own and a
+        launch of exactly 256 tiles needs a second round.  The split pays where the two half-batch launches of the widest
+        layer, next to those waves, take no more rounds of 256 work-groups than the whole-batch launch does: config 5's
+        buckets of 384 / 896 / 960 tiles (-0.09 / -0.22 / -0.09 ms), not 512 ... 768 (+0.05 ... +0.11 ms) and not config 3
+        (512 tiles: +0.10 ms)."""
+        if self.split_min_tiles is not None:  # measurement hook: a plain threshold instead of the rule (0 = always)
+            return True if self.split_min_tiles == 0 else self._top_tiles(buf) >= self.split_min_tiles
+        cus = 256
+        n = self._top_tiles(buf)
+        half = n // 2 + 3 * (buf.batch // 2)
+        return 2 * (-(-half // cus)) <= -(-n // cus)
+
+    def _top_tiles(self, buf):
+        widest = max(self.plans[i].cout_pad for i in range(len(self.plans) - 3, len(self.plans) - 1))
+        return buf.batch * (-(-buf.t_out // 256)) * (-(-widest // 256))
+
+    def _split_top_ok(self, buf):
+        n = len(self.plans)
+        if not self.split_top or self.dtype != "bf16" or self.dropout_rate or n < 4 or buf.batch < 2 or buf.batch % 2:
+            return False
+        if self.frozen_layer_count >= n - 3 or not self.fuse_output_softmax or not self.fuse_output_backward:
+            return False
+        top = (n - 3, n - 2, n - 1)
+        if any(s0 <= i <= e0 for (s0, e0) in self.runs for i in top) or any(self.plans[i].spec.stride != 1 for i in top):
+            return False
+        if any((kind, self.specs[i].name) in self.nt_cfg for kind in ("fwd", "dgrad", "wgrad") for i in top):
+            return False
+        if any(self.specs[i].activation not in ("relu", "elu") for i in (n - 4, n - 3, n - 2)):
+            return False
+        if not buf.bwd_ready or buf.bwd1x1_ws is None or buf.labels is None:
+            return False
+        hf, hw = self._half_geom(buf, "fwd", n - 1), self._half_geom(buf, "wgrad", n - 1)
+        return bool(self.lib.raw("sl_output_softmax_supported")(ctypes.byref(hf), self.grapheme_set_size, self.dtype_code)) \
+            and bool(self.lib.raw("sl_conv1d_backward_1x1_supported")(ctypes.byref(hw), self.grapheme_set_size,
+                                                                        self.dtype_code))
+
+    def _half_geom(self, buf, kind, i):
+        """geometry of layer i (kind 'fwd' / 'dgrad' / 'wgrad') for half the batch; follows set_length like the others"""
+        g = buf.half_geoms.get((kind, i))
+        if g is None:
+            src = {"fwd": buf.fwd_geom, "dgrad": buf.dgrad_geom, "wgrad": buf.wgrad_geom}[kind][i]
+            g = ConvGeom()
+            for name, _ in ConvGeom._fields_:
+                setattr(g, name, getattr(src, name))
+            g.batch = buf.batch // 2
+            buf.half_geoms[(kind, i)] = g
+            if kind in ("fwd", "dgrad"):  # (a half batch may pick more K splits: make sure the workspace covers it)
+                need = self.lib.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(g), self.dtype_code, 0)
+                if buf.nt_ws is None or buf.nt_ws.numel() < need:
+                    buf.nt_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+                    buf.launch_lists = {}
+        return g
+
+    @staticmethod
+    def _half_ptr(t, h):
+        """address of utterance h * B / 2 of a tensor whose first dimension is the batch"""
+        return t.data_ptr() + h * (t.shape[0] // 2) * t.stride(0) * t.element_size()
+
+    def _forward_top_split(self, buf, x, st, grad_scale):
+        """big_conv_1, big_conv_2, output_conv + softmax and the CTC, half-batch by half-batch (self.split_top)"""
+        n = len(self.plans)
+        for h in (0, 1):
+            xin = x
+            for i in (n - 3, n - 2):
+                p = self.plans[i]
+                _, bias = self.layer_param_views(self.params, p)
+                y = buf.y[i]
+                self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", self._half_ptr(xin, h), self.w_fwd[i].data_ptr(),
+                             bias.data_ptr(), None, self._half_ptr(y, h), ctypes.byref(self._half_geom(buf, "fwd", i)),
+                             _lib.EPI_BIAS_ELU if p.spec.activation == "elu" else _lib.EPI_BIAS_RELU, self.dtype_code, 0, 0,
+                             buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+                xin = y
+            self._eager_op(self._top_half_tail, buf, h, grad_scale)
+        buf.split_pending = True
+        return buf.probs
+
+    def _top_half_tail(self, buf, h, grad_scale):
+        """output layer + softmax of half h on the main stream, then its CTC loss + gradient on a side stream.  Marshalled
+        afresh every step: the dense probability tensors (offset of half 1 depends on the frame count), the label tensors
+        (the staged pipeline hands over new ones per batch) and the label width are per-batch values."""
+        n = len(self.plans)
+        last = n - 1
+        p = self.plans[last]
+        hb = buf.batch // 2
+        k = self.grapheme_set_size
+        main = torch.cuda.current_stream(self.device)
+        if self._ctc_streams is None:
+            self._ctc_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+        side = self._ctc_streams[h]
+        _, bias = self.layer_param_views(self.params, p)
+        dense = h * hb * buf.t_out * k * 4  # probs / log q: [B][T'][K] floats
+        self._launch("fwd:" + p.spec.name, "sl_output_softmax", self._half_ptr(buf.y[last - 1], h),
+                     self.w_fwd[last].data_ptr(), bias.data_ptr(), buf.probs.data_ptr() + dense, buf.logq.data_ptr() + dense,
+                     None, ctypes.byref(self._half_geom(buf, "fwd", last)), k, p.cout_pad, buf.tt_pad * p.cout_pad,
+                     self.ctc_epsilon, self.dtype_code, main.cuda_stream)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        labels = buf.labels if buf.labels.is_contiguous() else buf.labels.contiguous()
+        l_max = labels.shape[1]
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            self._launch("ctc", "sl_ctc_loss_grad", buf.probs.data_ptr() + dense, buf.logq.data_ptr() + dense,
+                         labels.data_ptr() + h * hb * l_max * 4, buf.label_len.data_ptr() + h * hb * 4,
+                         buf.input_len.data_ptr() + h * hb * 4, buf.loss.data_ptr() + h * hb * 4,
+                         self._half_ptr(buf.g[last], h), hb, buf.t_out, k, l_max, HALO, p.cout_pad, buf.rows * p.cout_pad,
+                         self.dtype_code, self.ctc_epsilon, grad_scale, buf.ctc_ws.data_ptr() + h * buf.ctc_half_bytes,
+                         buf.ctc_half_bytes, side.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(side)
+        buf.ctc_done[h] = done
+        buf._split_labels_keepalive = labels
+
+    def _wait_ctc_half(self, buf, h, main):
+        main.wait_event(buf.ctc_done[h])
+
+    def _backward_top_split(self, buf, main):
+        """the input gradients of the top three layers (and the output layer's weight gradient) by half-batches, each half
+        behind its own CTC: half B's lattice runs under half A's launches here"""
+        n = len(self.plans)
+        st = main.cuda_stream
+        last = n - 1
+        for h in (0, 1):
+            self._eager_op(self._wait_ctc_half, buf, h, main)
+            p = self.plans[last]
+            dw, _ = self.layer_param_views(self.grads, p)
+            epi = _lib.EPI_ELU_MASK if self.specs[last - 1].activation == "elu" else _lib.EPI_RELU_MASK
+            self._launch("bwd:" + p.spec.name, "sl_conv1d_backward_1x1_part", self._half_ptr(buf.y[last - 1], h),
+                         self._half_ptr(buf.g[last], h), self.w_dgrad[last].data_ptr(), self._half_ptr(buf.g[last - 1], h),
+                         dw.data_ptr(), ctypes.byref(self._half_geom(buf, "wgrad", last)), epi, self.grapheme_set_size,
+                         self.dtype_code, 0, h, buf.bwd1x1_ws.data_ptr(), buf.bwd1x1_ws.numel(), st)
+            for i in (n - 2, n - 3):
+                q = self.plans[i]
+                elu = self.specs[i - 1].activation == "elu"
+                self._launch("dgrad:" + q.spec.name, "sl_conv1d_nt", self._half_ptr(buf.g[i], h), self.w_dgrad[i].data_ptr(),
+                             None, self._half_ptr(buf.y[i - 1], h), self._half_ptr(buf.g[i - 1], h),
+                             ctypes.byref(self._half_geom(buf, "dgrad", i)), _lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK,
+                             self.dtype_code, 0, 0, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
 
     def _plane_geom(self, buf, kind, i, channels):
         """the NT geometry of layer i (kind 'fwd' / 'dgrad') with its OUTPUT side describing a bf16x3 plane tensor of
@@ -856,7 +1045,7 @@ class Engine:
                      self.ctc_epsilon, st)
         return buf.probs
 
-    def _forward_eager(self, buf, rate, fuse_out, st):
+    def _forward_eager(self, buf, rate, fuse_out, st, split_ctc=None):
         if self.planes > 1:
             return self._forward_x3(buf, st, rate)
         n = len(self.plans)
@@ -882,6 +1071,8 @@ class Engine:
             if p.index <= skip_until:
                 x = buf.y[p.index]
                 continue
+            if split_ctc is not None and p.index == n - 3:
+                return self._forward_top_split(buf, x, st, split_ctc)
             if p.index in chained:
                 layers = chained[p.index]
                 ys, ws, biases = self._chain_table("fwd", layers, buf)
@@ -1012,7 +1203,7 @@ class Engine:
             self._side_stream = torch.cuda.Stream(device=self.device)  # (ROCm offers no priority below the default)
         side = self._side_stream
         # launch list: not with dropout (its scale passes take the rate by value)
-        key = None if buf.dropped else ("bwd", main.cuda_stream, on_bucket_ready is not None, self.ones_channel,
+        key = None if buf.dropped else ("bwd", main.cuda_stream, buf.split_pending, on_bucket_ready is not None, self.ones_channel,
                                         self.frozen_layer_count, self.group_wgrad, self.use_chain, self.fuse_output_backward,
                                         self.use_wgrad_multi, self.small_bias_pass_on_main,
                                         tuple(sorted(self.nt_cfg.items())),
@@ -1346,6 +1537,10 @@ class Engine:
                 self._hand_over(side, main)
                 side_busy[0] = False
 
+        n = len(self.plans)
+        split = buf.split_pending
+        if split:  # the CTC ran by half-batches: so do the input gradients of the top three layers (see self.split_top)
+            self._backward_top_split(buf, main)
         pending, pending_bytes = [], 0  # layers whose bias-gradient pass is still owed to the side stream
         for p in reversed(self.plans[first:]):
             i = p.index
@@ -1357,7 +1552,9 @@ class Engine:
                 flush_bias_passes(pending)
                 pending_bytes = 0
             fused_bwd = self._fused_output_backward(buf, i, first, grouped, dchain, dchain_skip)
-            if fused_bwd:
+            if split and i == n - 1:
+                pass  # weight + input gradient of the output layer: done by halves above
+            elif fused_bwd:
                 self._launch_output_backward(buf, i, main.cuda_stream)
             elif i in multi:
                 if i == multi[0]:  # every gradient tensor the launch reads is complete at its lowest layer
@@ -1380,7 +1577,7 @@ class Engine:
                              "sl_conv1d_chain", buf.g[i].data_ptr(), ys, ws, None, masks,
                              ctypes.byref(buf.dgrad_geom[i]), len(layers), _lib.EPI_RELU_MASK, self.dtype_code,
                              main.cuda_stream)
-            elif i > first and i not in dchain_skip and not fused_bwd:
+            elif i > first and i not in dchain_skip and not fused_bwd and not (split and i >= n - 3):
                 self._launch_dgrad(buf, i, main.cuda_stream)
         if on_bucket_ready is None:
             if ones_in:
@@ -1443,11 +1640,16 @@ class Engine:
 
     def train_step_resident(self, reducer=None):
         """Same, with input / labels / lengths already resident in HBM (bench.py's timed region)."""
-        self.forward(training=True)
         dp = reducer is not None and (reducer.world_size > 1 or reducer.force)
         world = reducer.world_size if reducer is not None else 1
         self._sharded_reducer = reducer if (dp and reducer.shard_optimizer) else None
-        loss = self.ctc(grad_scale=1.0 / (self.cur.batch * world))
+        grad_scale = 1.0 / (self.cur.batch * world)
+        if self.split_top_ok(self.cur):
+            self.forward(training=True, split_ctc=grad_scale)  # ... and the CTC, by half-batches (self.split_top)
+            loss = self.cur.loss
+        else:
+            self.forward(training=True)
+            loss = self.ctc(grad_scale=grad_scale)
         if not dp:
             self.backward()
             self.adam_step()

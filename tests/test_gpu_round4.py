@@ -339,3 +339,112 @@ def _two_run_stack_checks(specs, weights, x, labels, lab_len, pred_len):
             torch.cuda.synchronize()
             finals.append(eng.params.clone())
         assert torch.equal(finals[-1], finals[-2]), dtype
+
+
+# ------------------------------------------------------------------------------------------ split top: CTC under the other half
+def _split_step(eng, case, split, steps=1, adam=False):
+    """`steps` training steps through train_step_resident with Engine.split_top = split; returns per-step losses"""
+    import torch
+    eng.split_top = split
+    eng.split_min_tiles = 0  # the mechanism under test, whatever the pays-off rule says about this geometry
+    losses = []
+    for _ in range(steps):
+        eng.load_input(case["x"])
+        eng.set_labels(case["labels"], np.array(case["label_lengths"]), np.array(case["prediction_lengths"]))
+        if adam:
+            losses.append(eng.train_step_resident().cpu().numpy().copy())
+        else:
+            gs = 1.0 / eng.cur.batch
+            if split:
+                assert eng.split_top_ok(eng.cur)
+                eng.forward(training=True, split_ctc=gs)
+                loss = eng.cur.loss
+            else:
+                eng.forward(training=True)
+                loss = eng.ctc(grad_scale=gs)
+            eng.backward()
+            losses.append(loss.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    return losses
+
+
+@pytest.mark.parametrize("b,t", [(8, 1000), (4, 333), (2, 64), (32, 1000)])
+def test_split_top_step_against_the_whole_batch_step(b, t):
+    """Engine.split_top (round 4): big_conv_1 / big_conv_2 / output_conv by half-batches with each half's CTC on a side
+    stream under the other half's launches -- against the whole-batch sequence: per-utterance losses and all gradients agree
+    (the half-batch launches may pick another K split than the whole-batch ones: fp32 summation order in front of a bf16
+    rounding), the step is bitwise reproducible, per-utterance results do not depend on which half an utterance is in, and
+    the layout invariants of the gradient tensors hold."""
+    import torch
+    from speechless_amd.engine import HALO
+    case = make_case(b=b, t=t, seed=22)
+    eng = make_engine(case, "bf16")
+    eng.use_launch_lists = False
+    whole = _split_step(eng, case, False)[0]
+    g_whole = eng.grads.clone()
+    split = _split_step(eng, case, True)[0]
+    g_split = eng.grads.clone()
+    again = _split_step(eng, case, True)[0]
+    assert np.array_equal(split, again) and torch.equal(g_split, eng.grads)              # deterministic
+    np.testing.assert_allclose(split, whole, rtol=2e-5)
+    err = float(torch.linalg.norm(g_split - g_whole) / torch.linalg.norm(g_whole))
+    _report("split_top_vs_whole_batch_grad_rel_l2_b{}_t{}".format(b, t), err)
+    assert err < 5e-3, err
+    buf = eng.cur
+    n = len(eng.plans)
+    for i in (n - 1, n - 2, n - 3, n - 4):
+        g = buf.g[i].float()
+        assert not g[:, :HALO].any() and not g[:, HALO + buf.t_out:].any(), i            # halo / tail rows stay zero
+    # utterances swapped across the halves: the same per-utterance losses, bit for bit
+    perm = np.random.RandomState(0).permutation(b)
+    case2 = dict(case, x=case["x"][perm], labels=case["labels"][perm],
+                 label_lengths=[case["label_lengths"][i] for i in perm],
+                 prediction_lengths=[case["prediction_lengths"][i] for i in perm])
+    swapped = _split_step(eng, case2, True)[0]
+    np.testing.assert_array_equal(split[perm], swapped)
+    assert float(torch.linalg.norm(eng.grads - g_split) / torch.linalg.norm(g_split)) < 1e-5
+
+
+def test_split_top_training_steps_through_launch_lists_equal_eager_steps():
+    """The split step with recorded launch lists (its per-batch part -- output layer + CTC of a half -- is an op that is
+    marshalled afresh at every replay) against SL_LAUNCH_LISTS=0, on batches of two lengths with label tensors that change
+    from step to step: bit-identical weights and losses.  And against the whole-batch step: the same trajectory within bf16
+    noise."""
+    import torch
+    case = make_case(b=6, t=300, seed=3)
+    short = dict(case, x=case["x"][:, :260].copy(), prediction_lengths=list(np.minimum(case["prediction_lengths"], 130)),
+                 labels=case["labels"][:, :max(case["label_lengths"])].copy())
+    finals = {}
+    for mode in ("lists", "eager", "whole"):
+        eng = make_engine(case, "bf16")
+        eng.use_launch_lists = mode != "eager"
+        eng.split_top = mode != "whole"
+        eng.split_min_tiles = 0
+        losses = []
+        for step in range(6):
+            c = case if step % 2 == 0 else short
+            losses.append(eng.train_step(c["x"], c["labels"], np.array(c["label_lengths"]),
+                                         np.array(c["prediction_lengths"])).cpu().numpy().copy())
+        torch.cuda.synchronize()
+        if mode == "lists":
+            assert any(k[0] == "fwd" and k[-1] is not None for k in eng.cur.launch_lists), list(eng.cur.launch_lists)
+        finals[mode] = (np.stack(losses), eng.params.clone())
+    assert np.array_equal(finals["lists"][0], finals["eager"][0])
+    assert torch.equal(finals["lists"][1], finals["eager"][1])
+    np.testing.assert_allclose(finals["lists"][0], finals["whole"][0], rtol=5e-3)
+    assert np.isfinite(finals["lists"][0]).all() and (finals["lists"][0][-2] < finals["lists"][0][0]).all()
+
+
+def test_split_top_is_chosen_where_it_was_measured_to_pay():
+    """the pays-off rule of Engine.split_top on the geometries it was measured on (tools/split_by_bucket.py): config 3 and
+    config 5's buckets of 512 .. 768 top-layer tiles keep the whole-batch step, 384 / 896 / 960 tiles split"""
+    from speechless_amd.engine import Engine, wav2letter_layer_specs
+    eng = Engine(wav2letter_layer_specs(257, 29), 29, dtype="bf16")
+
+    class Buf:
+        pass
+    for batch, t_out, want in ((32, 500, False), (8, 1484, True), (8, 1853, False), (8, 2354, False), (8, 2842, False),
+                               (8, 3369, True), (8, 3763, True), (8, 3997, False)):
+        buf = Buf()
+        buf.batch, buf.t_out = batch, t_out
+        assert eng._split_top_pays(buf) is want, (batch, t_out)

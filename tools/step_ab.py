@@ -19,8 +19,13 @@ def main():
     ap.add_argument("--attr", required=True)
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 5),
+                    help="3: the resident 32 x 1000-frame step; 5: bench.py's long-form bucketed batches (8 x 2000..8000 x 257)")
+    ap.add_argument("--force-split", action="store_true", help="split_top on every geometry (not only where the rule says)")
     args = ap.parse_args()
     import torch
+    if args.config == 5:
+        return config5(args)
     from speechless_amd.engine import Engine, wav2letter_layer_specs
     from speechless_amd.net import Wav2Letter
     specs = wav2letter_layer_specs(128, 29)
@@ -36,6 +41,8 @@ def main():
     eng.load_input(x)
     eng.set_labels(labels, lab_len, np.full(b, 500))
     assert isinstance(getattr(eng, args.attr), bool), args.attr
+    if args.force_split:
+        eng.split_min_tiles = 0
 
     def timed():
         for _ in range(4):
@@ -59,6 +66,44 @@ def main():
         print("{} = {!s:5}  median {:.4f} ms  min {:.4f}  all {}".format(args.attr, value, statistics.median(v), min(v),
                                                                       [round(t, 3) for t in v]))
     print("difference of medians (True - False): {:+.4f} ms".format(statistics.median(res[True]) - statistics.median(res[False])))
+
+
+def config5(args):
+    import statistics as st
+    import torch
+    import bench
+
+    class A:
+        profile_steps = 1
+    b = bench.Bench(5, A(), 1, 0, "cuda:0")
+    eng = b.eng
+    assert isinstance(getattr(eng, args.attr), bool), args.attr
+    n = len(b.resident)
+    if args.force_split:
+        eng.split_min_tiles = 0
+
+    def timed():
+        b.cursor = 0
+        for _ in range(n):
+            b.step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2 * n):
+            b.step()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (2 * n)
+    res = {True: [], False: []}
+    for _ in range(args.reps):
+        for value in (True, False):
+            setattr(eng, args.attr, value)
+            res[value].append(timed())
+    for value in (True, False):
+        v = res[value]
+        print("config 5: {} = {!s:5}  median {:.4f} ms  min {:.4f}  all {}".format(args.attr, value, st.median(v), min(v),
+                                                                                [round(t, 3) for t in v]))
+    print("config 5: difference of medians (True - False): {:+.4f} ms".format(st.median(res[True]) - st.median(res[False])))
 
 
 if __name__ == "__main__":
