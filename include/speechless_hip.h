@@ -180,6 +180,14 @@ int sl_conv1d_backward_1x1_part(const void* x, const void* g, const void* w_dgra
                                 const sl_conv_geom* geom, int epilogue, int k_real, int dtype, int cfg, int accumulate,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* How many CUs the library's grid choosers may count on: 0 = all (default 256), else 64 .. 256.  Process-wide, read when a
+ * launch is enqueued.  The MFMA kernels take a whole CU per work-group and size their grids to whole rounds of the chip; when
+ * communication kernels own some CUs during backward (data-parallel runs: GradBucketReducer sets 256 - its channel count) the
+ * split / segment / tile-height choosers of sl_conv1d_nt, sl_conv1d_wgrad[_grouped|_multi], sl_conv1d_chain and
+ * sl_conv1d_backward_1x1 plan their rounds for that many CUs instead.  (No reference counterpart: the reference is
+ * single-device, main.py:14-24.) */
+int sl_set_available_cus(int cus);
+
 /* ---- the weight gradients of SEVERAL layers in one balanced launch (bf16) ------------------------------------------------
  * Replaces a sequence of sl_conv1d_wgrad / sl_conv1d_wgrad_grouped calls (TF Conv2DBackpropFilter of several Conv1D layers,
  * net.py:389,550) for layers with few 256 x 256 tiles -- inner_conv_1..7 and striding_conv of net.py:317-323: the

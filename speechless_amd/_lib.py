@@ -109,6 +109,7 @@ SIGNATURES = {
     "sl_bias_grad_from_wgrad": (c_int, [c_void_p, POINTER(BgwLayer), c_int, c_int, c_void_p]),
     "sl_adam_pack_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AdamLayer), c_int, c_int, c_int,
                                     c_float, c_float, c_float, c_float, c_void_p]),
+    "sl_set_available_cus": (c_int, [c_int]),
     "sl_conv1d_backward_1x1_supported": (c_int, [POINTER(ConvGeom), c_int, c_int]),
     "sl_conv1d_backward_1x1_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int, c_int, c_int]),
     "sl_conv1d_backward_1x1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ConvGeom), c_int, c_int,

@@ -171,6 +171,14 @@ extern "C" int sl_conv1d_wgrad_multi(const sl_wgrad_job* jobs, int n_jobs, int d
     return wgrad_multi_bf16(jobs, n_jobs, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+static int g_available_cus = 256;
+int sl_cus() { return g_available_cus; }
+extern "C" int sl_set_available_cus(int cus) {
+    SL_CHECK_ARG(cus == 0 || (cus >= 64 && cus <= 256), "sl_set_available_cus: 0 (all) or 64 .. 256");
+    g_available_cus = cus == 0 ? 256 : cus;
+    return SL_OK;
+}
+
 extern "C" int sl_conv1d_backward_1x1_supported(const sl_conv_geom* geom, int k_real, int dtype) {
     return geom != nullptr && dtype == SL_BF16 && conv1x1_bwd_bf16_supported(geom, k_real) ? 1 : 0;
 }

@@ -73,16 +73,6 @@ __device__ __forceinline__ unsigned int dropout_bits(unsigned long long seed, un
     return (unsigned int)(z >> 32);
 }
 
-// Wave priority of the MFMA kernels that may share the chip with a latency-bound side-stream kernel (the CTC lattice of the
-// other half-batch, Engine.split_top): a hand-scheduled work-group is as slow as its slowest wave, and a default-priority
-// lattice wave on the same SIMD otherwise takes issue slots from it (big_conv_2 forward of a half batch: 94 instead of 59 us
-// next to the lattice waves, rocprofv3 kernel trace).  -DSL_NO_MFMA_PRIORITY: leave the priority alone (A/B builds).
-#if defined(SL_NO_MFMA_PRIORITY)
-#define SL_MFMA_KERNEL_PRIORITY() ((void)0)
-#else
-#define SL_MFMA_KERNEL_PRIORITY() __builtin_amdgcn_s_setprio(3)
-#endif
-
 // XCD-aware work-group remap: the dispatcher places block b on XCD b % 8 (speed only, never correctness).
 // Gives each XCD a contiguous range of logical ids so that neighbouring tiles share the XCD's private L2.
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
@@ -92,6 +82,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
     return (bid & 7) * per + (bid >> 3);
 }
 static inline int xcd_grid(int total) { return ((total + 7) >> 3) << 3; }
+
+// How many CUs the launch choosers may count on (sl_set_available_cus, capi.hip; default: all 256).  The MFMA kernels take a
+// whole CU per work-group and their grids are sized to fill the chip in whole rounds; a concurrent kernel that OWNS CUs (the
+// communication kernels of a multi-GPU run) turns every launch of exactly 256 work-groups into two rounds.
+int sl_cus();
 
 // kernels' C++ entry points (called from capi.hip)
 int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,

@@ -92,7 +92,6 @@ __device__ __forceinline__ float through_act(float d, float y) {
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(BwdArgs a) {
-    SL_MFMA_KERNEL_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -307,7 +306,7 @@ int pick_splits(const sl_conv_geom* g, int cfg, int* chunks_per_split) {
     const int t_chunks = (g->t_out + TK - 1) / TK;
     const int total = g->batch * t_chunks;
     const int n_cb = g->cin / CBW;
-    const int target = cfg > 0 ? cfg : 256;  // work-groups: one per CU measured best (26.5 us; 512: 29.0, 768: 32.5)
+    const int target = cfg > 0 ? cfg : sl_cus();  // work-groups: one per CU measured best (26.5 us; 512: 29.0, 768: 32.5)
     int want = (target + n_cb - 1) / n_cb;
     if (want > total) want = total;
     if (want < 1) want = 1;

@@ -472,7 +472,7 @@ static int chain_tile_rows(int batch, int t_out, int taps, int n_layers) {
         long tiles = 0;
         for (int l = 0; l < n_layers; ++l) tiles += (tm + (taps - 1) * (n_layers - 1 - l) + 15) / 16;
         const long wgs = (long)batch * ((t_out + tm - 1) / tm);
-        const double cost = (double)((wgs + 255) / 256) * (double)tiles;
+        const double cost = (double)((wgs + sl_cus() - 1) / sl_cus()) * (double)tiles;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best = tm;

@@ -273,7 +273,6 @@ struct IlvPhase<IT, G, NQ, NQ, RPG> {
 // read from LDS while the MFMAs of the current tile's second half run, see the loop)
 template <bool M32, int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_bf16_kernel(NtArgs a) {
-    SL_MFMA_KERNEL_PRIORITY();
     constexpr int STAGES = STAGES_P & 7;
     constexpr bool PIPE = (STAGES_P & 8) != 0;
     constexpr bool ILV = (STAGES_P & 16) != 0;  // hand-interleaved variant of the pipelined loop
@@ -704,7 +703,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
 //   the instructions that may stay in flight.
 template <int IT, int WM, int WN, int STAGES_P, int MODE, bool OUT_F32, bool ILV>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt_slab_bf16_kernel(NtArgs a) {
-    SL_MFMA_KERNEL_PRIORITY();
     constexpr int STAGES = STAGES_P & 7;
     constexpr bool PIPE = (STAGES_P & 8) != 0;
     static_assert(!ILV || PIPE, "the interleaved schedule is a variant of the register-pipelined loop");
@@ -1062,7 +1060,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
 // wave has finished reading before the barrier) interleaved.  Tap-major contraction, branch-free request stream.
 template <int STAGES, int MODE, bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void conv_nt_ks2_bf16_kernel(NtArgs a) {
-    SL_MFMA_KERNEL_PRIORITY();
     constexpr int IT = 4, WN = 2, NW = 8;
     constexpr int WROWS = 64, BM = 128, BN = 128;
     constexpr int X_BYTES = BM * 128;
@@ -1758,7 +1755,7 @@ Cfg auto_cfg(const sl_conv_geom* g) {
             double best_cost = 1e30;
             for (int ks = 1; ks <= 8; ++ks) {
                 if (chunks % ks) continue;
-                const double rounds = (double)((tiles256 * ks + 255) / 256);
+                const double rounds = (double)((tiles256 * ks + sl_cus() - 1) / sl_cus());
                 const double cost = rounds * ((double)nsteps / ks + 35.0);
                 if (cost < best_cost - 1e-9) {
                     best_cost = cost;

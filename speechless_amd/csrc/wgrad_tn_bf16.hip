@@ -932,6 +932,7 @@ WCfg decode_wcfg(int cfg) { return WCfg{cfg & 15, (cfg >> 4) & 15, (cfg >> 8) & 
 
 int choose_splits(const sl_conv_geom* g, int tci, int tco, int target_wgs, int groups = 1) {
     const long tiles = (long)g->taps * (g->cin / tci) * (g->cout / tco) * groups;
+    target_wgs = target_wgs * sl_cus() / 256;  // (the callers' targets are for the whole chip: sl_set_available_cus)
     long want = (target_wgs + tiles - 1) / tiles;
     if (want < 1) want = 1;
     if (want > g->batch) want = g->batch;
@@ -1132,7 +1133,7 @@ static int multi_fill(const sl_wgrad_job* jobs, int n_jobs, MultiArgs* a) {
     }
     a->total_tiles = tiles;
     // P aligned segments per tile, two per work-group, about one work-group per CU (the interleaved kernel takes a whole CU)
-    int segs = 512 / tiles;
+    int segs = 2 * sl_cus() / tiles;
     if (segs > a->spt) segs = a->spt;
     if (segs < 1) segs = 1;
     a->segs = segs;

@@ -221,10 +221,13 @@ class _Buffers:
 
     def size_nt_workspace(self, eng, geoms, kind):
         need = 16
-        for p, g in zip(eng.plans, geoms):
-            if g is not None:
-                need = max(need, lib().raw("sl_conv1d_nt_workspace_bytes")(
-                    ctypes.byref(g), eng.dtype_code, eng.nt_cfg.get((kind, p.spec.name), 0)))
+        for hint in eng.cu_hints():  # (the split choosers consult sl_set_available_cus: size for every setting in use)
+            lib().call("sl_set_available_cus", hint)
+            for p, g in zip(eng.plans, geoms):
+                if g is not None:
+                    need = max(need, lib().raw("sl_conv1d_nt_workspace_bytes")(
+                        ctypes.byref(g), eng.dtype_code, eng.nt_cfg.get((kind, p.spec.name), 0)))
+        lib().call("sl_set_available_cus", 0)
         if self.nt_ws is None or self.nt_ws.numel() < need:
             self.nt_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
             self.launch_lists = {}
@@ -299,11 +302,14 @@ class _Buffers:
         first = eng.frozen_layer_count
         ws_bytes = 0
         bias_ws = 0
-        for p in eng.plans[first:]:
-            wg = self.wgrad_geom[p.index]
-            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
-                ctypes.byref(wg), eng.dtype_code, eng.nt_cfg.get(("wgrad", p.spec.name), 0)))
-            bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
+        for hint in eng.cu_hints():
+            L.call("sl_set_available_cus", hint)
+            for p in eng.plans[first:]:
+                wg = self.wgrad_geom[p.index]
+                ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
+                    ctypes.byref(wg), eng.dtype_code, eng.nt_cfg.get(("wgrad", p.spec.name), 0)))
+                bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
+        L.call("sl_set_available_cus", 0)
         self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
         if eng.planes > 1:
             need = max(p.taps_view * (self.wgrad_geom[p.index].cin + self.wgrad_geom_b[p.index].cin) * p.cout_pad
@@ -327,6 +333,7 @@ class _Buffers:
             self.launch_lists = {}
         last = len(eng.plans) - 1
         if eng.dtype == "bf16" and last > first:
+            # (its split count only shrinks with fewer CUs: the whole-chip size covers every hint)
             need = L.raw("sl_conv1d_backward_1x1_workspace_bytes")(ctypes.byref(self.wgrad_geom[last]),
                                                                    eng.grapheme_set_size, eng.dtype_code, 0)
             if need and (self.bwd1x1_ws is None or self.bwd1x1_ws.numel() < need):
@@ -474,12 +481,35 @@ class Engine:
         # utterances in small batches, i.e. configuration 5); SL_SPLIT_TOP=0: the whole-batch sequence everywhere.
         self.split_top = os.environ.get("SL_SPLIT_TOP", "1") != "0"
         self.split_min_tiles = None
+        # Data-parallel runs: CUs the communication kernels are expected to own while a bucket is on the wire.  The MFMA
+        # kernels take a whole CU per work-group and their grids are sized to whole rounds of the chip, so backward() tells
+        # the library's choosers to plan for 256 - comm_cus (sl_set_available_cus) while an exchange can be in flight -- only
+        # then: forward runs with the whole chip.  0 = no hint.  Set by train_step_resident from the reducer (comm_cus).
+        self.comm_cus = 0
         self._ctc_streams = None
         self._rec = None
         self._adam_tables = {}
         self._sharded_reducer = None  # the reducer of the last step, if that step ran Adam on this rank's slices only
 
     # ------------------------------------------------------------------ plumbing
+    def cu_hints(self):
+        """the sl_set_available_cus settings this engine launches under (workspaces are sized for all of them)"""
+        return [0, 256 - self.comm_cus] if self.comm_cus else [0]
+
+    def set_comm_cus(self, comm_cus):
+        """see self.comm_cus; re-sizes the split workspaces of the existing buffer sets for the new choosers' decisions"""
+        comm_cus = int(comm_cus or 0)
+        if comm_cus == self.comm_cus:
+            return
+        if comm_cus and not 0 < comm_cus <= 128:
+            raise ValueError("comm_cus must be in 0 .. 128")
+        self.comm_cus = comm_cus
+        for buf in self._buffers.values():
+            buf.launch_lists = {}
+            buf.size_nt_workspace(self, buf.fwd_geom, "fwd")
+            if buf.bwd_ready:
+                buf.size_backward_workspaces(self)
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
@@ -1538,6 +1568,7 @@ class Engine:
                 side_busy[0] = False
 
         n = len(self.plans)
+        hint = on_bucket_ready is not None and self.comm_cus
         split = buf.split_pending
         if split:  # the CTC ran by half-batches: so do the input gradients of the top three layers (see self.split_top)
             self._backward_top_split(buf, main)
@@ -1570,6 +1601,8 @@ class Engine:
                 on_bucket_ready(b)
                 if self._rec is not None:
                     self._rec.append((2, b))
+                if hint and b == 0:  # from here on communication kernels may own CUs: the choosers plan for the rest
+                    self._launch("cu_hint", "sl_set_available_cus", 256 - self.comm_cus)
             if i in dchain:
                 layers = dchain[i]
                 ys, ws, masks = self._chain_table("dgrad", layers, buf)
@@ -1583,6 +1616,8 @@ class Engine:
             if ones_in:
                 self._bias_grads_from_wgrad(ones_in, bool(ones_db), main)
             join_side()
+        if hint:
+            self._launch("cu_hint", "sl_set_available_cus", 0)
 
     def adam_step(self, fused=True):
         """Keras-2.0 Adam on the flat fp32 masters.  fused=True: one kernel per trainable layer that applies Adam AND
@@ -1643,6 +1678,7 @@ class Engine:
         dp = reducer is not None and (reducer.world_size > 1 or reducer.force)
         world = reducer.world_size if reducer is not None else 1
         self._sharded_reducer = reducer if (dp and reducer.shard_optimizer) else None
+        self.set_comm_cus(getattr(reducer, "comm_cus", 0) if dp else 0)
         grad_scale = 1.0 / (self.cur.batch * world)
         if self.split_top_ok(self.cur):
             self.forward(training=True, split_ctc=grad_scale)  # ... and the CTC, by half-batches (self.split_top)

@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 class GradBucketReducer:
     def __init__(self, flat_grads, ranges, process_group=None, overlap=True, force=False, compress=None,
-                 shard_optimizer=False):
+                 shard_optimizer=False, comm_cus=None):
         """force: issue the collectives even in a world of one rank (tests exercise the stream / event choreography and
         the RCCL call on a single GPU that way).
         compress: None (fp32 on the wire: the reduced gradient is the exact sum, identical on every rank) or "bf16"
@@ -32,6 +32,15 @@ class GradBucketReducer:
         halves.  Needs every bucket length to be a multiple of the world size."""
         if compress not in (None, "bf16"):
             raise ValueError("compress must be None or 'bf16'")
+        # CUs the collectives are expected to own while a bucket is on the wire (one work-group per RCCL channel): the engine
+        # then sizes the grids of backward's MFMA kernels for the rest (Engine.comm_cus, sl_set_available_cus).  Default:
+        # SL_COMM_CUS, else 0 = no hint -- under a stand-in that owns 32 / 64 CUs the re-planned grids were measured SLOWER
+        # than the whole-chip ones (2.57 / 2.53 against 2.39 / 2.32 ms per step, profiles/r04_comm_interference_exclusive*.json:
+        # the exchange owns its CUs for a third of backward, the hint costs all of it).  Kept as a knob for the first N > 1 run.
+        import os
+        if comm_cus is None:
+            comm_cus = int(os.environ.get("SL_COMM_CUS", "0"))
+        self.comm_cus = int(comm_cus)
         if shard_optimizer and compress:
             raise ValueError("shard_optimizer moves fp32 slices; it does not combine with compress")
         self.compress = compress

@@ -27,6 +27,13 @@ sys.path.insert(0, str(ROOT))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--exclusive", action="store_true",
+                    help="the stand-in's work-groups hold 96 KB of LDS each: they OWN their CUs (no MFMA work-group fits beside "
+                         "them), the pessimistic model of RCCL's communication kernels")
+    ap.add_argument("--available-cus", type=int, default=0,
+                    help="tell the library's grid choosers how many CUs the step's kernels can count on (sl_set_available_cus) "
+                         "while the stand-in runs; 0 = leave them at the device's CU count")
+    ap.add_argument("--blocks", default="8,16,32,64,128")
     args = ap.parse_args()
     import torch
     import bench
@@ -38,6 +45,8 @@ def main():
                     str(ROOT / "tools" / "comm_probe.hip")], check=True)
     probe = ctypes.CDLL(str(so))
     probe.probe_reduce_like.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    probe.probe_reduce_like_excl.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_void_p]
 
     specs = wav2letter_layer_specs(bench.MEL, bench.K_CLASSES)
     eng = Engine(specs, bench.K_CLASSES, dtype="bf16")
@@ -63,7 +72,10 @@ def main():
                 t0 = torch.cuda.Event(enable_timing=True)
                 t1 = torch.cuda.Event(enable_timing=True)
                 t0.record()
-                if self.blocks:
+                if self.blocks and args.exclusive:
+                    probe.probe_reduce_like_excl(scratch_dst[lo:hi].data_ptr(), scratch_src[lo:hi].data_ptr(), hi - lo,
+                                                 self.blocks, 96 * 1024, self.comm_stream.cuda_stream)
+                elif self.blocks:
                     probe.probe_reduce_like(scratch_dst[lo:hi].data_ptr(), scratch_src[lo:hi].data_ptr(), hi - lo,
                                             self.blocks, self.comm_stream.cuda_stream)
                 t1.record()
@@ -102,14 +114,20 @@ def main():
     out = {"step_ms_single_gpu_path": plain, "bucket_bytes": [(hi - lo) * 4 for lo, hi in ranges], "runs": []}
     base, _ = run(0)
     out["step_ms_reducer_choreography_no_traffic"] = base
-    for blocks in (8, 16, 32, 64, 128):
+    out["exclusive_stand_in"] = bool(args.exclusive)
+    for blocks in [int(v) for v in args.blocks.split(",")]:
+        if args.available_cus:  # the engine tells the choosers of backward's kernels (Engine.comm_cus)
+            red.comm_cus = blocks if args.available_cus < 0 else 256 - args.available_cus
         ms, dur = run(blocks)
-        entry = {"work_groups": blocks, "step_ms": ms, "slowdown_ms": ms - base, "stand_in_ms_per_bucket": dur}
+        entry = {"work_groups": blocks, "step_ms": ms, "slowdown_ms": ms - base, "stand_in_ms_per_bucket": dur,
+                 "available_cus_hint": (256 - blocks if args.available_cus < 0 else args.available_cus) or None}
         entry["stand_in_GBps_per_bucket"] = {i: 3 * out["bucket_bytes"][i] / (d * 1e-3) / 1e9 for i, d in dur.items()}
         out["runs"].append(entry)
         print(entry, flush=True)
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
-    (ROOT / "gpurun_out" / "comm_interference.json").write_text(json.dumps(out, indent=1))
+    name = "comm_interference{}{}.json".format("_exclusive" if args.exclusive else "",
+                                               "_hint" if args.available_cus else "")
+    (ROOT / "gpurun_out" / name).write_text(json.dumps(out, indent=1))
     print(json.dumps({k: v for k, v in out.items() if k != "runs"}))
 
 
