@@ -226,6 +226,12 @@ int sl_pack_weights(const float* w_master, void* w_fwd, void* w_dgrad, int k, in
  */
 int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,
                   int64_t dst_batch_stride, int dtype, void* stream);
+/* The same with a ONES CHANNEL: padding channel `ones_channel` (f <= ones_channel < dst_row_stride) of every packed frame is set
+ * to 1 (-1: none).  Its weight rows are and stay zero, so the forward pass does not see it; the first layer's weight-gradient
+ * GEMM then leaves that layer's BIAS gradient in row ones_channel of dW (sl_bias_grad_from_wgrad) -- the bias gradient of
+ * striding_conv (net.py:317-319) without a pass of its own over the layer's gradient tensor. */
+int sl_pack_input_ones(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,
+                       int64_t dst_batch_stride, int ones_channel, int dtype, void* stream);
 
 /* ---- output softmax (net.py:131,328-330) + the Keras ctc_batch_cost prologue log(p+eps) re-normalised -----------
  * logits: float, row t of utterance b at logits + b*logit_batch_stride + t*logit_stride (first k valid).

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // loads of two rows in flight before the first store; 32-bit index arithmetic, one division per row
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ src, T* __restrict__ dst, int t_in,
-                                                         int f, int dst_row0, int dst_rs, long dst_bs, long rows) {
+                                                         int f, int dst_row0, int dst_rs, long dst_bs, long rows,
+                                                         int ones_ch) {
     constexpr int ROWS = 2, COLS = 8;  // per wave and pass; bins beyond 64 * COLS go through the tail loop
     const int lane = threadIdx.x & 63;
     const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < COLS; ++k) v[q][k] = lane + 64 * k < f ? sp[lane + 64 * k] : 0.f;
         for (int c = lane + 64 * COLS; c < f; c += 64) dp[q][c] = cvt_out<T>(sp[c]);
+        if (ones_ch >= 0 && lane == 0) dp[q][ones_ch] = cvt_out<T>(1.f);  // the input's ones channel (sl_pack_input_ones)
     }
 #pragma unroll
     for (int q = 0; q < ROWS; ++q)
@@ -417,15 +419,22 @@ extern "C" int sl_pack_weights(const float* w_master, void* w_fwd, void* w_dgrad
 
 extern "C" int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,
                              int64_t dst_batch_stride, int dtype, void* stream) {
+    return sl_pack_input_ones(src, dst, batch, t_in, f, dst_row0, dst_row_stride, dst_batch_stride, -1, dtype, stream);
+}
+
+extern "C" int sl_pack_input_ones(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,
+                                  int64_t dst_batch_stride, int ones_channel, int dtype, void* stream) {
     SL_CHECK_ARG(batch > 0 && t_in > 0 && f > 0 && dst_row_stride >= f, "sl_pack_input: bad sizes");
+    SL_CHECK_ARG(ones_channel < 0 || (ones_channel >= f && ones_channel < dst_row_stride),
+                 "sl_pack_input_ones: the ones channel must be a padding channel (f <= c < dst_row_stride)");
     const long total = (long)batch * t_in;  // rows; 8 per work-group
     const unsigned grid = (unsigned)((total + 7) / 8);
     if (dtype == SL_BF16)
         hipLaunchKernelGGL((pack_input_kernel<unsigned short>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src,
-                           (unsigned short*)dst, t_in, f, dst_row0, dst_row_stride, (long)dst_batch_stride, total);
+                           (unsigned short*)dst, t_in, f, dst_row0, dst_row_stride, (long)dst_batch_stride, total, ones_channel);
     else
         hipLaunchKernelGGL((pack_input_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
-                           t_in, f, dst_row0, dst_row_stride, (long)dst_batch_stride, total);
+                           t_in, f, dst_row0, dst_row_stride, (long)dst_batch_stride, total, ones_channel);
     return sl_check_launch("sl_pack_input");
 }
 

@@ -669,9 +669,15 @@ class Engine:
         """hidden layer whose output has channel padding: its last padded channel is the constant 1"""
         return self.ones_channel and plan.index < len(self.plans) - 1 and plan.cout_pad > plan.spec.cout
 
+    def _has_ones_input(self):
+        """the packed INPUT carries a ones channel (sl_pack_input_ones) where its bins leave a padding channel free: 257 bins in
+        rows of 320 (configuration 5) -- not 128 mel bins, which fill their rows.  Single-plane paths only."""
+        return self.ones_channel and self.planes == 1 and self.plans[0].cin_pad > self.specs[0].cin
+
     def _ones_input_layers(self, first):
         """trainable layers whose input carries a ones channel: their bias gradient is row cin_pad - 1 of dW"""
-        return [i for i in range(max(first, 1), len(self.plans)) if self._has_ones_output(self.plans[i - 1])]
+        lower = [0] if (first == 0 and self._has_ones_input()) else []
+        return lower + [i for i in range(max(first, 1), len(self.plans)) if self._has_ones_output(self.plans[i - 1])]
 
     def _bias_grads_from_wgrad(self, layers, copy, stream):
         """One sl_bias_grad_from_wgrad launch for `layers` (their weight gradients are complete on `stream`)."""
@@ -778,8 +784,9 @@ class Engine:
             self.cur = buf
             self._src_keepalive = src
             return buf
-        self._launch("pack_input", "sl_pack_input", src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.pad_left, p0.cin_pad,
-                      buf.rows0 * p0.cin_pad, self.dtype_code, self._stream())
+        self._launch("pack_input", "sl_pack_input_ones", src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.pad_left,
+                     p0.cin_pad, buf.rows0 * p0.cin_pad, p0.cin_pad - 1 if self._has_ones_input() else -1, self.dtype_code,
+                     self._stream())
         self.cur = buf
         self._src_keepalive = src
         return buf

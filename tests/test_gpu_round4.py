@@ -448,3 +448,49 @@ def test_split_top_is_chosen_where_it_was_measured_to_pay():
         buf = Buf()
         buf.batch, buf.t_out = batch, t_out
         assert eng._split_top_pays(buf) is want, (batch, t_out)
+
+
+# ------------------------------------------------------------------------------------------ ones channel in the packed input
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_first_layer_bias_gradient_from_the_ones_channel_of_the_input(dtype):
+    """257 bins are packed into rows of 320 channels: the last padding channel of every input frame carries the constant 1
+    (sl_pack_input_ones), so striding_conv's weight-gradient GEMM leaves its BIAS gradient in row 319 of the centre tap
+    (no pass of its own over the layer's gradient tensor).  Against the pass (ones_channel off): the
+    same bias gradient, every other gradient unchanged, the padding rows of dW and of the weights still zero after
+    optimisation steps; 128 mel bins fill their rows and keep the pass."""
+    import torch
+    from speechless_amd.engine import HALO
+    case = make_case(b=3, t=150, f=257, seed=4)
+    grads = {}
+    for ones in (True, False):
+        eng = make_engine(case, dtype)
+        eng.ones_channel = ones
+        eng.set_weights(case["weights"])  # (the hidden layers' ones channels are part of the weights)
+        eng.use_launch_lists = False
+        eng.load_input(case["x"])
+        eng.set_labels(case["labels"], np.array(case["label_lengths"]), np.array(case["prediction_lengths"]))
+        eng.timeline = []
+        eng.forward(training=True)
+        eng.ctc()
+        eng.backward()
+        torch.cuda.synchronize()
+        tags = [t for t, _, _ in eng.timeline]
+        eng.timeline = None
+        assert ("bgrad:striding_conv" in tags) == (not ones), tags
+        p0 = eng.plans[0]
+        assert eng._has_ones_input() == ones and p0.cin_pad == 320
+        x0 = eng.cur.x0.float()
+        col = x0[:, p0.pad_left:p0.pad_left + 150, 319]
+        assert bool((col == (1.0 if ones else 0.0)).all()) and not x0[:, :p0.pad_left, 319].any() \
+            and not x0[:, p0.pad_left + 150:, 319].any() and not x0[:, :, 257:319].any()
+        grads[ones] = eng.get_gradients()
+        full = eng.layer_param_views(eng.grads, p0)[0]
+        assert not full[:, 257:, :].any()                                   # row 319 of every tap was moved / zeroed
+        for _ in range(3):
+            eng.train_step_resident()
+        torch.cuda.synchronize()
+        assert not eng.layer_param_views(eng.params, p0)[0][:, 257:, :].any()
+    for (wa, ba), (wb, bb) in zip(grads[True], grads[False]):
+        assert rel_l2(ba, bb) < 2e-6 and rel_l2(wa, wb) < 2e-6
+    mel = make_engine(make_case(b=2, t=64, f=128, seed=4), dtype)
+    assert not mel._has_ones_input()
