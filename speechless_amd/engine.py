@@ -163,7 +163,7 @@ class _Buffers:
         self.half_geoms = {}   # split top (Engine.split_top): (kind, layer) -> the layer's geometry for half the batch
         self.ctc_done = [None, None]  # split top: events behind the CTC launches of the two half-batches
         self.ctc_half_bytes = 0
-        self.split_pending = False    # the last forward ran the CTC by half-batches; backward() consumes it
+        self.split_pending = 0        # utterances in the first part if the last forward ran the CTC in two parts (else 0)
         self.wgrad_r = None  # bf16x3: the two partial weight gradients (RA | RB) in front of sl_split3_wgrad_combine
         self.wgrad_geom_b = [None] * n
         self.wgrad_geom = [None] * n
@@ -344,8 +344,8 @@ class _Buffers:
         """CTC workspace for label rows of up to l_max graphemes: sized in BYTES and never shrunk (the library's need
         is monotonic in l_max since round 3, but a buffer set that has served long labels keeps its allocation)."""
         need = lib().raw("sl_ctc_workspace_bytes")(self.batch, self.tt_pad, l_max)  # covers every length
-        if eng.split_top and self.batch % 2 == 0:  # two half-batches at a time, each with its own half of the workspace
-            half = _round_up(lib().raw("sl_ctc_workspace_bytes")(self.batch // 2, self.tt_pad, l_max), 256)
+        if eng.split_top and self.batch >= 2:  # two parts of the batch at a time (up to B - 1 utterances), each with its own workspace
+            half = _round_up(lib().raw("sl_ctc_workspace_bytes")(self.batch - 1, self.tt_pad, l_max), 256)
             self.ctc_half_bytes = max(self.ctc_half_bytes, half)
             need = max(need, 2 * self.ctc_half_bytes)
         if self.ctc_ws is None or self.ctc_ws.numel() < need:
@@ -477,7 +477,7 @@ class Engine:
         # backward.  The training step therefore runs its TOP by half-batches: big_conv_1 / big_conv_2 / output_conv forward of
         # half A, then A's CTC on a side stream UNDER the same layers of half B; B's CTC under the input gradients of A's top
         # layers.  Per-utterance results do not depend on the half an utterance is in; weight gradients stay whole-batch
-        # launches (sl_conv1d_backward_1x1_part accumulates the output layer's).  Used where it pays (_split_top_pays: long
+        # launches (sl_conv1d_backward_1x1_part accumulates the output layer's).  Used where it pays (_split_parts: long
         # utterances in small batches, i.e. configuration 5); SL_SPLIT_TOP=0: the whole-batch sequence everywhere.
         self.split_top = os.environ.get("SL_SPLIT_TOP", "1") != "0"
         self.split_min_tiles = None
@@ -830,9 +830,9 @@ class Engine:
         training=True applies dropout (if self.dropout_rate) to the inputs of the first n-3 layers: the packed input
         goes through sl_dropout into a second buffer, every other activation is dropped in place right after the
         layer that produced it (so the stored activation is the post-dropout one the backward pass needs).
-        split_ctc=grad_scale (train_step_resident, when split_top_ok()): the top three layers run by half-batches and each
-        half's CTC loss + gradient (ctc(grad_scale)) is launched on a side stream as soon as its probabilities exist;
-        backward() picks the halves up (see self.split_top)."""
+        split_ctc=(grad_scale, a) (train_step_resident, a = split_top_plan()): the top three layers run in two parts of the
+        batch -- utterances [0, a) and [a, B) -- and each part's CTC loss + gradient (ctc(grad_scale)) is launched on a side
+        stream as soon as its probabilities exist; backward() picks the parts up (see self.split_top)."""
         buf = self.load_input(input_batch) if input_batch is not None else self.cur
         if self._packed_dirty:
             self.repack_weights()
@@ -840,7 +840,7 @@ class Engine:
         n = len(self.plans)
         rate = self.dropout_rate if training else None
         buf.dropped = bool(rate)
-        buf.split_pending = False
+        buf.split_pending = 0
         fuse_out = self.fuse_output_softmax and self.dtype == "bf16" and bool(self.lib.raw("sl_output_softmax_supported")(
             ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size, self.dtype_code))
         # launch list (no dropout): everything below takes its frame count from the geometries, except the unfused
@@ -850,7 +850,7 @@ class Engine:
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
             self._replay(ops)
-            buf.split_pending = split_ctc is not None
+            buf.split_pending = split_ctc[1] if split_ctc is not None else 0
             return buf.probs
         record = key is not None and self.use_launch_lists and self.timeline is None and \
             self.kernel_timeline is None and self._rec is None
@@ -865,29 +865,40 @@ class Engine:
             self._rec = None
 
     # ------------------------------------------------------------------ split top (see self.split_top)
-    def split_top_ok(self, buf):
-        """whether the training step on `buf` can run its top three layers and the CTC by half-batches"""
+    def split_top_plan(self, buf):
+        """How the training step on `buf` runs its top three layers and the CTC in two parts of the batch: the number of
+        utterances in the first part, or 0 (whole-batch step)."""
         state = (self.split_top, bool(self.dropout_rate), self.frozen_layer_count, self.fuse_output_softmax,
                  self.fuse_output_backward, tuple(sorted(self.nt_cfg)), buf.bwd_ready, buf.bwd1x1_ws is not None,
                  buf.labels is not None)
         if getattr(buf, "_split_ok", (None, None))[0] != state:
             buf._split_ok = (state, self._split_top_ok(buf))
-        return buf._split_ok[1] and self._split_top_pays(buf)
+        return self._split_parts(buf) if buf._split_ok[1] else 0
 
-    def _split_top_pays(self, buf):
+    def _split_parts(self, buf):
         """Measured rule (MI355X, tools/split_by_bucket.py, rocprofv3 kernel traces under profiles/r04_trace_*): the top
         layers run 256 x 256 tiles, ONE work-group per CU, and a CTC lattice wave cannot share a CU with such a work-group
-        (its registers fill the SIMDs) -- so while a half's lattice runs, 3 waves per utterance hold CUs of their own and a
-        launch of exactly 256 tiles needs a second round.  The split pays where the two half-batch launches of the widest
-        layer, next to those waves, take no more rounds of 256 work-groups than the whole-batch launch does: config 5's
-        buckets of 384 / 896 / 960 tiles (-0.09 / -0.22 / -0.09 ms), not 512 ... 768 (+0.05 ... +0.11 ms) and not config 3
-        (512 tiles: +0.10 ms)."""
-        if self.split_min_tiles is not None:  # measurement hook: a plain threshold instead of the rule (0 = always)
-            return True if self.split_min_tiles == 0 else self._top_tiles(buf) >= self.split_min_tiles
+        (its registers fill the SIMDs) -- so while a part's lattice runs, 3 waves per utterance hold CUs of their own and a
+        launch of exactly 256 tiles needs a second round.  The split pays where the two launches of the widest layer, each
+        next to the other part's lattice waves, take no more rounds of 256 work-groups than the whole-batch launch: config
+        5's buckets of 384 / 896 / 960 tiles in halves (-0.09 / -0.22 / -0.09 ms), 640 tiles as 3 + 5 utterances (240 + 400
+        tiles = 1 + 2 rounds), not 512 / 768 / 1024 (whole rounds already: +0.05 ... +0.11 ms when halved) and not config
+        3 (512 tiles: +0.10 ms).  Among the splits that qualify the most even one is taken (equal halves also keep an
+        utterance's results independent of the part it is in: the two launches then pick the same K split)."""
+        b = buf.batch
+        if self.split_min_tiles is not None:  # measurement hook: halves, from a tile count on (0 = always)
+            return b // 2 if (b % 2 == 0 and self._top_tiles(buf) >= self.split_min_tiles) else 0
         cus = 256
-        n = self._top_tiles(buf)
-        half = n // 2 + 3 * (buf.batch // 2)
-        return 2 * (-(-half // cus)) <= -(-n // cus)
+        per_utt = self._top_tiles(buf) // b
+        whole = -(-(b * per_utt) // cus)
+        best, best_key = 0, None
+        for a in range(1, b):
+            rounds = -(-(a * per_utt + 3 * (b - a)) // cus) + -(-((b - a) * per_utt + 3 * a) // cus)
+            if rounds <= whole:
+                key = (abs(2 * a - b), a)
+                if best_key is None or key < best_key:
+                    best, best_key = a, key
+        return best
 
     def _top_tiles(self, buf):
         widest = max(self.plans[i].cout_pad for i in range(len(self.plans) - 3, len(self.plans) - 1))
@@ -895,7 +906,7 @@ class Engine:
 
     def _split_top_ok(self, buf):
         n = len(self.plans)
-        if not self.split_top or self.dtype != "bf16" or self.dropout_rate or n < 4 or buf.batch < 2 or buf.batch % 2:
+        if not self.split_top or self.dtype != "bf16" or self.dropout_rate or n < 4 or buf.batch < 2:
             return False
         if self.frozen_layer_count >= n - 3 or not self.fuse_output_softmax or not self.fuse_output_backward:
             return False
@@ -908,22 +919,22 @@ class Engine:
             return False
         if not buf.bwd_ready or buf.bwd1x1_ws is None or buf.labels is None:
             return False
-        hf, hw = self._half_geom(buf, "fwd", n - 1), self._half_geom(buf, "wgrad", n - 1)
-        return bool(self.lib.raw("sl_output_softmax_supported")(ctypes.byref(hf), self.grapheme_set_size, self.dtype_code)) \
-            and bool(self.lib.raw("sl_conv1d_backward_1x1_supported")(ctypes.byref(hw), self.grapheme_set_size,
-                                                                        self.dtype_code))
+        return bool(self.lib.raw("sl_output_softmax_supported")(ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size,
+                                                                self.dtype_code)) \
+            and bool(self.lib.raw("sl_conv1d_backward_1x1_supported")(ctypes.byref(buf.wgrad_geom[n - 1]),
+                                                                        self.grapheme_set_size, self.dtype_code))
 
-    def _half_geom(self, buf, kind, i):
-        """geometry of layer i (kind 'fwd' / 'dgrad' / 'wgrad') for half the batch; follows set_length like the others"""
-        g = buf.half_geoms.get((kind, i))
+    def _part_geom(self, buf, kind, i, count):
+        """geometry of layer i (kind 'fwd' / 'dgrad' / 'wgrad') for `count` utterances; follows set_length like the others"""
+        g = buf.half_geoms.get((kind, i, count))
         if g is None:
             src = {"fwd": buf.fwd_geom, "dgrad": buf.dgrad_geom, "wgrad": buf.wgrad_geom}[kind][i]
             g = ConvGeom()
             for name, _ in ConvGeom._fields_:
                 setattr(g, name, getattr(src, name))
-            g.batch = buf.batch // 2
-            buf.half_geoms[(kind, i)] = g
-            if kind in ("fwd", "dgrad"):  # (a half batch may pick more K splits: make sure the workspace covers it)
+            g.batch = count
+            buf.half_geoms[(kind, i, count)] = g
+            if kind in ("fwd", "dgrad"):  # (a part of the batch may pick more K splits: make sure the workspace covers it)
                 need = self.lib.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(g), self.dtype_code, 0)
                 if buf.nt_ws is None or buf.nt_ws.numel() < need:
                     buf.nt_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
@@ -931,46 +942,46 @@ class Engine:
         return g
 
     @staticmethod
-    def _half_ptr(t, h):
-        """address of utterance h * B / 2 of a tensor whose first dimension is the batch"""
-        return t.data_ptr() + h * (t.shape[0] // 2) * t.stride(0) * t.element_size()
+    def _utt_ptr(t, first):
+        """address of utterance `first` of a tensor whose first dimension is the batch"""
+        return t.data_ptr() + first * t.stride(0) * t.element_size()
 
-    def _forward_top_split(self, buf, x, st, grad_scale):
-        """big_conv_1, big_conv_2, output_conv + softmax and the CTC, half-batch by half-batch (self.split_top)"""
+    def _forward_top_split(self, buf, x, st, grad_scale, a):
+        """big_conv_1, big_conv_2, output_conv + softmax and the CTC, part by part: utterances [0, a), then [a, B)"""
         n = len(self.plans)
-        for h in (0, 1):
+        for h, (first, count) in enumerate(((0, a), (a, buf.batch - a))):
             xin = x
             for i in (n - 3, n - 2):
                 p = self.plans[i]
                 _, bias = self.layer_param_views(self.params, p)
                 y = buf.y[i]
-                self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", self._half_ptr(xin, h), self.w_fwd[i].data_ptr(),
-                             bias.data_ptr(), None, self._half_ptr(y, h), ctypes.byref(self._half_geom(buf, "fwd", i)),
+                self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", self._utt_ptr(xin, first), self.w_fwd[i].data_ptr(),
+                             bias.data_ptr(), None, self._utt_ptr(y, first),
+                             ctypes.byref(self._part_geom(buf, "fwd", i, count)),
                              _lib.EPI_BIAS_ELU if p.spec.activation == "elu" else _lib.EPI_BIAS_RELU, self.dtype_code, 0, 0,
                              buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
                 xin = y
-            self._eager_op(self._top_half_tail, buf, h, grad_scale)
-        buf.split_pending = True
+            self._eager_op(self._top_part_tail, buf, h, first, count, grad_scale)
+        buf.split_pending = a
         return buf.probs
 
-    def _top_half_tail(self, buf, h, grad_scale):
-        """output layer + softmax of half h on the main stream, then its CTC loss + gradient on a side stream.  Marshalled
-        afresh every step: the dense probability tensors (offset of half 1 depends on the frame count), the label tensors
+    def _top_part_tail(self, buf, h, first, count, grad_scale):
+        """output layer + softmax of one part on the main stream, then its CTC loss + gradient on a side stream.  Marshalled
+        afresh every step: the dense probability tensors (a part's offset depends on the frame count), the label tensors
         (the staged pipeline hands over new ones per batch) and the label width are per-batch values."""
         n = len(self.plans)
         last = n - 1
         p = self.plans[last]
-        hb = buf.batch // 2
         k = self.grapheme_set_size
         main = torch.cuda.current_stream(self.device)
         if self._ctc_streams is None:
             self._ctc_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
         side = self._ctc_streams[h]
         _, bias = self.layer_param_views(self.params, p)
-        dense = h * hb * buf.t_out * k * 4  # probs / log q: [B][T'][K] floats
-        self._launch("fwd:" + p.spec.name, "sl_output_softmax", self._half_ptr(buf.y[last - 1], h),
+        dense = first * buf.t_out * k * 4  # probs / log q: [B][T'][K] floats
+        self._launch("fwd:" + p.spec.name, "sl_output_softmax", self._utt_ptr(buf.y[last - 1], first),
                      self.w_fwd[last].data_ptr(), bias.data_ptr(), buf.probs.data_ptr() + dense, buf.logq.data_ptr() + dense,
-                     None, ctypes.byref(self._half_geom(buf, "fwd", last)), k, p.cout_pad, buf.tt_pad * p.cout_pad,
+                     None, ctypes.byref(self._part_geom(buf, "fwd", last, count)), k, p.cout_pad, buf.tt_pad * p.cout_pad,
                      self.ctc_epsilon, self.dtype_code, main.cuda_stream)
         ready = torch.cuda.Event()
         ready.record(main)
@@ -979,11 +990,11 @@ class Engine:
         with torch.cuda.stream(side):
             side.wait_event(ready)
             self._launch("ctc", "sl_ctc_loss_grad", buf.probs.data_ptr() + dense, buf.logq.data_ptr() + dense,
-                         labels.data_ptr() + h * hb * l_max * 4, buf.label_len.data_ptr() + h * hb * 4,
-                         buf.input_len.data_ptr() + h * hb * 4, buf.loss.data_ptr() + h * hb * 4,
-                         self._half_ptr(buf.g[last], h), hb, buf.t_out, k, l_max, HALO, p.cout_pad, buf.rows * p.cout_pad,
-                         self.dtype_code, self.ctc_epsilon, grad_scale, buf.ctc_ws.data_ptr() + h * buf.ctc_half_bytes,
-                         buf.ctc_half_bytes, side.cuda_stream)
+                         labels.data_ptr() + first * l_max * 4, buf.label_len.data_ptr() + first * 4,
+                         buf.input_len.data_ptr() + first * 4, buf.loss.data_ptr() + first * 4,
+                         self._utt_ptr(buf.g[last], first), count, buf.t_out, k, l_max, HALO, p.cout_pad,
+                         buf.rows * p.cout_pad, self.dtype_code, self.ctc_epsilon, grad_scale,
+                         buf.ctc_ws.data_ptr() + h * buf.ctc_half_bytes, buf.ctc_half_bytes, side.cuda_stream)
             done = torch.cuda.Event()
             done.record(side)
         buf.ctc_done[h] = done
@@ -992,41 +1003,30 @@ class Engine:
     def _wait_ctc_half(self, buf, h, main):
         main.wait_event(buf.ctc_done[h])
 
-    def _backward_top_split(self, buf, main):
-        """the input gradients of the top three layers (and the output layer's weight gradient) by half-batches, each half
-        behind its own CTC: half B's lattice runs under half A's launches here"""
+    def _backward_top_split(self, buf, main, a):
+        """the input gradients of the top three layers (and the output layer's weight gradient) part by part, each part
+        behind its own CTC: the second part's lattice runs under the first part's launches here"""
         n = len(self.plans)
         st = main.cuda_stream
         last = n - 1
-        for h in (0, 1):
+        for h, (first, count) in enumerate(((0, a), (a, buf.batch - a))):
             self._eager_op(self._wait_ctc_half, buf, h, main)
             p = self.plans[last]
             dw, _ = self.layer_param_views(self.grads, p)
             epi = _lib.EPI_ELU_MASK if self.specs[last - 1].activation == "elu" else _lib.EPI_RELU_MASK
-            self._launch("bwd:" + p.spec.name, "sl_conv1d_backward_1x1_part", self._half_ptr(buf.y[last - 1], h),
-                         self._half_ptr(buf.g[last], h), self.w_dgrad[last].data_ptr(), self._half_ptr(buf.g[last - 1], h),
-                         dw.data_ptr(), ctypes.byref(self._half_geom(buf, "wgrad", last)), epi, self.grapheme_set_size,
+            self._launch("bwd:" + p.spec.name, "sl_conv1d_backward_1x1_part", self._utt_ptr(buf.y[last - 1], first),
+                         self._utt_ptr(buf.g[last], first), self.w_dgrad[last].data_ptr(),
+                         self._utt_ptr(buf.g[last - 1], first), dw.data_ptr(),
+                         ctypes.byref(self._part_geom(buf, "wgrad", last, count)), epi, self.grapheme_set_size,
                          self.dtype_code, 0, h, buf.bwd1x1_ws.data_ptr(), buf.bwd1x1_ws.numel(), st)
             for i in (n - 2, n - 3):
                 q = self.plans[i]
                 elu = self.specs[i - 1].activation == "elu"
-                self._launch("dgrad:" + q.spec.name, "sl_conv1d_nt", self._half_ptr(buf.g[i], h), self.w_dgrad[i].data_ptr(),
-                             None, self._half_ptr(buf.y[i - 1], h), self._half_ptr(buf.g[i - 1], h),
-                             ctypes.byref(self._half_geom(buf, "dgrad", i)), _lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK,
-                             self.dtype_code, 0, 0, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-
-    def _plane_geom(self, buf, kind, i, channels):
-        """the NT geometry of layer i (kind 'fwd' / 'dgrad') with its OUTPUT side describing a bf16x3 plane tensor of
-        `channels` padded channels (rows of 3 x channels behind HALO halo rows) instead of the fp32 staging buffer"""
-        g = buf.plane_geoms.get((kind, i))
-        if g is None:
-            src = (buf.fwd_geom if kind == "fwd" else buf.dgrad_geom)[i]
-            g = ConvGeom()
-            for name, _ in ConvGeom._fields_:
-                setattr(g, name, getattr(src, name))
-            g.y_row0, g.y_row_stride, g.y_batch_stride = HALO, self.planes * channels, buf.rows * channels * self.planes
-            buf.plane_geoms[(kind, i)] = g
-        return g
+                self._launch("dgrad:" + q.spec.name, "sl_conv1d_nt", self._utt_ptr(buf.g[i], first), self.w_dgrad[i].data_ptr(),
+                             None, self._utt_ptr(buf.y[i - 1], first), self._utt_ptr(buf.g[i - 1], first),
+                             ctypes.byref(self._part_geom(buf, "dgrad", i, count)),
+                             _lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK, self.dtype_code, 0, 0, buf.nt_ws.data_ptr(),
+                             buf.nt_ws.numel(), st)
 
     def _dropout_x3(self, tag, src, dst, y, channels, mode, seed, st):
         """sl_split3_dropout over a whole plane tensor (halo rows and padding included: zeros stay zeros)"""
@@ -1109,7 +1109,7 @@ class Engine:
                 x = buf.y[p.index]
                 continue
             if split_ctc is not None and p.index == n - 3:
-                return self._forward_top_split(buf, x, st, split_ctc)
+                return self._forward_top_split(buf, x, st, split_ctc[0], split_ctc[1])
             if p.index in chained:
                 layers = chained[p.index]
                 ys, ws, biases = self._chain_table("fwd", layers, buf)
@@ -1577,8 +1577,8 @@ class Engine:
         n = len(self.plans)
         hint = on_bucket_ready is not None and self.comm_cus
         split = buf.split_pending
-        if split:  # the CTC ran by half-batches: so do the input gradients of the top three layers (see self.split_top)
-            self._backward_top_split(buf, main)
+        if split:  # the CTC ran in two parts: so do the input gradients of the top three layers (see self.split_top)
+            self._backward_top_split(buf, main, split)
         pending, pending_bytes = [], 0  # layers whose bias-gradient pass is still owed to the side stream
         for p in reversed(self.plans[first:]):
             i = p.index
@@ -1687,8 +1687,9 @@ class Engine:
         self._sharded_reducer = reducer if (dp and reducer.shard_optimizer) else None
         self.set_comm_cus(getattr(reducer, "comm_cus", 0) if dp else 0)
         grad_scale = 1.0 / (self.cur.batch * world)
-        if self.split_top_ok(self.cur):
-            self.forward(training=True, split_ctc=grad_scale)  # ... and the CTC, by half-batches (self.split_top)
+        part = self.split_top_plan(self.cur)
+        if part:
+            self.forward(training=True, split_ctc=(grad_scale, part))  # ... and the CTC, in two parts (self.split_top)
             loss = self.cur.loss
         else:
             self.forward(training=True)

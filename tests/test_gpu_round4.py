@@ -356,8 +356,9 @@ def _split_step(eng, case, split, steps=1, adam=False):
         else:
             gs = 1.0 / eng.cur.batch
             if split:
-                assert eng.split_top_ok(eng.cur)
-                eng.forward(training=True, split_ctc=gs)
+                part = eng.split_top_plan(eng.cur)
+                assert part == eng.cur.batch // 2
+                eng.forward(training=True, split_ctc=(gs, part))
                 loss = eng.cur.loss
             else:
                 eng.forward(training=True)
@@ -437,60 +438,40 @@ def test_split_top_training_steps_through_launch_lists_equal_eager_steps():
 
 def test_split_top_is_chosen_where_it_was_measured_to_pay():
     """the pays-off rule of Engine.split_top on the geometries it was measured on (tools/split_by_bucket.py): config 3 and
-    config 5's buckets of 512 .. 768 top-layer tiles keep the whole-batch step, 384 / 896 / 960 tiles split"""
+    config 5's buckets of 512 / 768 / 1024 top-layer tiles (whole rounds of 256 work-groups already) keep the whole-batch
+    step, 384 / 896 / 960 tiles split in halves, 640 tiles as 3 + 5 utterances (1 + 2 rounds)"""
     from speechless_amd.engine import Engine, wav2letter_layer_specs
     eng = Engine(wav2letter_layer_specs(257, 29), 29, dtype="bf16")
 
     class Buf:
         pass
-    for batch, t_out, want in ((32, 500, False), (8, 1484, True), (8, 1853, False), (8, 2354, False), (8, 2842, False),
-                               (8, 3369, True), (8, 3763, True), (8, 3997, False)):
+    for batch, t_out, want in ((32, 500, 0), (8, 1484, 4), (8, 1853, 0), (8, 2354, 3), (8, 2842, 0), (8, 3369, 4),
+                               (8, 3763, 4), (8, 3997, 0)):
         buf = Buf()
         buf.batch, buf.t_out = batch, t_out
-        assert eng._split_top_pays(buf) is want, (batch, t_out)
+        assert eng._split_parts(buf) == want, (batch, t_out, eng._split_parts(buf))
 
 
-# ------------------------------------------------------------------------------------------ ones channel in the packed input
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
-def test_first_layer_bias_gradient_from_the_ones_channel_of_the_input(dtype):
-    """257 bins are packed into rows of 320 channels: the last padding channel of every input frame carries the constant 1
-    (sl_pack_input_ones), so striding_conv's weight-gradient GEMM leaves its BIAS gradient in row 319 of the centre tap
-    (no pass of its own over the layer's gradient tensor).  Against the pass (ones_channel off): the
-    same bias gradient, every other gradient unchanged, the padding rows of dW and of the weights still zero after
-    optimisation steps; 128 mel bins fill their rows and keep the pass."""
+def test_split_top_with_uneven_parts_against_the_whole_batch_step():
+    """8 utterances as 3 + 5 (what the rule picks for config 5's 640-tile buckets): same losses and gradients as the
+    whole-batch step within bf16 noise, bitwise reproducible, through launch lists as well."""
     import torch
-    from speechless_amd.engine import HALO
-    case = make_case(b=3, t=150, f=257, seed=4)
-    grads = {}
-    for ones in (True, False):
-        eng = make_engine(case, dtype)
-        eng.ones_channel = ones
-        eng.set_weights(case["weights"])  # (the hidden layers' ones channels are part of the weights)
-        eng.use_launch_lists = False
-        eng.load_input(case["x"])
-        eng.set_labels(case["labels"], np.array(case["label_lengths"]), np.array(case["prediction_lengths"]))
-        eng.timeline = []
-        eng.forward(training=True)
-        eng.ctc()
+    case = make_case(b=8, t=700, seed=31)
+    eng = make_engine(case, "bf16")
+    eng.load_input(case["x"])
+    eng.set_labels(case["labels"], np.array(case["label_lengths"]), np.array(case["prediction_lengths"]))
+    eng.forward(training=True)  # (the separate calls are the whole-batch sequence; only train_step_resident splits)
+    whole = eng.ctc(grad_scale=1.0 / 8).cpu().numpy().copy()
+    eng.backward()
+    g_whole = eng.grads.clone()
+    results = []
+    for lists in (False, True, True):
+        eng.use_launch_lists = lists
+        eng.forward(training=True, split_ctc=(1.0 / 8, 3))
         eng.backward()
         torch.cuda.synchronize()
-        tags = [t for t, _, _ in eng.timeline]
-        eng.timeline = None
-        assert ("bgrad:striding_conv" in tags) == (not ones), tags
-        p0 = eng.plans[0]
-        assert eng._has_ones_input() == ones and p0.cin_pad == 320
-        x0 = eng.cur.x0.float()
-        col = x0[:, p0.pad_left:p0.pad_left + 150, 319]
-        assert bool((col == (1.0 if ones else 0.0)).all()) and not x0[:, :p0.pad_left, 319].any() \
-            and not x0[:, p0.pad_left + 150:, 319].any() and not x0[:, :, 257:319].any()
-        grads[ones] = eng.get_gradients()
-        full = eng.layer_param_views(eng.grads, p0)[0]
-        assert not full[:, 257:, :].any()                                   # row 319 of every tap was moved / zeroed
-        for _ in range(3):
-            eng.train_step_resident()
-        torch.cuda.synchronize()
-        assert not eng.layer_param_views(eng.params, p0)[0][:, 257:, :].any()
-    for (wa, ba), (wb, bb) in zip(grads[True], grads[False]):
-        assert rel_l2(ba, bb) < 2e-6 and rel_l2(wa, wb) < 2e-6
-    mel = make_engine(make_case(b=2, t=64, f=128, seed=4), dtype)
-    assert not mel._has_ones_input()
+        results.append((eng.cur.loss.cpu().numpy().copy(), eng.grads.clone()))
+    np.testing.assert_allclose(results[0][0], whole, rtol=2e-5)
+    assert float(torch.linalg.norm(results[0][1] - g_whole) / torch.linalg.norm(g_whole)) < 5e-3
+    for loss, grads in results[1:]:
+        assert np.array_equal(loss, results[0][0]) and torch.equal(grads, results[0][1])

@@ -17,8 +17,9 @@ def main():
         profile_steps = 1
     b = bench.Bench(5, A(), 1, 0, "cuda:0")
     eng = b.eng
-    eng.split_min_tiles = 0  # the mechanism on every bucket, whatever the engine's pays-off rule says
-    print("{:>6} {:>6} {:>9} {:>9} {:>8}".format("T'max", "tiles", "whole_ms", "split_ms", "diff"))
+    # default: equal halves on every bucket (the mechanism, whatever the engine's rule says); --rule: the engine's own choice
+    eng.split_min_tiles = None if "--rule" in sys.argv else 0
+    print("{:>6} {:>6} {:>9} {:>9} {:>8} {:>6}".format("T'max", "tiles", "whole_ms", "split_ms", "diff", "part"))
     for (x_dev, lab, ll, pl, tl) in b.resident:
         res = {}
         for split in (False, True, False, True):
@@ -40,7 +41,8 @@ def main():
         t_out = eng.cur.t_out
         tiles = eng.cur.batch * (-(-t_out // 256)) * 8
         w, s = min(res[False]), min(res[True])
-        print("{:6d} {:6d} {:9.4f} {:9.4f} {:+8.4f}".format(t_out, tiles, w, s, s - w))
+        eng.split_top = True
+        print("{:6d} {:6d} {:9.4f} {:9.4f} {:+8.4f} {:6d}".format(t_out, tiles, w, s, s - w, eng.split_top_plan(eng.cur)))
 
 
 if __name__ == "__main__":
