@@ -410,6 +410,10 @@ class Bench:
         for other in ("ctc", "softmax", "decode"):
             if other in live_ms:
                 groups[other] = {"ms_per_step": live_ms[other]}
+        if config == 5 and "ctc" in groups:
+            groups["ctc"]["note"] = ("where Engine.split_top applies (buckets whose top-layer launches split into whole rounds of "
+                                     "256 work-groups) the CTC runs in two parts on side streams UNDER the top layers of the "
+                                     "other part: its duration is then not additive with the other groups")
         groups["adam_and_repack"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("adam"))}
         groups["bias_grad"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("bgrad:")),
                                "note": "side stream, concurrent with the wgrad/dgrad kernels of the same layer: these "
@@ -455,20 +459,25 @@ class Bench:
         dom_flops = sum(per_launch[t]["flops"] for t in dom_tags) / len(dom_tags)
         dom_ms = sum(kernel_ms[t] for t in dom_tags) / len(dom_tags)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        traffic, traffic_source, per_launch_traffic = None, None, None
+        traffic, traffic_source, per_launch_traffic, traffic_age = None, None, None, None
         for name in sorted((ROOT / "profiles").glob("r*_pmc_traffic_wgrad_ilv.json"), reverse=True):
             pmc = json.loads(name.read_text())  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh
             per_launch_traffic = {k: v["traffic_bytes"] for k, v in pmc.get("launches", {}).items()}
             dom = [v for k, v in per_launch_traffic.items() if k in ("big_conv_1", "big_conv_2")]
             traffic = sum(dom) / len(dom) if dom else pmc["traffic_bytes_per_launch_avg"]
             traffic_source = "profiles/" + name.name
+            try:  # which commit the constant comes from: a stale file shows as an old hash
+                traffic_age = subprocess.run(["git", "log", "-1", "--format=%h %cs", "--", str(name)], cwd=str(ROOT),
+                                             capture_output=True, text=True, timeout=10).stdout.strip() or None
+            except Exception:
+                traffic_age = None
             break
         return {
             "bound": "mfma", "kernel": "wgrad_tn_ilv_kernel (weight gradient of big_conv_1 and big_conv_2; average over its {} "
                                        "launches per step)".format(len(dom_tags)),
             "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_source": traffic_source, "traffic_per_launch": per_launch_traffic,
+            "traffic_source": traffic_source, "traffic_age": traffic_age, "traffic_per_launch": per_launch_traffic,
             "algorithmic_bytes_per_launch": {
                 "big_conv_1": BATCH_PER_GPU * (FRAMES // 2) * (256 + 2048) * 2 + 32 * 256 * 2048 * 4,
                 "big_conv_2": BATCH_PER_GPU * (FRAMES // 2) * (2048 + 2048) * 2 + 2048 * 2048 * 4,
