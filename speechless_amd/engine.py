@@ -1028,6 +1028,19 @@ class Engine:
                              _lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK, self.dtype_code, 0, 0, buf.nt_ws.data_ptr(),
                              buf.nt_ws.numel(), st)
 
+    def _plane_geom(self, buf, kind, i, channels):
+        """the NT geometry of layer i (kind 'fwd' / 'dgrad') with its OUTPUT side describing a bf16x3 plane tensor of
+        `channels` padded channels (rows of 3 x channels behind HALO halo rows) instead of the fp32 staging buffer"""
+        g = buf.plane_geoms.get((kind, i))
+        if g is None:
+            src = (buf.fwd_geom if kind == "fwd" else buf.dgrad_geom)[i]
+            g = ConvGeom()
+            for name, _ in ConvGeom._fields_:
+                setattr(g, name, getattr(src, name))
+            g.y_row0, g.y_row_stride, g.y_batch_stride = HALO, self.planes * channels, buf.rows * channels * self.planes
+            buf.plane_geoms[(kind, i)] = g
+        return g
+
     def _dropout_x3(self, tag, src, dst, y, channels, mode, seed, st):
         """sl_split3_dropout over a whole plane tensor (halo rows and padding included: zeros stay zeros)"""
         self._launch(tag, "sl_split3_dropout", src.data_ptr(), dst.data_ptr(), y.data_ptr() if y is not None else None,
