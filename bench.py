@@ -315,9 +315,13 @@ class Bench:
         eng = self.eng
         eng.timeline = []
         n_steps = self.args.profile_steps if self.config != 5 else len(self.resident)
+        # per-launch durations are taken from the whole-batch sequence: where Engine.split_top runs the CTC of one part of the
+        # batch under the top layers of the other, both sides' event-bracketed durations are stretched by the overlap
+        split, eng.split_top = eng.split_top, False
         for _ in range(n_steps):
             self.step()
         self.torch.cuda.synchronize()
+        eng.split_top = split
         per_tag = {}
         for tag, start, stop in eng.timeline:
             per_tag.setdefault(tag, []).append(start.elapsed_time(stop))
@@ -410,10 +414,11 @@ class Bench:
         for other in ("ctc", "softmax", "decode"):
             if other in live_ms:
                 groups[other] = {"ms_per_step": live_ms[other]}
-        if config == 5 and "ctc" in groups:
-            groups["ctc"]["note"] = ("where Engine.split_top applies (buckets whose top-layer launches split into whole rounds of "
-                                     "256 work-groups) the CTC runs in two parts on side streams UNDER the top layers of the "
-                                     "other part: its duration is then not additive with the other groups")
+        if config == 5:
+            groups["note"] = ("per-launch durations of the WHOLE-BATCH sequence; in the timed region Engine.split_top runs the CTC "
+                              "of one part of the batch on a side stream under the top layers of the other part where that takes "
+                              "no more rounds of 256 work-groups (the 384 / 640 / 896 / 960-tile buckets): ms_per_step is "
+                              "smaller than the sum of these groups by the CTC time hidden there")
         groups["adam_and_repack"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("adam"))}
         groups["bias_grad"] = {"ms_per_step": sum(v for t, v in live_ms.items() if t.startswith("bgrad:")),
                                "note": "side stream, concurrent with the wgrad/dgrad kernels of the same layer: these "
@@ -466,11 +471,9 @@ class Bench:
             dom = [v for k, v in per_launch_traffic.items() if k in ("big_conv_1", "big_conv_2")]
             traffic = sum(dom) / len(dom) if dom else pmc["traffic_bytes_per_launch_avg"]
             traffic_source = "profiles/" + name.name
-            try:  # which commit the constant comes from: a stale file shows as an old hash
-                traffic_age = subprocess.run(["git", "log", "-1", "--format=%h %cs", "--", str(name)], cwd=str(ROOT),
-                                             capture_output=True, text=True, timeout=10).stdout.strip() or None
-            except Exception:
-                traffic_age = None
+            # when the constant was measured (stamped into the file by tools/pmc_traffic.sh; there is no .git on the GPU
+            # box to ask): a stale file shows as an old stamp
+            traffic_age = pmc.get("measured")
             break
         return {
             "bound": "mfma", "kernel": "wgrad_tn_ilv_kernel (weight gradient of big_conv_1 and big_conv_2; average over its {} "

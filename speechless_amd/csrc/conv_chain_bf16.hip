@@ -19,7 +19,7 @@
 //     row-contiguous from the LDS copy, 16 bytes per lane).
 //   * a wave requests exactly the weight rows it reads itself, so the ring needs NO barrier: the waves drift apart inside a
 //     layer and one wave's request / read phase runs under its SIMD partner's MFMAs; barriers only at the layer ends.
-// Measured (config 3, tools/chain_time.py, tools/chain_stamps.py; history in DESIGN.md section 3.1a): forward 124 us against
+// Measured (config 3, tools/chain_time.py, tools/chain_stamps.py; history in HISTORY.md section 3.1a): forward 124 us against
 // 7 x 23.6 = 165 us of single launches, input gradients 126 against 185 us.  A step is 930 cycles against 713 of MFMA issue.
 // LDS: activations 4 chunk-slabs x 120 rows x 128 B = 60 KB (row r, 16-byte slot s stored at slot s ^ (r & 7): a fragment
 // read at any tap offset stays conflict-free, as in the slab kernel of conv_nt_bf16.hip) + 3 x 32 KB weight slots.

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         // registers.  That same barrier publishes tile i+1, whose first-half fragments are then read from LDS while
         // the MFMAs of tile i's second half run; the second-half reads overlap the first-half MFMAs.  The LDS read
         // latency, which the plain loop exposes after every barrier (all waves read, then all waves multiply), is
-        // hidden behind MFMA work: measured step time on the 250-channel layers 0.61 us -> see DESIGN.md section 3.1.
+        // hidden behind MFMA work: measured step time on the 250-channel layers 0.61 us -> see HISTORY.md section 3.1.
 #pragma unroll
         for (int i = 0; i < STAGES; ++i)
             if (i < n) stage(s_begin + i, i);
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
 // step drop from (BM + BN) * 128 to BN * 128 + BM * 128 / taps (inner layers, taps = 7: 32 -> 18.3 KB; big_conv_1, taps =
 // 32, 256x256 tile: 64 -> 33 KB) and the activation re-reads that used to miss the L2 between taps (big_conv_1 dgrad:
 // ~2 GB per launch out of the Infinity Cache) disappear.  The XOR swizzle key is the SLAB row & 7, so a fragment read at
-// row offset `tap` stays bank-conflict free for every tap (checked exhaustively).
+// row offset `tap` stays bank-conflict free for every tap (checked exhaustively, HISTORY.md section 3.1).
 //   LDS: [slab 0][slab 1][weight ring: STAGES slots];   slab rows = BM + 32  (taps <= 33)
 //   vmcnt bookkeeping: the slab of chunk c+1 is issued in step (c, tap 0) BEFORE that step's weight tile, so it is older
 //   than every weight tile of chunk c+1 (needs taps >= STAGES) and only the steps with tap in [1, STAGES-2] see it among
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
 // share a SIMD (waves p and p + 4); wave p multiplies k-half 0 of every 64-deep step, wave p + 4 k-half 1, into private
 // accumulators that are added through LDS in the epilogue.  Same LDS bytes and MFMAs per step as four waves, but two
 // instruction streams per SIMD: a single wave issues in order, so every wait, request and address instruction it cannot
-// hide behind its own MFMAs is exposed (0.45 us per step against 0.244 us of MFMAs).
+// hide behind its own MFMAs is exposed (HISTORY.md section 3.1: 0.45 us per step against 0.244 us of MFMAs).
 // One phase and one barrier per step: [frags(i) in registers] wait for tile i+1, barrier, 16 MFMAs on tile i's
 // fragments with the 8 fragment reads of tile i+1 and the 4 requests of tile i+STAGES (into tile i's slot, which every
 // wave has finished reading before the barrier) interleaved.  Tap-major contraction, branch-free request stream.
@@ -1731,7 +1731,7 @@ Cfg decode_cfg(int cfg) {
 }
 
 Cfg auto_cfg(const sl_conv_geom* g) {
-    // Table measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01j_tune_kernels.json), see DESIGN.md section 3.1.
+    // Table measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01j_tune_kernels.json), see HISTORY.md section 3.1.
     const long nsteps = (long)g->taps * (g->cin / BK);
     if (g->cout % 256 == 0) {
         const long tiles256 = (long)g->batch * ((g->t_out + 255) / 256) * (g->cout / 256);

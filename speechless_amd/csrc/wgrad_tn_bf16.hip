@@ -955,7 +955,7 @@ int choose_splits(const sl_conv_geom* g, int tci, int tco, int target_wgs, int g
 }
 
 WCfg auto_wcfg(const sl_conv_geom* g, int groups) {
-    // measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01j_tune_kernels.json), see DESIGN.md section 3
+    // measured on MI355X with tools/tune_kernels.py (latest copy: profiles/r01j_tune_kernels.json), see HISTORY.md section 3
     if (g->cin % 256 == 0 && g->cout % 256 == 0) {
         const long tiles256 = (long)g->taps * (g->cin / 256) * (g->cout / 256) * groups;
         // 256x256 tile, 8 waves, interleaved stream: big_conv_1 0.329 ms = 1.55 PFLOP/s (16-wave kernel 0.374, 128x128

@@ -466,7 +466,7 @@ class Engine:
         # re-targeted in place (_Buffers.set_length), so one list serves every batch length of a buffer set.
         # runs of identical layers (inner_conv_1..7) as ONE launch with the activations kept in LDS (sl_conv1d_chain):
         # forward 124 us against 7 x 23.6 = 165 us of single launches, input gradients 126 against 185 (config 3;
-        # DESIGN.md section 3.1).  SL_CHAIN=0 restores the single launches (A/B measurements).
+        # HISTORY.md section 3.1).  SL_CHAIN=0 restores the single launches (A/B measurements).
         self.use_chain = os.environ.get("SL_CHAIN", "1") == "1"
         self.use_launch_lists = os.environ.get("SL_LAUNCH_LISTS", "1") != "0"
         if self.planes > 1:  # the fused launches read and write single-plane bf16 tensors

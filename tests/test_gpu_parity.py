@@ -755,7 +755,7 @@ def test_power_spectrogram_shape_with_ragged_lengths(dtype):
         # Back-propagated signal per layer and utterance.  A pre-activation within fp32 rounding of zero can take a
         # different sign in the fp32 forward than in the float64 oracle; that flips ONE ReLU-mask element (of ~3e5 per
         # utterance and layer) and moves that utterance's gradient by ~1/sqrt(n) = 2e-3 from there on (measured:
-        # DESIGN.md "ReLU mask flips").  Any two float32 implementations differ like this, so: most utterances must
+        # HISTORY.md section 1 "ReLU mask flips").  Any two float32 implementations differ like this, so: most utterances must
         # agree to 2e-4 at every layer, every one to 1e-2, and the weight gradients to 5e-3.
         for li in range(len(eng.plans)):
             s = eng.specs[li]
@@ -1048,7 +1048,7 @@ def test_dropout_training_step_matches_the_oracle_with_the_same_masks(dtype):
                                case["label_lengths"], input_scales=input_scales)
     assert np.allclose(loss, ref["losses"], rtol=2e-5)
     errs = [max(rel_l2(dw, rw), rel_l2(db, rb)) for (dw, db), (rw, rb) in zip(eng.get_gradients(), ref["grads"])]
-    # flip-aware (DESIGN.md "ReLU mask flips"): one pre-activation within fp32 rounding of zero that takes the other
+    # flip-aware (HISTORY.md section 1 "ReLU mask flips"): one pre-activation within fp32 rounding of zero that takes the other
     # branch than in float64 moves the gradients of all layers BELOW it by ~1/sqrt(elements) = 2e-3 here
     loose = [i for i, e in enumerate(errs) if e >= 2e-4]
     assert max(errs) < 1e-2 and loose == list(range(len(loose))) and errs[-1] < 2e-4, errs

@@ -154,7 +154,7 @@ def test_bf16_gradients_at_full_length_against_the_cpu_path():
     names = [s.name for s in case["specs"]]
     # Bounds = what was measured (profiles/r02k_parity.json, gpurun_out/parity.json) + 20 %, per tensor, so that a regression
     # of any single layer shows.  fp32 path: the floor of 2.5e-4 on EVERY tensor is the reference's, not the kernels' -- the
-    # torch-CPU CTC is an fp32 log-domain lattice (2.5e-4 at 500 frames), the HIP lattice runs in
+    # torch-CPU CTC is an fp32 log-domain lattice (2.5e-4 at 500 frames, HISTORY.md section 3.3), the HIP lattice runs in
     # doubles; on top of it the ReLU flips between two fp32 summation orders (see the config-5 test) in the lowest layers.
     f32_bounds = {"striding_conv": 4.7e-3, "inner_conv_1": 7.5e-4, "inner_conv_2": 5.4e-4, "inner_conv_3": 4.0e-4}
     for name, (ew, eb) in zip(names, errs["f32"]):
@@ -477,7 +477,7 @@ def test_dropout_training_step_with_recomputed_masks(activation):
     assert np.allclose(loss, ref["losses"], rtol=2e-5), (loss, ref["losses"])
     errs = [max(rel_l2(dw, rw), rel_l2(db, rb)) for (dw, db), (rw, rb) in zip(eng.get_gradients(), ref["grads"])]
     # fp32 against float64: a pre-activation within fp32 rounding of zero may take the other ReLU branch (one mask
-    # element of ~36 000 here = 5e-3 of the signal from that layer DOWN, DESIGN.md "ReLU mask flips"); so the layers
+    # element of ~36 000 here = 5e-3 of the signal from that layer DOWN, HISTORY.md section 1 "ReLU mask flips"); so the layers
     # above the first such flip agree to 2e-4 and the ones below it, a prefix of the stack, to 1e-2
     loose = [i for i, e in enumerate(errs) if e >= 2e-4]
     assert max(errs) < 1e-2 and loose == list(range(len(loose))) and errs[-1] < 2e-4, errs

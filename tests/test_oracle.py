@@ -233,7 +233,7 @@ def test_keras_adam_first_steps():
 
 
 def test_bf16_storage_noise_is_in_the_activations_not_in_g():
-    """Where the bf16 path's gradient error comes from (DESIGN.md "bf16 gradient noise"), on the float64 oracle run with
+    """Where the bf16 path's gradient error comes from (HISTORY.md section 1 "bf16 gradient noise"), on the float64 oracle run with
     the HIP path's rounding points: keeping the back-propagated signal g in fp32 instead of bf16 changes the per-layer
     weight-gradient error by less than a tenth of it -- the error is made in the forward pass (bf16 activations flip the
     sign of pre-activations within rounding of zero, one whole element of g per flip), it grows from 1e-3 at the output

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -o p -- python bench.py --no-cpu-baseline --no-also > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_prof.err
 cp gpurun_out/${TAG}_prof/*kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
-bash tools/pmc_traffic.sh > gpurun_out/${TAG}_pmc_traffic.log 2>&1
+TAG=$TAG bash tools/pmc_traffic.sh > gpurun_out/${TAG}_pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic_wgrad_ilv.json
 timeout 600 python bench.py --config 2 > gpurun_out/${TAG}_bench_config2.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --config 5 > gpurun_out/${TAG}_bench_config5.json 2>> gpurun_out/${TAG}_bench.err
