@@ -226,6 +226,13 @@ int sl_pack_weights(const float* w_master, void* w_fwd, void* w_dgrad, int k, in
  */
 int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,
                   int64_t dst_batch_stride, int dtype, void* stream);
+/* Raw-wave input (net.py:310-312: `wave_conv`, Conv1D(250, kernel 250, stride 160, padding="same") over the samples in front
+ * of striding_conv when use_raw_wave_input=True): the sample windows of the t_out = ceil(t_in / stride) output frames as rows of
+ * k * cin columns (zero padded to dst_row_stride), pad_left = TF's SAME rule for this t_in -- over which the layer is a 1 x 1
+ * GEMM for sl_conv1d_nt (forward, output straight into the pair-view input buffer of the stack) and sl_conv1d_wgrad.
+ *   audio: float[B][t_in][cin];   dst: [B][rows >= t_out][dst_row_stride] dtype at dst_batch_stride elements per utterance */
+int sl_wave_frames(const float* audio, void* dst, int batch, int t_in, int cin, int k, int stride, int pad_left, int t_out,
+                   int dst_row_stride, int64_t dst_batch_stride, int dtype, void* stream);
 /* The same with a ONES CHANNEL: padding channel `ones_channel` (f <= ones_channel < dst_row_stride) of every packed frame is set
  * to 1 (-1: none).  Its weight rows are and stay zero, so the forward pass does not see it; the first layer's weight-gradient
  * GEMM then leaves that layer's BIAS gradient in row ones_channel of dW (sl_bias_grad_from_wgrad) -- the bias gradient of

@@ -66,10 +66,17 @@ class LayerSpec:
 
 def layer_specs(input_size_per_time_step, grapheme_set_size, main_filter_count=250, out_filter_count=2000,
                 activation="relu", output_activation="softmax", inner_count=7,
-                striding_kernel=48, inner_kernel=7, big_kernel=32):
+                striding_kernel=48, inner_kernel=7, big_kernel=32, use_raw_wave_input=False, wave_kernel=250,
+                wave_stride=160):
     """The 11-layer spectrogram-input stack of net.py:307-330 (sizes parameterised so that tests can
-    build shrunken nets with the same structure)."""
-    specs = [LayerSpec("striding_conv", striding_kernel, 2, input_size_per_time_step, main_filter_count, activation)]
+    build shrunken nets with the same structure); use_raw_wave_input: `wave_conv` (250 taps, stride 160,
+    net.py:310-312) in front of it, striding_conv then reads its filters."""
+    specs = []
+    if use_raw_wave_input:
+        specs.append(LayerSpec("wave_conv", wave_kernel, wave_stride, input_size_per_time_step, main_filter_count,
+                               activation))
+        input_size_per_time_step = main_filter_count
+    specs.append(LayerSpec("striding_conv", striding_kernel, 2, input_size_per_time_step, main_filter_count, activation))
     for i in range(1, inner_count + 1):
         specs.append(LayerSpec("inner_conv_{}".format(i), inner_kernel, 1, main_filter_count, main_filter_count,
                                activation))

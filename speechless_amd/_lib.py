@@ -88,6 +88,7 @@ SIGNATURES = {
     "sl_scale": (c_int, [c_void_p, c_size_t, c_int, c_float, c_void_p]),
     "sl_elu_dropout_backward": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, ctypes.c_uint64, c_void_p]),
     "sl_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "sl_wave_frames": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "sl_pack_input_ones": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "sl_softmax_logq": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float,
                                 c_void_p]),

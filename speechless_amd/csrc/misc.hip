@@ -64,6 +64,27 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
             if (lane + 64 * k < f) dp[q][lane + 64 * k] = cvt_out<T>(v[q][k]);
 }
 
+// Raw-wave front layer (reference net.py:310-312: Conv1D(250 filters, 250 taps, stride 160, SAME) over the samples): the sample
+// windows of the output frames, one row of k * cin columns per frame, so that the layer is a 1 x 1 GEMM over them for the
+// ordinary kernels (forward: sl_conv1d_nt, weight gradient: sl_conv1d_wgrad).  3 GFLOP per 32 x 8 s of audio: the window matrix
+// (1.6 x the samples at stride 160 / 250 taps) is the cheap part of a layer that is nothing next to the stack behind it.
+//   dst[b][t][j * cin + c] = audio[b][t * stride + j - pad_left][c]  (0 outside [0, t_in)),  columns >= k * cin: 0
+template <typename T>
+__global__ __launch_bounds__(256) void wave_frames_kernel(const float* __restrict__ audio, T* __restrict__ dst, int t_in, int cin,
+                                                          int k, int stride, int pad_left, int t_out, int dst_rs, long dst_bs) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)t_out * dst_rs) return;
+    const int t = (int)(i / dst_rs), col = (int)(i - (long)t * dst_rs);
+    float v = 0.f;
+    if (col < k * cin) {
+        const int j = col / cin, c = col - j * cin;
+        const long s = (long)t * stride + j - pad_left;
+        if (s >= 0 && s < t_in) v = audio[((long)b * t_in + s) * cin + c];
+    }
+    dst[(long)b * dst_bs + i] = cvt_out<T>(v);
+}
+
 // stage 1: partial[b][co] = sum_t g[b][row0+t][co]; block = 256 threads = 16 column-groups(8 ch) x 16 row lanes
 template <typename T>
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const T* __restrict__ g, float* __restrict__ partial,
@@ -415,6 +436,24 @@ extern "C" int sl_pack_weights(const float* w_master, void* w_fwd, void* w_dgrad
         hipLaunchKernelGGL((pack_weights_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, w_master,
                            (float*)w_fwd, (float*)w_dgrad, k, cin_pad, cout_pad);
     return sl_check_launch("sl_pack_weights");
+}
+
+extern "C" int sl_wave_frames(const float* audio, void* dst, int batch, int t_in, int cin, int k, int stride, int pad_left,
+                              int t_out, int dst_row_stride, int64_t dst_batch_stride, int dtype, void* stream) {
+    SL_CHECK_ARG(audio && dst && batch > 0 && t_in > 0 && cin > 0 && k > 0 && stride > 0 && pad_left >= 0 && t_out > 0,
+                 "sl_wave_frames: bad sizes");
+    SL_CHECK_ARG(dst_row_stride >= k * cin && dst_batch_stride >= (int64_t)t_out * dst_row_stride,
+                 "sl_wave_frames: a row holds k * cin = %d columns", k * cin);
+    SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32, "sl_wave_frames: unknown dtype %d", dtype);
+    const long n = (long)t_out * dst_row_stride;
+    const dim3 grid((unsigned)((n + 255) / 256), batch);
+    if (dtype == SL_BF16)
+        hipLaunchKernelGGL((wave_frames_kernel<unsigned short>), grid, dim3(256), 0, (hipStream_t)stream, audio,
+                           (unsigned short*)dst, t_in, cin, k, stride, pad_left, t_out, dst_row_stride, (long)dst_batch_stride);
+    else
+        hipLaunchKernelGGL((wave_frames_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, audio, (float*)dst, t_in, cin,
+                           k, stride, pad_left, t_out, dst_row_stride, (long)dst_batch_stride);
+    return sl_check_launch("sl_wave_frames");
 }
 
 extern "C" int sl_pack_input(const float* src, void* dst, int batch, int t_in, int f, int dst_row0, int dst_row_stride,

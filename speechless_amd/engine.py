@@ -40,10 +40,16 @@ class LayerSpec:
 
 def wav2letter_layer_specs(input_size_per_time_step, grapheme_set_size, activation="relu",
                            output_activation="softmax", main_filter_count=250, out_filter_count=2000, inner_count=7,
-                           striding_kernel=48, inner_kernel=7, big_kernel=32):
-    """Topology of reference net.py:307-330 (spectrogram input).  Sizes are parameters only so that tests can build
-    shrunken stacks of the same structure."""
-    specs = [LayerSpec("striding_conv", striding_kernel, 2, input_size_per_time_step, main_filter_count, activation)]
+                           striding_kernel=48, inner_kernel=7, big_kernel=32, use_raw_wave_input=False, wave_kernel=250,
+                           wave_stride=160):
+    """Topology of reference net.py:307-330; use_raw_wave_input: `wave_conv` (250 taps at stride 160 over the samples,
+    net.py:310-312) in front of striding_conv, which then reads its filters instead of spectrogram bins.  Sizes are
+    parameters only so that tests can build shrunken stacks of the same structure."""
+    specs = []
+    if use_raw_wave_input:
+        specs.append(LayerSpec("wave_conv", wave_kernel, wave_stride, input_size_per_time_step, main_filter_count, activation))
+        input_size_per_time_step = main_filter_count
+    specs.append(LayerSpec("striding_conv", striding_kernel, 2, input_size_per_time_step, main_filter_count, activation))
     for i in range(1, inner_count + 1):
         specs.append(LayerSpec("inner_conv_{}".format(i), inner_kernel, 1, main_filter_count, main_filter_count,
                                activation))
@@ -160,6 +166,17 @@ class _Buffers:
         self.stage32 = torch.empty((batch * self.tt_pad * max(p.cout_pad for p in eng.plans),), dtype=torch.float32,
                                    device=dev) if pl > 1 else None
         self.plane_geoms = {}  # bf16x3: (kind, layer) -> geometry whose output side describes a plane tensor
+        # front layer (raw-wave input): gathered sample windows [B][2 tt_pad][K_pad], the gradient w.r.t. the stack's input in
+        # the pair-view layout of x0, and the three geometries of the launches around them (Engine._front_*)
+        self.frames = self.gx0 = self.front_geom = self.front_dgrad_geom = None
+        if eng.front_plan is not None:
+            fp = eng.front_plan
+            self.frames = torch.zeros((batch, 2 * tt_pad, fp.cin_pad), dtype=dt, device=dev)
+            g = ConvGeom()
+            g.batch, g.t_out, g.taps, g.cin, g.cout = batch, 2 * tt_pad, 1, fp.cin_pad, fp.cout_pad
+            g.x_row0, g.x_row_stride, g.x_batch_stride = 0, fp.cin_pad, 2 * tt_pad * fp.cin_pad
+            g.y_row0, g.y_row_stride, g.y_batch_stride = p0.pad_left, p0.cin_pad, self.rows0 * p0.cin_pad
+            self.front_geom = g  # forward (x = frames, y = x0) and weight gradient (x = frames, "y" = gx0): t_out = input frames
         self.half_geoms = {}   # split top (Engine.split_top): (kind, layer) -> the layer's geometry for half the batch
         self.ctc_done = [None, None]  # split top: events behind the CTC launches of the two half-batches
         self.ctc_half_bytes = 0
@@ -189,6 +206,8 @@ class _Buffers:
         # beyond the valid time, so they are cleared here (nothing to do while the lengths grow)
         if t_in < self._clean_in:
             self.x0[:, p0.pad_left + t_in: p0.pad_left + self._clean_in].zero_()
+            if self.gx0 is not None:
+                self.gx0[:, p0.pad_left + t_in: p0.pad_left + self._clean_in].zero_()
         if t_out < self._clean_out:
             for block in self._blocks:
                 block[:, :, HALO + t_out: HALO + self._clean_out].zero_()
@@ -213,6 +232,10 @@ class _Buffers:
             g.t_out = t_out
         for g in self.half_geoms.values():
             g.t_out = t_out
+        if self.front_geom is not None:
+            self.front_geom.t_out = t_in
+        if self.front_dgrad_geom is not None:
+            self.front_dgrad_geom.t_out = t_out + eng.FRONT_DGRAD_EXTRA_ROWS
         if t_out not in self._ws_sized_fwd:  # split counts (hence workspace sizes) depend on the number of time tiles
             self._ws_sized_fwd.add(t_out)
             self.size_nt_workspace(eng, self.fwd_geom, "fwd")
@@ -248,7 +271,12 @@ class _Buffers:
                     self.g[lo + q] = block[q]
         for p in eng.plans[first:]:
             if self.g[p.index] is None:
-                self.g[p.index] = torch.zeros((self.batch, self.rows, p.cout_pad * eng.planes), dtype=dt, device=dev)
+                # (layer 0 under a front layer: its input-gradient launch reads up to a time tile past the last utterance's
+                # rows -- one utterance of zero slack behind the batch)
+                slack = 1 if (p.index == 0 and eng.front_plan is not None) else 0
+                full = torch.zeros((self.batch + slack, self.rows, p.cout_pad * eng.planes), dtype=dt, device=dev)
+                self.g[p.index] = full[:self.batch]
+                self._g0_keepalive = full
                 self._blocks.append(self.g[p.index].unsqueeze(0))
             pl = eng.planes
             wg = ConvGeom()
@@ -288,6 +316,18 @@ class _Buffers:
                     dg.y_row_stride = p.cin_pad
                     dg.y_batch_stride = self.rows * p.cin_pad
                 self.dgrad_geom[p.index] = dg
+        if eng.front_plan is not None and first == 0 and not eng.front_frozen:
+            # dL/d(x0) in x0's own pair-view layout: pair row r = sum over the 24 pair taps j of g0[r - j] . Wpair[j]^T, as an
+            # NT launch over g0 with flipped taps.  Frames start at pair row 11, so rows from 7 on are computed: the launch
+            # then reads g0 from its first halo row (16 - 23 + 7 = 0) and never in front of the buffer.
+            p0 = eng.plans[0]
+            self.gx0 = torch.zeros_like(self.x0)
+            dg = ConvGeom()
+            dg.batch, dg.t_out, dg.taps = self.batch, (self.t_out or 0) + eng.FRONT_DGRAD_EXTRA_ROWS, p0.taps_view
+            dg.cin, dg.cout = p0.cout_pad, p0.cin_view
+            dg.x_row0, dg.x_row_stride, dg.x_batch_stride = 0, p0.cout_pad, self.rows * p0.cout_pad
+            dg.y_row0, dg.y_row_stride, dg.y_batch_stride = eng.FRONT_DGRAD_ROW0, p0.cin_view, self.rows0 * p0.cin_pad
+            self.front_dgrad_geom = dg
         self.bias_ws = None
         self.bwd1x1_ws = None
         self.ctc_ws = None
@@ -311,6 +351,15 @@ class _Buffers:
                 bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
         L.call("sl_set_available_cus", 0)
         self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
+        if eng.front_plan is not None:
+            for g in (self.front_geom, self.front_dgrad_geom):
+                if g is not None:
+                    need = L.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(g), eng.dtype_code, 0)
+                    if self.nt_ws.numel() < need:
+                        self.nt_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
+                        self.launch_lists = {}
+            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(ctypes.byref(self.front_geom), eng.dtype_code, 0))
+            bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(self.front_geom)))
         if eng.planes > 1:
             need = max(p.taps_view * (self.wgrad_geom[p.index].cin + self.wgrad_geom_b[p.index].cin) * p.cout_pad
                        for p in eng.plans[first:])
@@ -360,6 +409,9 @@ class Engine:
     benchmarked path), 'f32' (parity path: fp32 storage, exact-fp32 MFMA) or 'bf16x3' (the fast parity path: every value as
     hi + lo bf16 planes, three bf16 MFMA terms per product, fp32 accumulate; csrc/split3.hip)."""
 
+    FRONT_DGRAD_ROW0 = 7          # first pair row of x0's gradient that is computed (frames start at pair row 11)
+    FRONT_DGRAD_EXTRA_ROWS = 17   # pair rows computed beyond the output frames: up to row T' + 23 = the last frame's
+
     def __init__(self, specs, grapheme_set_size, dtype="bf16", device="cuda:0", ctc_epsilon=1e-8,
                  frozen_layer_count=0, lr=1e-4, beta_1=0.9, beta_2=0.999, adam_epsilon=1e-8):
         if not torch.cuda.is_available():
@@ -377,7 +429,25 @@ class Engine:
             self.torch_dtype, self.dtype_code, self.planes = torch.bfloat16, _lib.SL_BF16, 3
         else:
             raise ValueError("dtype must be 'bf16', 'f32' or 'bf16x3'")
+        # Raw-wave input (reference net.py:310-312: `wave_conv`, 250 taps at stride 160 over the samples, in front of
+        # striding_conv): the FRONT layer.  It is a GEMM over gathered sample windows (sl_wave_frames: K = 250 * Cin
+        # columns per output frame, 3 GFLOP per 32 x 8 s -- nothing next to the stack) whose output lands directly in the
+        # pair-view input buffer of the stack below; the eleven layers behind it, their plans, indices and launches are
+        # untouched.  Internally the front plan has index len(plans) (its parameters sit at the END of the flat buffers);
+        # the public order of set_weights / get_weights / get_gradients puts it first, as the reference's layer list does.
+        self.front_spec = None
+        self.front_frozen = False
+        if specs and specs[0].stride > 2:
+            if dtype == "bf16x3":
+                raise NotImplementedError("raw-wave input is implemented on the bf16 and f32 paths")
+            self.front_spec = specs[0]
+            specs = list(specs[1:])
+            self.front_frozen = frozen_layer_count >= 1
+            frozen_layer_count = max(frozen_layer_count - 1, 0)
+            if self.front_spec.activation not in ("relu", "elu"):
+                raise NotImplementedError("the raw-wave layer takes a relu / elu activation")
         self.specs = specs
+        self.all_specs = ([self.front_spec] if self.front_spec is not None else []) + list(specs)
         self.grapheme_set_size = grapheme_set_size
         self.ctc_epsilon = ctc_epsilon
         self.frozen_layer_count = frozen_layer_count
@@ -405,6 +475,18 @@ class Engine:
             off += cout_pad
             self.plans.append(LayerPlan(i, s, cin_pad, cout_pad, w_off, b_off))
             cin_pad = cout_pad
+        self.front_plan = None
+        if self.front_spec is not None:
+            fs = self.front_spec
+            p0 = self.plans[0]
+            if fs.cout != specs[0].cin or p0.cin_pad % 128:
+                raise NotImplementedError("the raw-wave layer's filters must be the next layer's inputs, padded to a multiple "
+                                          "of 128 (250 -> 256)")
+            k_real = fs.kernel_size * fs.cin
+            gemm = LayerSpec(fs.name, 1, 1, k_real, fs.cout, fs.activation)  # the layer as the 1 x 1 GEMM it is launched as
+            self.front_plan = LayerPlan(len(self.plans), gemm, _round_up(k_real, 128), p0.cin_pad, off, off + _round_up(k_real, 128) * p0.cin_pad)
+            off = self.front_plan.b_off + p0.cin_pad
+        self.all_plans = self.plans + ([self.front_plan] if self.front_plan is not None else [])
         self.param_numel = off
         # runs of >= 2 consecutive stride-1 layers with identical padded geometry (net.py:321-323: inner_conv_1..7)
         self.runs = []
@@ -426,9 +508,11 @@ class Engine:
         self.adam_v = torch.zeros((off,), dtype=torch.float32, device=dev)
         pl = self.planes  # bf16x3: packed weight rows are [w_hi | w_hi | w_lo]
         self.w_fwd = [torch.zeros((p.cout_pad, p.spec.kernel_size, p.cin_pad * pl), dtype=self.torch_dtype, device=dev)
-                      for p in self.plans]
+                      for p in self.all_plans]
+        # (with a front layer the first layer of the stack needs its input gradient too: its dgrad operand in the pair view)
         self.w_dgrad = [torch.zeros((p.cin_pad, p.spec.kernel_size, p.cout_pad * pl), dtype=self.torch_dtype, device=dev)
-                        if p.index > 0 else None for p in self.plans]
+                        if (0 < p.index < len(self.plans) or (p.index == 0 and self.front_plan is not None)) else None
+                        for p in self.all_plans]
         self._packed_dirty = True
         self._buffers = {}
         self.max_cached_shapes = 4  # (batch, frames rounded up to 512) geometries kept allocated
@@ -643,6 +727,9 @@ class Engine:
             if layers:
                 hi_layer = self.plans[layers[-1]]
                 plan.append((layers, (self.plans[layers[0]].w_off, hi_layer.b_off + hi_layer.cout_pad)))
+        if self.front_plan is not None and not self.front_frozen and first == 0:
+            fp = self.front_plan  # (raw-wave front layer: its gradients are the last launches of backward)
+            plan.append(([fp.index], (fp.w_off, fp.b_off + fp.cout_pad)))
         return plan
 
     def bucket_ranges(self):
@@ -652,10 +739,11 @@ class Engine:
     # ------------------------------------------------------------------ weights
     def set_weights(self, weights):
         """weights: [(W (k,Cin,Cout), b (Cout,))] numpy, Keras layout."""
-        assert len(weights) == len(self.plans)
+        assert len(weights) == len(self.all_plans)
         self.params.zero_()
-        for p, (w, b) in zip(self.plans, weights):
+        for p, (w, b) in zip(self._public_plans(), weights):
             s = p.spec
+            w = self._front_to_gemm(p, w)
             if tuple(w.shape) != (s.kernel_size, s.cin, s.cout) or tuple(b.shape) != (s.cout,):
                 raise ValueError("weights of layer {} have shape {} / {}".format(s.name, w.shape, b.shape))
             wv, bv = self.layer_param_views(self.params, p)
@@ -665,13 +753,32 @@ class Engine:
                 bv[p.cout_pad - 1] = 1.0  # relu(0 * x + 1) = elu(1) = 1: the ones channel (see self.ones_channel)
         self._packed_dirty = True
 
+    def _public_plans(self):
+        """the plans in the public layer order (the reference's layer list): the front layer first"""
+        return ([self.front_plan] if self.front_plan is not None else []) + self.plans
+
+    def _front_to_gemm(self, plan, w):
+        """the front layer's Keras kernel (k, Cin, Cout) as the (1, k * Cin, Cout) matrix it is stored and launched as"""
+        if plan is self.front_plan and np.ndim(w) == 3 and w.shape[0] == self.front_spec.kernel_size:
+            return np.reshape(w, (1, w.shape[0] * w.shape[1], w.shape[2]))
+        return w
+
+    def _front_from_gemm(self, plan, w):
+        if plan is self.front_plan:
+            fs = self.front_spec
+            return np.reshape(w, (fs.kernel_size, fs.cin, fs.cout))
+        return w
+
     def _has_ones_output(self, plan):
         """hidden layer whose output has channel padding: its last padded channel is the constant 1"""
-        return self.ones_channel and plan.index < len(self.plans) - 1 and plan.cout_pad > plan.spec.cout
+        hidden = plan is self.front_plan or plan.index < len(self.plans) - 1
+        return self.ones_channel and hidden and plan.cout_pad > plan.spec.cout
 
     def _has_ones_input(self):
         """the packed INPUT carries a ones channel (sl_pack_input_ones) where its bins leave a padding channel free: 257 bins in
         rows of 320 (configuration 5) -- not 128 mel bins, which fill their rows.  Single-plane paths only."""
+        if self.front_plan is not None:  # the front layer's last padded filter is the constant 1 (its bias; _has_ones_output)
+            return self._has_ones_output(self.front_plan)
         return self.ones_channel and self.planes == 1 and self.plans[0].cin_pad > self.specs[0].cin
 
     def _ones_input_layers(self, first):
@@ -698,10 +805,11 @@ class Engine:
 
     def _unpad(self, tensor):
         out = []
-        for p in self.plans:
+        for p in self._public_plans():
             s = p.spec
             wv, bv = self.layer_param_views(tensor, p)
-            out.append((wv[:, :s.cin, :s.cout].contiguous().cpu().numpy(), bv[:s.cout].contiguous().cpu().numpy()))
+            out.append((self._front_from_gemm(p, wv[:, :s.cin, :s.cout].contiguous().cpu().numpy()),
+                        bv[:s.cout].contiguous().cpu().numpy()))
         return out
 
     def get_weights(self):
@@ -730,8 +838,9 @@ class Engine:
     def set_optimizer_state(self, state):
         for name, flat in (("m", self.adam_m), ("v", self.adam_v)):
             flat.zero_()
-            for p, (w, b) in zip(self.plans, state[name]):
+            for p, (w, b) in zip(self._public_plans(), state[name]):
                 s = p.spec
+                w = self._front_to_gemm(p, w)
                 if tuple(w.shape) != (s.kernel_size, s.cin, s.cout) or tuple(b.shape) != (s.cout,):
                     raise ValueError("optimizer state of layer {} has shape {} / {}".format(s.name, w.shape, b.shape))
                 wv, bv = self.layer_param_views(flat, p)
@@ -756,13 +865,21 @@ class Engine:
         if self.planes > 1:
             return self._repack_weights_x3()
         st = self._stream()
-        for p in self.plans:
+        for p in self.all_plans:
             wv, _ = self.layer_param_views(self.params, p)
             wd = self.w_dgrad[p.index]
+            k, cin = self._pack_dims(p)
             self._launch("pack:" + p.spec.name, "sl_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
-                          wd.data_ptr() if wd is not None else None, p.spec.kernel_size, p.cin_pad, p.cout_pad,
-                          self.dtype_code, st)
+                          wd.data_ptr() if wd is not None else None, k, cin, p.cout_pad, self.dtype_code, st)
         self._packed_dirty = False
+
+    def _pack_dims(self, p):
+        """(taps, input channels) the operand copies of plan p are packed with: the PAIR VIEW for a strided first layer that
+        has a dgrad operand (same bytes for the forward operand; the flipped taps of the input-gradient operand are the
+        pair view's 24, not the layer's 48)"""
+        if p.index == 0 and p.spec.stride == 2 and self.w_dgrad[0] is not None:
+            return p.taps_view, p.cin_view
+        return p.spec.kernel_size, p.cin_pad
 
     # ------------------------------------------------------------------ forward
     def load_input(self, input_batch):
@@ -774,6 +891,8 @@ class Engine:
         else:
             src = input_batch.to(device=self.device, dtype=torch.float32).contiguous()
         batch, t_in, f = src.shape
+        if self.front_plan is not None:
+            return self._load_front_input(src)
         if f != self.specs[0].cin:
             raise ValueError("input has {} bins per frame, the net expects {}".format(f, self.specs[0].cin))
         buf = self.buffers(batch, t_in)
@@ -790,6 +909,72 @@ class Engine:
         self.cur = buf
         self._src_keepalive = src
         return buf
+
+    # ------------------------------------------------------------------ front layer (raw-wave input, see __init__)
+    def _load_front_input(self, src):
+        """src: float32 (B, T, Cin) samples in HBM.  Gathers the sample windows of the ceil(T / stride) output frames (the
+        weight-independent half of the front layer; its GEMM is part of forward())."""
+        fs = self.front_spec
+        batch, t_audio, f = src.shape
+        if f != fs.cin:
+            raise ValueError("input has {} values per sample, the net expects {}".format(f, fs.cin))
+        t1, pad_l, _ = same_padding(t_audio, fs.kernel_size, fs.stride)
+        buf = self.buffers(batch, t1)
+        buf.front_src, buf.front_geometry = src, (t_audio, t1, pad_l)
+        self._front_gather(buf, src)
+        self.cur = buf
+        self._src_keepalive = src
+        return buf
+
+    def _front_gather(self, buf, src):
+        fs, fp = self.front_spec, self.front_plan
+        t_audio, t1, pad_l = buf.front_geometry
+        self._launch("wave_frames", "sl_wave_frames", src.data_ptr(), buf.frames.data_ptr(), buf.batch, t_audio, fs.cin,
+                     fs.kernel_size, fs.stride, pad_l, t1, fp.cin_pad, buf.frames.stride(0), self.dtype_code, self._stream())
+        buf.front_frames_dropped = False
+
+    def _front_forward(self, buf, rate, seed0, st):
+        """wave_conv: bias + activation epilogue of a 1 x 1 NT launch over the gathered windows, written into x0 where
+        sl_pack_input would have put a spectrogram.  With dropout (a Dropout sits in front of wave_conv too, net.py:301-303)
+        the samples are dropped first (seed offset 63: the stack's layers use 0 .. n) and the windows gathered again."""
+        fp = self.front_plan
+        if rate:
+            if getattr(buf, "front_src_dropped", None) is None or buf.front_src_dropped.shape != buf.front_src.shape:
+                buf.front_src_dropped = torch.empty_like(buf.front_src)
+            self._launch("dropout:samples", "sl_dropout", buf.front_src.data_ptr(), buf.front_src_dropped.data_ptr(),
+                         buf.front_src.numel(), _lib.SL_F32, rate, seed0 + 63, st)
+            self._front_gather(buf, buf.front_src_dropped)
+            buf.front_frames_dropped = True
+        elif buf.front_frames_dropped:
+            self._front_gather(buf, buf.front_src)
+        _, bias = self.layer_param_views(self.params, fp)
+        self._launch("fwd:" + fp.spec.name, "sl_conv1d_nt", buf.frames.data_ptr(), self.w_fwd[fp.index].data_ptr(),
+                     bias.data_ptr(), None, buf.x0.data_ptr(), ctypes.byref(buf.front_geom),
+                     _lib.EPI_BIAS_ELU if fp.spec.activation == "elu" else _lib.EPI_BIAS_RELU, self.dtype_code, 0, 0,
+                     buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+
+    def _front_backward(self, buf, st):
+        """behind the stack's backward: x0's gradient (pair-view NT launch over g[0] with the flipped pair taps, masked by
+        wave_conv's stored activation), then wave_conv's weight and bias gradient from the gathered windows"""
+        fp, p0 = self.front_plan, self.plans[0]
+        x0 = buf.x0_dropped if buf.dropped else buf.x0
+        elu = fp.spec.activation == "elu"
+        elu_dropped = elu and buf.dropped
+        self._launch("dgrad:" + p0.spec.name, "sl_conv1d_nt", buf.g[0].data_ptr(), self.w_dgrad[0].data_ptr(), None,
+                     None if elu_dropped else x0.data_ptr(), buf.gx0.data_ptr(), ctypes.byref(buf.front_dgrad_geom),
+                     _lib.EPI_NONE if elu_dropped else (_lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK), self.dtype_code, 0,
+                     0, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+        if elu_dropped:
+            self._launch("dropout_elu_bwd:" + p0.spec.name, "sl_elu_dropout_backward", buf.gx0.data_ptr(), x0.data_ptr(),
+                         buf.gx0.numel(), self.dtype_code, self.dropout_rate, buf.dropout_seed0, st)
+        elif buf.dropped:
+            self._launch("dropout_scale:" + p0.spec.name, "sl_scale", buf.gx0.data_ptr(), buf.gx0.numel(), self.dtype_code,
+                         1.0 / (1.0 - self.dropout_rate), st)
+        dw, db = self.layer_param_views(self.grads, fp)
+        self._launch("wgrad:" + fp.spec.name, "sl_conv1d_wgrad", buf.frames.data_ptr(), buf.gx0.data_ptr(), dw.data_ptr(),
+                     ctypes.byref(buf.front_geom), self.dtype_code, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+        self._launch("bgrad:" + fp.spec.name, "sl_bias_grad", buf.gx0.data_ptr(), db.data_ptr(), ctypes.byref(buf.front_geom),
+                     self.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
 
     def _chain_table(self, kind, layers, buf):
         """ctypes pointer tables of sl_conv1d_chain for the given layers (plan indices in launch order), cached on the
@@ -841,6 +1026,8 @@ class Engine:
         rate = self.dropout_rate if training else None
         buf.dropped = bool(rate)
         buf.split_pending = 0
+        if self.front_plan is not None and not rate and getattr(buf, "front_frames_dropped", False):
+            self._front_gather(buf, buf.front_src)  # (the last step gathered DROPPED samples; not part of any launch list)
         fuse_out = self.fuse_output_softmax and self.dtype == "bf16" and bool(self.lib.raw("sl_output_softmax_supported")(
             ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size, self.dtype_code))
         # launch list (no dropout): everything below takes its frame count from the geometries, except the unfused
@@ -1100,10 +1287,14 @@ class Engine:
             return self._forward_x3(buf, st, rate)
         n = len(self.plans)
         x = buf.x0
+        seed0 = 0
         if rate:
             self._dropout_steps += 1
             seed0 = (self.dropout_seed * 1000003 + self._dropout_steps) * 64
             buf.dropout_seed0 = seed0  # ELU layers: backward recomputes the keep decisions (sl_elu_dropout_backward)
+        if self.front_plan is not None:
+            self._front_forward(buf, rate, seed0, st)
+        if rate:
             if buf.x0_dropped is None:
                 buf.x0_dropped = torch.zeros_like(buf.x0)
             self._launch("dropout:input", "sl_dropout", buf.x0.data_ptr(), buf.x0_dropped.data_ptr(), buf.x0.numel(),
@@ -1636,6 +1827,13 @@ class Engine:
             if ones_in:
                 self._bias_grads_from_wgrad(ones_in, bool(ones_db), main)
             join_side()
+        if self.front_plan is not None and first == 0 and not self.front_frozen:
+            self._front_backward(buf, main.cuda_stream)
+            if on_bucket_ready is not None:  # the front layer's parameters: the last bucket of bucket_plan()
+                b = len(self.bucket_plan()) - 1
+                on_bucket_ready(b)
+                if self._rec is not None:
+                    self._rec.append((2, b))
         if hint:
             self._launch("cu_hint", "sl_set_available_cus", 0)
 
@@ -1653,19 +1851,27 @@ class Engine:
             return
         if self._packed_dirty:
             self.repack_weights()  # frozen layers keep these copies; trainable ones are rewritten below
-        self._adam_layers(range(self.frozen_layer_count, len(self.plans)), st)
+        self._adam_layers(self._trainable_layers(), st)
+
+    def _trainable_layers(self):
+        """internal indices of the layers the optimizer updates (the front layer, if any, has index len(plans))"""
+        layers = list(range(self.frozen_layer_count, len(self.plans)))
+        if self.front_plan is not None and not self.front_frozen:
+            layers.append(self.front_plan.index)
+        return layers
 
     def _adam_table(self, chunk):
         table = self._adam_tables.get(tuple(chunk))
         if table is None:  # (the operand copies never move: built once per set of layers)
             table = (_lib.AdamLayer * len(chunk))()
             for entry, i in zip(table, chunk):
-                p = self.plans[i]
+                p = self.all_plans[i]
                 wd = self.w_dgrad[p.index]
                 entry.offset = p.w_off
                 entry.w_fwd = self.w_fwd[p.index].data_ptr()
                 entry.w_dgrad = wd.data_ptr() if wd is not None else None
-                entry.k, entry.cin_pad, entry.cout_pad = p.spec.kernel_size, p.cin_pad, p.cout_pad
+                entry.k, entry.cin_pad = self._pack_dims(p)
+                entry.cout_pad = p.cout_pad
             self._adam_tables[tuple(chunk)] = table
         return table
 
@@ -1676,7 +1882,7 @@ class Engine:
         for lo in range(0, len(layers), 16):
             chunk = layers[lo:lo + 16]
             table = self._adam_table(chunk)
-            tag = "adam:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name)
+            tag = "adam:{}..{}".format(self.all_plans[chunk[0]].spec.name, self.all_plans[chunk[-1]].spec.name)
             if self.planes == 3:  # bf16x3: the [w_hi | w_hi | w_lo] operand rows are rewritten in the same pass
                 self._launch(tag, "sl_split3_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(),
                              self.adam_m.data_ptr(), self.adam_v.data_ptr(), table, len(chunk), self.adam_iterations,
@@ -1752,6 +1958,6 @@ class Engine:
         layers = list(layers)
         for lo in range(0, len(layers), 16):
             chunk = layers[lo:lo + 16]
-            self._launch("pack:{}..{}".format(self.plans[chunk[0]].spec.name, self.plans[chunk[-1]].spec.name),
+            self._launch("pack:{}..{}".format(self.all_plans[chunk[0]].spec.name, self.all_plans[chunk[-1]].spec.name),
                          "sl_pack_layers", self.params.data_ptr(), self._adam_table(chunk), len(chunk), self.dtype_code,
                          st)

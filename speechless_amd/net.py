@@ -169,7 +169,7 @@ class PredictiveNet:
 
     def __init__(self, engine):
         self._engine = engine
-        self.layers = [_ConvLayerHandle(self, i, s.name) for i, s in enumerate(engine.specs)]
+        self.layers = [_ConvLayerHandle(self, i, s.name) for i, s in enumerate(engine.all_specs)]
 
     def get_weights(self):
         return self._engine.get_weights()
@@ -250,8 +250,6 @@ class Wav2Letter:
             raise ValueError("Layers cannot be frozen if model is trained from scratch.")
         if use_asg:
             raise NotImplementedError("ASG is not yet implemented.")  # as reference net.py:396-399
-        if use_raw_wave_input:
-            raise NotImplementedError("raw-wave input (wave_conv, net.py:310-312) is outside the MI355X hot path")
         if dropout is not None and not 0.0 <= dropout < 1.0:
             raise ValueError("dropout must be a rate in [0, 1)")
         self.kenlm_directory = kenlm_directory
@@ -271,7 +269,7 @@ class Wav2Letter:
         self._layer_sizes = dict(layer_sizes or {})
         specs = wav2letter_layer_specs(input_size_per_time_step, self.grapheme_encoding.grapheme_set_size,
                                        activation=activation, output_activation=output_activation,
-                                       **self._layer_sizes)
+                                       use_raw_wave_input=use_raw_wave_input, **self._layer_sizes)
         self.engine = Engine(specs, self.grapheme_encoding.grapheme_set_size, dtype=compute_dtype, device=device,
                              ctc_epsilon=ctc_epsilon, frozen_layer_count=frozen_layer_count, lr=self.optimizer.lr,
                              beta_1=self.optimizer.beta_1, beta_2=self.optimizer.beta_2,
@@ -401,7 +399,7 @@ class Wav2Letter:
     @property
     def input_to_prediction_length_ratio(self):
         ratio = 1
-        for s in self.engine.specs:
+        for s in self.engine.all_specs:
             ratio *= s.stride
         return ratio
 

@@ -475,3 +475,140 @@ def test_split_top_with_uneven_parts_against_the_whole_batch_step():
     assert float(torch.linalg.norm(results[0][1] - g_whole) / torch.linalg.norm(g_whole)) < 5e-3
     for loss, grads in results[1:]:
         assert np.array_equal(loss, results[0][0]) and torch.equal(grads, results[0][1])
+
+
+# ------------------------------------------------------------------------------------------ raw-wave input (wave_conv)
+def _wave_case(b=3, t_audio=24055, seed=6, cin=1, activation="relu"):
+    from speechless_amd.engine import wav2letter_layer_specs
+    sizes = dict(out_filter_count=256)
+    specs = wav2letter_layer_specs(cin, 29, activation=activation, use_raw_wave_input=True, **sizes)
+    ospecs = o.layer_specs(cin, 29, activation=activation, use_raw_wave_input=True, **sizes)
+    weights = o.glorot_uniform_weights(ospecs, seed=seed, dtype=np.float32)
+    rng = np.random.RandomState(seed)
+    weights = [(w, rng.uniform(-0.05, 0.05, size=bb.shape).astype(np.float32)) for (w, bb) in weights]
+    x = rng.randn(b, t_audio, cin).astype(np.float32)
+    t_out = -(-(-(-t_audio // 160)) // 2)
+    lab_len = [int(rng.randint(1, max(2, t_out // 3))) for _ in range(b)]
+    labels = o.pack_label_batch([list(rng.randint(0, 28, size=n)) for n in lab_len])
+    pred_len = [t_audio // 320 - (i % 2) for i in range(b)]
+    return dict(specs=specs, ospecs=ospecs, weights=weights, x=x, labels=labels, label_lengths=lab_len,
+                prediction_lengths=pred_len, k=29)
+
+
+@pytest.mark.parametrize("dtype,cin", [("f32", 1), ("bf16", 1), ("f32", 2)])
+def test_raw_wave_input_against_the_float64_oracle(dtype, cin):
+    """use_raw_wave_input=True (reference net.py:310-312): `wave_conv` -- 250 filters, 250 taps, stride 160, SAME padding, over
+    the samples -- in front of striding_conv, 12 layers, input-to-prediction ratio 320.  The front layer runs as a GEMM over
+    gathered sample windows (sl_wave_frames) whose output lands in the pair-view input buffer of the stack; the stack's first
+    layer gets an input gradient (pair-view NT launch with flipped taps).  Loss, every gradient (the front layer's included)
+    and the greedy decode against the float64 oracle, on two batches of different lengths through the same buffers (the
+    second shorter: stale rows of the first must not leak into it); sample counts that are not multiples of the stride."""
+    import torch
+    from speechless_amd.engine import Engine
+    case = _wave_case(cin=cin)
+    eng = Engine(case["specs"], 29, dtype=dtype)
+    assert [s.name for s in eng.all_specs][:2] == ["wave_conv", "striding_conv"] and len(eng.all_specs) == 12
+    eng.set_weights(case["weights"])
+    got_w = eng.get_weights()
+    assert got_w[0][0].shape == (250, cin, 250) and np.array_equal(got_w[0][0], case["weights"][0][0])
+    for t_audio in (24055, 20007):
+        x = case["x"][:, :t_audio]
+        pred_len = [min(n, t_audio // 320) for n in case["prediction_lengths"]]
+        eng.load_input(x)
+        eng.set_labels(case["labels"], np.array(case["label_lengths"]), np.array(pred_len))
+        eng.forward(training=True)
+        losses = eng.ctc().cpu().numpy()
+        eng.backward()
+        torch.cuda.synchronize()
+        ref = o.loss_and_gradients(case["ospecs"], weights64(case), x.astype(np.float64), case["labels"], pred_len,
+                                   case["label_lengths"])
+        grads = eng.get_gradients()
+        assert len(grads) == 12 and grads[0][0].shape == (250, cin, 250)
+        errs = [max(rel_l2(dw, rw), rel_l2(db, rb)) for (dw, db), (rw, rb) in zip(grads, ref["grads"])]
+        _report("raw_wave_gradient_errors_{}_cin{}_t{}".format(dtype, cin, t_audio), errs)
+        if dtype == "f32":
+            np.testing.assert_allclose(losses, ref["losses"], rtol=2e-5)
+            # flip-aware as everywhere on the fp32 path: the top of the stack tight, a prefix below the first flipped ReLU
+            # decision looser (75 output frames per utterance)
+            assert errs[-1] < 2e-4 and max(errs) < 1e-2, errs
+            decoded, _ = eng.greedy_decode(pred_len)
+            assert decoded == o.greedy_decode_indices(ref["probs"], pred_len)
+        else:
+            np.testing.assert_allclose(losses, ref["losses"], rtol=2e-3)
+            assert np.isfinite(errs).all() and errs[-1] < 2e-2, errs
+        buf = eng.cur
+        p0 = eng.plans[0]
+        t1 = -(-t_audio // 160)
+        x0 = buf.x0.float()
+        assert bool((x0[:, p0.pad_left:p0.pad_left + t1, 255] == 1).all())          # ones channel from wave_conv's bias
+        assert not x0[:, :p0.pad_left].any() and not x0[:, p0.pad_left + t1:].any()  # layout invariant of the input buffer
+        gx0 = buf.gx0.float()
+        assert not gx0[:, p0.pad_left + t1:].any() and not gx0[:, :p0.pad_left].any()
+    # optimisation steps: the loss goes down, padded parameters stay zero, the ones stay ones
+    first = float(np.mean(losses))
+    for _ in range(8):
+        eng.train_step_resident()
+    torch.cuda.synchronize()
+    assert float(eng.cur.loss.mean().item()) < first
+    fw = eng.layer_param_views(eng.params, eng.front_plan)[0]
+    assert not fw[:, 250 * cin:, :].any() and not fw[:, :, 250:].any()
+
+
+def test_wav2letter_api_with_raw_wave_input(tmp_path):
+    """Wav2Letter(use_raw_wave_input=True) no longer raises: the reference's 12-layer net on (T, 1) sample arrays -- ratio 320,
+    training steps (with and without dropout), predict, an HDF5 checkpoint round trip with the `wave_conv` layer, the
+    data-parallel bucket plan with the front layer's bucket last and the RCCL step on one rank bit-identical."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from speechless_amd import Wav2Letter, english_frequent_characters
+    from speechless_amd.net import Adam, LabeledSpectrogram
+    from speechless_amd.parallel import GradBucketReducer
+    rng = np.random.RandomState(3)
+    words = ["she", "was", "abc", "a", "zoo"]
+    batch = [LabeledSpectrogram(id="u{}".format(i), label=" ".join(rng.choice(words, size=rng.randint(1, 3))),
+                                spectrogram=0.1 * rng.randn(int(rng.randint(9000, 12000)), 1)) for i in range(4)]
+    sizes = dict(out_filter_count=256)
+    finals = []
+    for dropout in (None, 0.1):
+        net = Wav2Letter(1, english_frequent_characters, use_raw_wave_input=True, optimizer=Adam(1e-3), seed=5,
+                         dropout=dropout, layer_sizes=sizes)
+        assert net.input_to_prediction_length_ratio == 320
+        assert [l.name for l in net.predictive_net.layers][:2] == ["wave_conv", "striding_conv"]
+        before = net.test_and_predict_batch(batch).average_loss
+        for _ in range(10):
+            net.train_on_batch(batch)
+        after = net.test_and_predict_batch(batch)
+        assert after.average_loss < before and isinstance(net.predict(batch[0]), str)
+        finals.append(net)
+    net = finals[0]
+    net.predictive_net.save_weights(tmp_path / "w.h5")
+    other = Wav2Letter(1, english_frequent_characters, use_raw_wave_input=True, seed=9, layer_sizes=sizes)
+    other.predictive_net.load_weights(str(tmp_path / "w.h5"))
+    for (a, ab), (b, bb) in zip(net.predictive_net.get_weights(), other.predictive_net.get_weights()):
+        assert np.array_equal(a, b) and np.array_equal(ab, bb)
+    assert net.predictive_net.get_weights()[0][0].shape == (250, 1, 250)
+    # data parallel: the front layer's bucket is the last one; one rank through RCCL = the plain step, bit for bit
+    eng = net.engine
+    plan = eng.bucket_plan()
+    assert plan[-1][0] == [eng.front_plan.index] and plan[-1][1][1] == eng.param_numel
+    assert sum(hi - lo for _, (lo, hi) in plan) == eng.param_numel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29536")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        results = []
+        for use_reducer in (False, True):
+            n2 = Wav2Letter(1, english_frequent_characters, use_raw_wave_input=True, optimizer=Adam(1e-3), seed=5,
+                            layer_sizes=sizes)
+            reducer = GradBucketReducer(n2.engine.grads, n2.engine.bucket_ranges(), force=True) if use_reducer else None
+            for _ in range(3):
+                n2.train_on_batch(batch, reducer=reducer)
+            torch.cuda.synchronize()
+            results.append(n2.engine.params.clone())
+        assert torch.equal(results[0], results[1])
+    finally:
+        if created:
+            dist.destroy_process_group()
