@@ -768,7 +768,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_ilv_multi_kernel(MultiArgs a)
         const int x_step = TK * x_rs, g_step = TK * g_rs;
         const int x_wrap = (int)J.x_bs - (a.t_chunks - 1) * x_step;
         const int g_wrap = (int)J.g_bs - (a.t_chunks - 1) * g_step;
-        const __bf16* xs_r = J.x + (long)(J.x_row0 + tap) * x_rs + ci_tile * 256 + (long)b_begin * J.x_bs + (long)tc_begin * x_step;
+        // (a channel count that is not a multiple of 256 -- the 640-wide pair view of 257 bins -- ends with a tile that starts
+        // at cin - 256 and overlaps its neighbour; the reduction writes the overlapped rows from the neighbour only)
+        const int ci_start = __builtin_amdgcn_readfirstlane(min(ci_tile * 256, J.cin - 256));
+        const __bf16* xs_r = J.x + (long)(J.x_row0 + tap) * x_rs + ci_start + (long)b_begin * J.x_bs + (long)tc_begin * x_step;
         const __bf16* gs_r = J.g + (long)J.g_row0 * g_rs + co_tile * 256 + (long)b_begin * J.g_bs + (long)tc_begin * g_step;
         const __bf16* xs_n = nullptr;
         const __bf16* gs_n = nullptr;
@@ -904,7 +907,9 @@ __global__ __launch_bounds__(256) void wgrad_multi_reduce_kernel(MultiArgs a) {
         const f32x4 v = *(const f32x4*)(a.slots + ((long)(a.pair_wgs + tile / 2) * 2 + (tile & 1)) * (256 * 256) + e);
         s = pairs == 0 ? v : s + v;
     }
-    *(f32x4*)(J.dw + ((long)tap * J.cin + ci_tile * 256 + ci) * J.cout + co_tile * 256 + co) = s;
+    const int ci_start = min(ci_tile * 256, J.cin - 256);  // last tile of a channel count that is not a multiple of 256
+    if (ci_start + ci < ci_tile * 256) return;               // ... its overlap is the neighbouring tile's to write
+    *(f32x4*)(J.dw + ((long)tap * J.cin + ci_start + ci) * J.cout + co_tile * 256 + co) = s;
 }
 
 template <int WM, int WN, int STAGES>
@@ -1106,11 +1111,11 @@ static int multi_fill(const sl_wgrad_job* jobs, int n_jobs, MultiArgs* a) {
     for (int i = 0; i < n_jobs; ++i) {
         const sl_conv_geom& g = jobs[i].geom;
         if (g.batch != a->batch || g.t_out != jobs[0].geom.t_out || g.batch <= 0 || g.t_out <= 0 || g.taps <= 0 ||
-            g.cin <= 0 || g.cout <= 0 || g.cin % 256 || g.cout % 256 || g.x_row_stride % 8 || g.y_row_stride % 8 ||
+            g.cin < 256 || g.cout <= 0 || g.cin % 64 || g.cout % 256 || g.x_row_stride % 8 || g.y_row_stride % 8 ||
             g.x_row_stride < g.cin || g.y_row_stride < g.cout || g.x_batch_stride >= (1LL << 31) ||
             g.y_batch_stride >= (1LL << 31)) {
-            sl_set_error("sl_conv1d_wgrad_multi: job %d: all jobs need the same batch and t_out, channel counts that are "
-                         "multiples of 256 and row strides that are multiples of 8", i);
+            sl_set_error("sl_conv1d_wgrad_multi: job %d: all jobs need the same batch and t_out, output channels in multiples of "
+                         "256, at least 256 input channels in multiples of 64 and row strides that are multiples of 8", i);
             return SL_ERR_UNSUPPORTED;
         }
         MultiJob& J = a->job[i];
@@ -1120,7 +1125,7 @@ static int multi_fill(const sl_wgrad_job* jobs, int n_jobs, MultiArgs* a) {
         J.taps = g.taps;
         J.cin = g.cin;
         J.cout = g.cout;
-        J.ci_tiles = g.cin / 256;
+        J.ci_tiles = (g.cin + 255) / 256;
         J.co_tiles = g.cout / 256;
         J.x_row0 = g.x_row0;
         J.x_rs = g.x_row_stride;

@@ -540,6 +540,9 @@ class Engine:
         # whose (tile, 64-frame step) space is cut into one equal range per CU (sl_conv1d_wgrad_multi) instead of a grouped
         # launch + a 128 x 128-tile launch with utterance-granular batch splits.  SL_WGRAD_MULTI=0: those launches.
         self.use_wgrad_multi = os.environ.get("SL_WGRAD_MULTI", "1") != "0"
+        # ... also for a layer whose input channels are not a multiple of the 256-wide tile (257 bins: the 640-wide pair view
+        # of striding_conv): its last tile starts at cin - 256 and overlaps the one before (A/B knob)
+        self.multi_overlap_tiles = True
         self.small_bias_pass_on_main = os.environ.get("SL_BIAS_MAIN", "1") != "0"  # A/B knob
         self.x3_fused_epilogue = os.environ.get("SL_X3_FUSED_EPILOGUE", "1") != "0"  # bf16x3: activation + plane split in the NT epilogue
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
@@ -1446,7 +1449,7 @@ class Engine:
         # launch list: not with dropout (its scale passes take the rate by value)
         key = None if buf.dropped else ("bwd", main.cuda_stream, buf.split_pending, on_bucket_ready is not None, self.ones_channel,
                                         self.frozen_layer_count, self.group_wgrad, self.use_chain, self.fuse_output_backward,
-                                        self.use_wgrad_multi, self.small_bias_pass_on_main,
+                                        self.use_wgrad_multi, self.multi_overlap_tiles, self.small_bias_pass_on_main,
                                         tuple(sorted(self.nt_cfg.items())),
                                         buf.t_out if self.planes > 1 else None)  # (bf16x3 helpers take it by value)
         ops = self._launch_list(buf, key) if key is not None else None
@@ -1703,9 +1706,10 @@ class Engine:
         if not self.use_wgrad_multi or self.dtype != "bf16" or not grouped:
             return []
 
-        def fits(i):
-            return self.plans[i].cin_view % 256 == 0 and self.plans[i].cout_pad % 256 == 0 and \
-                ("wgrad", self.specs[i].name) not in self.nt_cfg
+        def fits(i):  # (input channels: whole 256-wide tiles, or -- round 4 -- a last tile overlapping its neighbour)
+            cin = self.plans[i].cin_view
+            return cin >= 256 and cin % (64 if self.multi_overlap_tiles else 256) == 0 and \
+                self.plans[i].cout_pad % 256 == 0 and ("wgrad", self.specs[i].name) not in self.nt_cfg
         layers = sorted(grouped)
         if not all(fits(i) for i in layers) or len(layers) > 15:
             return []
