@@ -283,6 +283,7 @@ struct TrPhase {
     static __device__ __forceinline__ void run(f32x4 (&acc)[4][8], TrFrags& cur, TrFrags& nxt, const unsigned (&gaddr)[4],
                                                const unsigned (&xaddr)[8], const Hook& hook) {
         constexpr int GRB = 512, XRB = 512;
+#if !defined(SL_WGRAD_PROBE_NO_MFMA)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = 2 * Q + j;
@@ -290,10 +291,18 @@ struct TrPhase {
             acc[jn][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(cur.gl[jn], cur.gh[jn]), frag8(cur.xl[it], cur.xh[it]),
                                                                   acc[jn][it], 0, 0, 0);
         }
+#else
+        asm volatile("" : "+v"(cur.gl[Q % 4]), "+v"(cur.xl[Q % 8]));
+#endif
+#if !defined(SL_WGRAD_PROBE_NO_READS)  // timing probes (wrong results by construction): tools/README.md, DESIGN.md section 4
         if constexpr (Q < 4)
             tr_read8<KK * 32 * GRB, GRB>(nxt.gl[Q], nxt.gh[Q], gaddr[Q]);
         else if constexpr (Q < 12)
             tr_read8<KK * 32 * XRB, XRB>(nxt.xl[Q - 4], nxt.xh[Q - 4], xaddr[Q - 4]);
+#endif
+#if defined(SL_WGRAD_PROBE_NO_MFMA)
+        (void)0;
+#endif
         hook(std::integral_constant<int, Q>{});
         __builtin_amdgcn_sched_barrier(0);
         TrPhase<KK, Q + 1, NQ>::template run<Hook>(acc, cur, nxt, gaddr, xaddr, hook);
@@ -377,10 +386,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_ilv_kernel(TnArgs a) {
     };
     auto dma_piece = [&](auto q_c) {
         constexpr int Q = decltype(q_c)::value;
+#if !defined(SL_WGRAD_PROBE_NO_DMA)
         if constexpr (Q < XPW)
             glds16(xs_n + xoff[Q], smem + xl_n + Q * 1024);
         else if constexpr (Q < XPW + GPW)
             glds16(gs_n + goff_src[Q - XPW], smem + gl_n + (Q - XPW) * 1024);
+#endif
     };
     const int i16 = lane & 15;
     const int rkey = (i16 >> 2) | ((g & 1) << 2);
