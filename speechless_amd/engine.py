@@ -385,6 +385,14 @@ class _Buffers:
             # (its split count only shrinks with fewer CUs: the whole-chip size covers every hint)
             need = L.raw("sl_conv1d_backward_1x1_workspace_bytes")(ctypes.byref(self.wgrad_geom[last]),
                                                                    eng.grapheme_set_size, eng.dtype_code, 0)
+            # a PART of the batch (Engine.split_top) can pick more chunk ranges than the whole batch does (33 chunks: 11
+            # ranges of 3, 32 chunks: 16 of 2): size for the most any chunk count gets -- that of a very long batch
+            many = ConvGeom()
+            for name, _ in ConvGeom._fields_:
+                setattr(many, name, getattr(self.wgrad_geom[last], name))
+            many.batch = 4096
+            need = max(need, L.raw("sl_conv1d_backward_1x1_workspace_bytes")(ctypes.byref(many), eng.grapheme_set_size,
+                                                                             eng.dtype_code, 0))
             if need and (self.bwd1x1_ws is None or self.bwd1x1_ws.numel() < need):
                 self.bwd1x1_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
                 self.launch_lists = {}

@@ -612,3 +612,17 @@ def test_wav2letter_api_with_raw_wave_input(tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_random_shapes_with_the_top_of_the_step_split():
+    """tools/fuzz_shapes.py --split, ten cases: random batch sizes, frame counts and label lengths with Engine.split_top forced
+    in a random split a + (B - a) -- loss and gradients against the whole-batch sequence, deterministic (76 cases at 128 and
+    257 bins: all passed; the first run of this fuzz found the part-sized workspace of the output layer's backward)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    res = subprocess.run([sys.executable, str(root / "tools" / "fuzz_shapes.py"), "--cases", "10", "--seed", "21", "--split",
+                          "--max-batch", "8"], capture_output=True, text=True, cwd=str(root), timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert "all 10 cases passed" in res.stdout

@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--max-frames", type=int, default=1400)
     ap.add_argument("--max-batch", type=int, default=6)
     ap.add_argument("--x3", action="store_true", help="also the bf16x3 path (loss within 2e-6 of fp32)")
+    ap.add_argument("--split", action="store_true",
+                    help="also the bf16 path with Engine.split_top forced on every batch of >= 2 utterances, in a random split "
+                         "a + (B - a) (the CTC of one part under the top layers of the other): loss within 2e-5 of the "
+                         "whole-batch bf16 step, gradients within 1e-2, deterministic")
     args = ap.parse_args()
     import torch
     from speechless_amd.engine import Engine, wav2letter_layer_specs
@@ -62,6 +66,28 @@ def main():
             assert np.isfinite(loss).all(), (dtype, b, t, loss)
             assert bool(torch.isfinite(grads).all()) and bool(torch.isfinite(params).all()), (dtype, b, t)
             out[dtype] = loss
+        if args.split and b >= 2:
+            eng = engines["bf16"]
+            a = int(rng.randint(1, b))
+            whole_grads = None
+            runs = []
+            for rep in range(3):
+                eng.set_weights(weights)
+                eng.load_input(x)
+                eng.set_labels(labels, lab_len, pred_len)
+                if rep == 0:  # the whole-batch sequence
+                    eng.forward(training=True)
+                    loss = eng.ctc(grad_scale=1.0 / b)
+                else:
+                    eng.forward(training=True, split_ctc=(1.0 / b, a))
+                    loss = eng.cur.loss
+                eng.backward()
+                torch.cuda.synchronize()
+                runs.append((loss.cpu().numpy().copy(), eng.grads.clone()))
+            assert np.array_equal(runs[1][0], runs[2][0]) and torch.equal(runs[1][1], runs[2][1]), ("split not deterministic", b, t, a)
+            np.testing.assert_allclose(runs[1][0], runs[0][0], rtol=2e-5, atol=1e-4, err_msg=str((b, t, a)))
+            err = float(torch.linalg.norm(runs[1][1] - runs[0][1]) / torch.linalg.norm(runs[0][1]))
+            assert err < 1e-2, ("split gradients", b, t, a, err)
         rel = float(np.max(np.abs(out["bf16"] - out["f32"]) / np.maximum(np.abs(out["f32"]), 1.0)))
         worst = max(worst, rel)
         assert rel < 2e-3, (b, t, pred_len, lab_len, out)
