@@ -19,400 +19,14 @@ import torch
 
 from . import _lib
 from ._lib import ConvGeom, lib
-
-HALO = 16
-TIME_TILE = 256  # SL_TIME_TILE: the conv kernels read whole time tiles of up to 256 rows
-
-
-def _round_up(x, m):
-    return (x + m - 1) // m * m
+from .buffers import _Buffers
+from .engine_front import FrontLayerMixin
+from .engine_split import SplitTopMixin
+from .engine_x3 import X3Mixin
+from .plan import HALO, TIME_TILE, LayerPlan, LayerSpec, _round_up, same_padding, wav2letter_layer_specs  # noqa: F401
 
 
-class LayerSpec:
-    def __init__(self, name, kernel_size, stride, cin, cout, activation):
-        self.name = name
-        self.kernel_size = kernel_size
-        self.stride = stride
-        self.cin = cin
-        self.cout = cout
-        self.activation = activation
-
-
-def wav2letter_layer_specs(input_size_per_time_step, grapheme_set_size, activation="relu",
-                           output_activation="softmax", main_filter_count=250, out_filter_count=2000, inner_count=7,
-                           striding_kernel=48, inner_kernel=7, big_kernel=32, use_raw_wave_input=False, wave_kernel=250,
-                           wave_stride=160):
-    """Topology of reference net.py:307-330; use_raw_wave_input: `wave_conv` (250 taps at stride 160 over the samples,
-    net.py:310-312) in front of striding_conv, which then reads its filters instead of spectrogram bins.  Sizes are
-    parameters only so that tests can build shrunken stacks of the same structure."""
-    specs = []
-    if use_raw_wave_input:
-        specs.append(LayerSpec("wave_conv", wave_kernel, wave_stride, input_size_per_time_step, main_filter_count, activation))
-        input_size_per_time_step = main_filter_count
-    specs.append(LayerSpec("striding_conv", striding_kernel, 2, input_size_per_time_step, main_filter_count, activation))
-    for i in range(1, inner_count + 1):
-        specs.append(LayerSpec("inner_conv_{}".format(i), inner_kernel, 1, main_filter_count, main_filter_count,
-                               activation))
-    specs.append(LayerSpec("big_conv_1", big_kernel, 1, main_filter_count, out_filter_count, activation))
-    specs.append(LayerSpec("big_conv_2", 1, 1, out_filter_count, out_filter_count, activation))
-    specs.append(LayerSpec("output_conv", 1, 1, out_filter_count, grapheme_set_size, output_activation))
-    return specs
-
-
-def same_padding(t_in, kernel_size, stride):
-    """TF 'SAME': T_out = ceil(T/s); pad_total = max((T_out-1)*s + k - T, 0); extra padding goes right."""
-    t_out = -(-t_in // stride)
-    pad_total = max((t_out - 1) * stride + kernel_size - t_in, 0)
-    return t_out, pad_total // 2, pad_total - pad_total // 2
-
-
-class LayerPlan:
-    def __init__(self, index, spec, cin_pad, cout_pad, w_off, b_off):
-        self.index = index
-        self.spec = spec
-        self.cin_pad = cin_pad
-        self.cout_pad = cout_pad
-        k = spec.kernel_size
-        if spec.stride == 2:
-            if k % 2:
-                raise NotImplementedError("stride-2 layers need an even kernel size (pair view)")
-            self.taps_view = k // 2
-            self.cin_view = 2 * cin_pad
-            # pair view needs pad_left odd/even consistent with row offset; pad_left of SAME stride 2, even k is k/2-1
-            self.pad_left = (k - 2) // 2 if k >= 2 else 0
-            self.pad_right = None  # depends on T parity, not needed in the pair view
-        else:
-            self.taps_view = k
-            self.cin_view = cin_pad
-            self.pad_left = (k - 1) // 2
-            self.pad_right = (k - 1) - self.pad_left
-        self.w_off = w_off
-        self.w_numel = k * cin_pad * cout_pad
-        self.b_off = b_off
-
-
-class _Buffers:
-    """All HBM tensors of one (batch, padded frames) geometry.  Batches of any length whose output frames round up to
-    the same multiple of TIME_TILE share one set of buffers (the reference's training generator, corpus.py:224-226,
-    pads every batch to its own longest member, so the frame count changes with nearly every step): set_length()
-    re-targets the geometry descriptors and keeps the layout invariant (rows beyond the valid time are zero) by clearing
-    only the rows between the new length and the previous high-water mark."""
-
-    def __init__(self, eng, batch, tt_pad):
-        dev = eng.device
-        dt = eng.torch_dtype
-        p0 = eng.plans[0]
-        pl = eng.planes  # 3 on the bf16x3 path: every tensor row holds the planes [hi | lo | hi] (csrc/split3.hip)
-        self.batch = batch
-        self.tt_pad = tt_pad
-        self.t_in = None
-        self.t_out = None
-        self.rows = HALO + self.tt_pad + HALO
-        self.rows0 = 2 * (self.tt_pad + p0.taps_view)
-        self.x0 = torch.zeros((batch, self.rows0, p0.cin_pad * pl), dtype=dt, device=dev)
-        self.x0_dropped = None  # dropout(x0), allocated by the first training forward with dropout
-        self.dropped = False    # the activations of the last forward are post-dropout
-        n = len(eng.plans)
-        self.y = [None] * (n - 1)
-        self._blocks = []  # every halo'd allocation (runs of identical layers are one), for set_length()'s clearing
-        # a run of identical layers (the seven inner_conv_i) keeps its inputs y[s-1..e-1] in ONE allocation so that
-        # the grouped weight-gradient launch can address layer q as base + q*stride
-        for (s0, e0) in eng.runs:
-            block = torch.zeros((e0 - s0 + 1, batch, self.rows, eng.plans[s0].cin_pad * pl), dtype=dt, device=dev)
-            self._blocks.append(block)
-            for q in range(e0 - s0 + 1):
-                self.y[s0 - 1 + q] = block[q]
-        for p in eng.plans[:-1]:
-            if self.y[p.index] is None:
-                self.y[p.index] = torch.zeros((batch, self.rows, p.cout_pad * pl), dtype=dt, device=dev)
-                self._blocks.append(self.y[p.index].unsqueeze(0))
-        self.logits = torch.zeros((batch, self.tt_pad, eng.plans[-1].cout_pad), dtype=torch.float32, device=dev)
-        k = eng.grapheme_set_size
-        # dense [B][T'][K] / [B][T'] results: flat allocations for the longest batch, viewed per length
-        self._probs_flat = torch.zeros((batch * self.tt_pad * k,), dtype=torch.float32, device=dev)
-        self._logq_flat = torch.zeros((batch * self.tt_pad * k,), dtype=torch.float32, device=dev)
-        self._decoded_flat = torch.zeros((batch * self.tt_pad,), dtype=torch.int32, device=dev)
-        self._argmax_flat = torch.zeros((batch * self.tt_pad,), dtype=torch.int32, device=dev)
-        self.g = [None] * n  # allocated lazily by ensure_backward()
-        self.decoded_len = torch.zeros((batch,), dtype=torch.int32, device=dev)
-        self.input_len = torch.zeros((batch,), dtype=torch.int32, device=dev)
-        self.loss = torch.zeros((batch,), dtype=torch.float32, device=dev)
-        self.fwd_geom = []
-        for p in eng.plans:
-            g = ConvGeom()
-            g.batch = batch
-            g.t_out = self.tt_pad
-            g.taps = p.taps_view
-            g.cin = p.cin_view * pl
-            g.cout = p.cout_pad
-            if p.index == 0:
-                g.x_row0 = 0
-                g.x_row_stride = p.cin_view * pl
-                g.x_batch_stride = self.rows0 * p.cin_pad * pl
-            else:
-                g.x_row0 = HALO - p.pad_left
-                g.x_row_stride = p.cin_pad * pl
-                g.x_batch_stride = self.rows * p.cin_pad * pl
-            if p.index == n - 1 or pl > 1:  # fp32 out: the logits -- and on the bf16x3 path every layer's staging buffer
-                g.y_row0 = 0
-                g.y_row_stride = p.cout_pad
-                g.y_batch_stride = self.tt_pad * p.cout_pad
-            else:
-                g.y_row0 = HALO
-                g.y_row_stride = p.cout_pad
-                g.y_batch_stride = self.rows * p.cout_pad
-            self.fwd_geom.append(g)
-        # bf16x3: fp32 staging buffer of a layer's pre-activations / input gradients (sl_conv1d_nt out_f32 -> sl_split3)
-        self.stage32 = torch.empty((batch * self.tt_pad * max(p.cout_pad for p in eng.plans),), dtype=torch.float32,
-                                   device=dev) if pl > 1 else None
-        self.plane_geoms = {}  # bf16x3: (kind, layer) -> geometry whose output side describes a plane tensor
-        # front layer (raw-wave input): gathered sample windows [B][2 tt_pad][K_pad], the gradient w.r.t. the stack's input in
-        # the pair-view layout of x0, and the three geometries of the launches around them (Engine._front_*)
-        self.frames = self.gx0 = self.front_geom = self.front_dgrad_geom = None
-        if eng.front_plan is not None:
-            fp = eng.front_plan
-            self.frames = torch.zeros((batch, 2 * tt_pad, fp.cin_pad), dtype=dt, device=dev)
-            g = ConvGeom()
-            g.batch, g.t_out, g.taps, g.cin, g.cout = batch, 2 * tt_pad, 1, fp.cin_pad, fp.cout_pad
-            g.x_row0, g.x_row_stride, g.x_batch_stride = 0, fp.cin_pad, 2 * tt_pad * fp.cin_pad
-            g.y_row0, g.y_row_stride, g.y_batch_stride = p0.pad_left, p0.cin_pad, self.rows0 * p0.cin_pad
-            self.front_geom = g  # forward (x = frames, y = x0) and weight gradient (x = frames, "y" = gx0): t_out = input frames
-        self.half_geoms = {}   # split top (Engine.split_top): (kind, layer) -> the layer's geometry for half the batch
-        self.ctc_done = [None, None]  # split top: events behind the CTC launches of the two half-batches
-        self.ctc_half_bytes = 0
-        self.split_pending = 0        # utterances in the first part if the last forward ran the CTC in two parts (else 0)
-        self.wgrad_r = None  # bf16x3: the two partial weight gradients (RA | RB) in front of sl_split3_wgrad_combine
-        self.wgrad_geom_b = [None] * n
-        self.wgrad_geom = [None] * n
-        self.dgrad_geom = [None] * n
-        self.bwd_ready = False
-        self.nt_ws = None
-        self.wgrad_ws = None
-        self.launch_lists = {}   # recorded launch lists (Engine._replay); dropped whenever a pointer they hold changes
-        self.chain_tables = {}   # sl_conv1d_chain pointer tables of this buffer set (Engine._chain_table)
-        self.multi_tables = {}   # sl_conv1d_wgrad_multi job tables (their geometries follow set_length)
-        self.wgrad_multi_ws = None
-        self._ws_sized_fwd = set()   # output lengths whose forward / backward workspace needs have been checked
-        self._ws_sized_bwd = set()   # (a length first seen by predict() and trained on later still gets its dgrad sizing)
-        self._clean_in = 0       # input frames / output rows up to which stale data may sit in the buffers
-        self._clean_out = 0
-
-    def set_length(self, eng, t_in):
-        """Re-targets the buffers at batches of t_in input frames (same tt_pad)."""
-        p0 = eng.plans[0]
-        t_out, pad_l, _ = same_padding(t_in, p0.spec.kernel_size, p0.spec.stride)
-        assert pad_l == p0.pad_left and _round_up(t_out, TIME_TILE) == self.tt_pad
-        # rows [new length, high-water mark) still hold the previous, longer batch: the kernels never write rows
-        # beyond the valid time, so they are cleared here (nothing to do while the lengths grow)
-        if t_in < self._clean_in:
-            self.x0[:, p0.pad_left + t_in: p0.pad_left + self._clean_in].zero_()
-            if self.gx0 is not None:
-                self.gx0[:, p0.pad_left + t_in: p0.pad_left + self._clean_in].zero_()
-        if t_out < self._clean_out:
-            for block in self._blocks:
-                block[:, :, HALO + t_out: HALO + self._clean_out].zero_()
-        self._clean_in, self._clean_out = t_in, t_out
-        if t_in == self.t_in:
-            return
-        self.t_in, self.t_out = t_in, t_out
-        k = eng.grapheme_set_size
-        b = self.batch
-        self.probs = self._probs_flat[:b * t_out * k].view(b, t_out, k)
-        self.logq = self._logq_flat[:b * t_out * k].view(b, t_out, k)
-        self.decoded = self._decoded_flat[:b * t_out].view(b, t_out)
-        self.frame_argmax = self._argmax_flat[:b * t_out].view(b, t_out)
-        for geoms in (self.fwd_geom, self.wgrad_geom, self.dgrad_geom):
-            for g in geoms:
-                if g is not None:
-                    g.t_out = t_out
-        for table in self.multi_tables.values():
-            for job in (table[0] if isinstance(table, tuple) else table):  # (bf16x3: (table, partial buffers, ...))
-                job.geom.t_out = t_out
-        for g in self.plane_geoms.values():
-            g.t_out = t_out
-        for g in self.half_geoms.values():
-            g.t_out = t_out
-        if self.front_geom is not None:
-            self.front_geom.t_out = t_in
-        if self.front_dgrad_geom is not None:
-            self.front_dgrad_geom.t_out = t_out + eng.FRONT_DGRAD_EXTRA_ROWS
-        if t_out not in self._ws_sized_fwd:  # split counts (hence workspace sizes) depend on the number of time tiles
-            self._ws_sized_fwd.add(t_out)
-            self.size_nt_workspace(eng, self.fwd_geom, "fwd")
-        if self.bwd_ready and t_out not in self._ws_sized_bwd:
-            self.size_backward_workspaces(eng)
-
-    def size_nt_workspace(self, eng, geoms, kind):
-        need = 16
-        for hint in eng.cu_hints():  # (the split choosers consult sl_set_available_cus: size for every setting in use)
-            lib().call("sl_set_available_cus", hint)
-            for p, g in zip(eng.plans, geoms):
-                if g is not None:
-                    need = max(need, lib().raw("sl_conv1d_nt_workspace_bytes")(
-                        ctypes.byref(g), eng.dtype_code, eng.nt_cfg.get((kind, p.spec.name), 0)))
-        lib().call("sl_set_available_cus", 0)
-        if self.nt_ws is None or self.nt_ws.numel() < need:
-            self.nt_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
-            self.launch_lists = {}
-
-    def ensure_backward(self, eng):
-        if self.bwd_ready:
-            return
-        dev, dt = eng.device, eng.torch_dtype
-        n = len(eng.plans)
-        first = eng.frozen_layer_count
-        for (s0, e0) in eng.runs:  # gradients g[s..e] of a run of identical layers: one allocation (grouped wgrad)
-            lo = max(s0, first)
-            if e0 >= lo:
-                block = torch.zeros((e0 - lo + 1, self.batch, self.rows, eng.plans[lo].cout_pad * eng.planes), dtype=dt,
-                                    device=dev)
-                self._blocks.append(block)
-                for q in range(e0 - lo + 1):
-                    self.g[lo + q] = block[q]
-        for p in eng.plans[first:]:
-            if self.g[p.index] is None:
-                # (layer 0 under a front layer: its input-gradient launch reads up to a time tile past the last utterance's
-                # rows -- one utterance of zero slack behind the batch)
-                slack = 1 if (p.index == 0 and eng.front_plan is not None) else 0
-                full = torch.zeros((self.batch + slack, self.rows, p.cout_pad * eng.planes), dtype=dt, device=dev)
-                self.g[p.index] = full[:self.batch]
-                self._g0_keepalive = full
-                self._blocks.append(self.g[p.index].unsqueeze(0))
-            pl = eng.planes
-            wg = ConvGeom()
-            f = self.fwd_geom[p.index]
-            for name, _ in ConvGeom._fields_:
-                setattr(wg, name, getattr(f, name))
-            wg.y_row0 = HALO
-            wg.y_row_stride = p.cout_pad * pl
-            wg.y_batch_stride = self.rows * p.cout_pad * pl
-            self.wgrad_geom[p.index] = wg
-            if pl > 1:
-                # bf16x3: two launches.  A: the [hi | lo] prefix of x against g_hi (hh and lh in one (2 Cin) x Cout product),
-                # B: x_hi against g_lo (hl); sl_split3_wgrad_combine adds the three blocks.  The pair view of the striding
-                # layer has the planes of two frames in a row, so there the whole row is the x operand of both.
-                wb = ConvGeom()
-                for name, _ in ConvGeom._fields_:
-                    setattr(wb, name, getattr(wg, name))
-                wg.cin = p.cin_view * pl if p.index == 0 else 2 * p.cin_pad
-                wb.cin = p.cin_view * pl if p.index == 0 else p.cin_pad
-                self.wgrad_geom_b[p.index] = wb
-            if p.index > first:
-                dg = ConvGeom()
-                dg.batch = self.batch
-                dg.t_out = self.t_out
-                dg.taps = p.spec.kernel_size
-                dg.cin = p.cout_pad * pl
-                dg.cout = p.cin_pad
-                dg.x_row0 = HALO - p.pad_right
-                dg.x_row_stride = p.cout_pad * pl
-                dg.x_batch_stride = self.rows * p.cout_pad * pl
-                if pl > 1:  # fp32 into the staging buffer, sl_split3 applies the mask and writes the planes
-                    dg.y_row0 = 0
-                    dg.y_row_stride = p.cin_pad
-                    dg.y_batch_stride = self.tt_pad * p.cin_pad
-                else:
-                    dg.y_row0 = HALO
-                    dg.y_row_stride = p.cin_pad
-                    dg.y_batch_stride = self.rows * p.cin_pad
-                self.dgrad_geom[p.index] = dg
-        if eng.front_plan is not None and first == 0 and not eng.front_frozen:
-            # dL/d(x0) in x0's own pair-view layout: pair row r = sum over the 24 pair taps j of g0[r - j] . Wpair[j]^T, as an
-            # NT launch over g0 with flipped taps.  Frames start at pair row 11, so rows from 7 on are computed: the launch
-            # then reads g0 from its first halo row (16 - 23 + 7 = 0) and never in front of the buffer.
-            p0 = eng.plans[0]
-            self.gx0 = torch.zeros_like(self.x0)
-            dg = ConvGeom()
-            dg.batch, dg.t_out, dg.taps = self.batch, (self.t_out or 0) + eng.FRONT_DGRAD_EXTRA_ROWS, p0.taps_view
-            dg.cin, dg.cout = p0.cout_pad, p0.cin_view
-            dg.x_row0, dg.x_row_stride, dg.x_batch_stride = 0, p0.cout_pad, self.rows * p0.cout_pad
-            dg.y_row0, dg.y_row_stride, dg.y_batch_stride = eng.FRONT_DGRAD_ROW0, p0.cin_view, self.rows0 * p0.cin_pad
-            self.front_dgrad_geom = dg
-        self.bias_ws = None
-        self.bwd1x1_ws = None
-        self.ctc_ws = None
-        self.labels = None
-        self.label_len = torch.zeros((self.batch,), dtype=torch.int32, device=dev)
-        self.bwd_ready = True
-        self.size_backward_workspaces(eng)
-
-    def size_backward_workspaces(self, eng):
-        L = lib()
-        self._ws_sized_bwd.add(self.t_out)
-        first = eng.frozen_layer_count
-        ws_bytes = 0
-        bias_ws = 0
-        for hint in eng.cu_hints():
-            L.call("sl_set_available_cus", hint)
-            for p in eng.plans[first:]:
-                wg = self.wgrad_geom[p.index]
-                ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
-                    ctypes.byref(wg), eng.dtype_code, eng.nt_cfg.get(("wgrad", p.spec.name), 0)))
-                bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
-        L.call("sl_set_available_cus", 0)
-        self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
-        if eng.front_plan is not None:
-            for g in (self.front_geom, self.front_dgrad_geom):
-                if g is not None:
-                    need = L.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(g), eng.dtype_code, 0)
-                    if self.nt_ws.numel() < need:
-                        self.nt_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
-                        self.launch_lists = {}
-            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(ctypes.byref(self.front_geom), eng.dtype_code, 0))
-            bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(self.front_geom)))
-        if eng.planes > 1:
-            need = max(p.taps_view * (self.wgrad_geom[p.index].cin + self.wgrad_geom_b[p.index].cin) * p.cout_pad
-                       for p in eng.plans[first:])
-            if self.wgrad_r is None or self.wgrad_r.numel() < need:
-                self.wgrad_r = torch.empty((need,), dtype=torch.float32, device=eng.device)
-            for p in eng.plans[first:]:
-                ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
-                    ctypes.byref(self.wgrad_geom_b[p.index]), eng.dtype_code, 0))
-        if eng.dtype == "bf16":
-            for (s0, e0) in eng.runs:
-                lo = max(s0, first)
-                if e0 > lo:
-                    ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_grouped_workspace_bytes")(
-                        ctypes.byref(self.wgrad_geom[lo]), e0 - lo + 1, 0))
-        if self.wgrad_ws is None or self.wgrad_ws.numel() < ws_bytes:
-            self.wgrad_ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=eng.device)
-            self.launch_lists = {}
-        if self.bias_ws is None or self.bias_ws.numel() < bias_ws:
-            self.bias_ws = torch.empty((max(bias_ws, 16),), dtype=torch.uint8, device=eng.device)
-            self.launch_lists = {}
-        last = len(eng.plans) - 1
-        if eng.dtype == "bf16" and last > first:
-            # (its split count only shrinks with fewer CUs: the whole-chip size covers every hint)
-            need = L.raw("sl_conv1d_backward_1x1_workspace_bytes")(ctypes.byref(self.wgrad_geom[last]),
-                                                                   eng.grapheme_set_size, eng.dtype_code, 0)
-            # a PART of the batch (Engine.split_top) can pick more chunk ranges than the whole batch does (33 chunks: 11
-            # ranges of 3, 32 chunks: 16 of 2): size for the most any chunk count gets -- that of a very long batch
-            many = ConvGeom()
-            for name, _ in ConvGeom._fields_:
-                setattr(many, name, getattr(self.wgrad_geom[last], name))
-            many.batch = 4096
-            need = max(need, L.raw("sl_conv1d_backward_1x1_workspace_bytes")(ctypes.byref(many), eng.grapheme_set_size,
-                                                                             eng.dtype_code, 0))
-            if need and (self.bwd1x1_ws is None or self.bwd1x1_ws.numel() < need):
-                self.bwd1x1_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
-                self.launch_lists = {}
-
-    def ensure_ctc(self, eng, l_max):
-        """CTC workspace for label rows of up to l_max graphemes: sized in BYTES and never shrunk (the library's need
-        is monotonic in l_max since round 3, but a buffer set that has served long labels keeps its allocation)."""
-        need = lib().raw("sl_ctc_workspace_bytes")(self.batch, self.tt_pad, l_max)  # covers every length
-        if eng.split_top and self.batch >= 2:  # two parts of the batch at a time (up to B - 1 utterances), each with its own workspace
-            half = _round_up(lib().raw("sl_ctc_workspace_bytes")(self.batch - 1, self.tt_pad, l_max), 256)
-            self.ctc_half_bytes = max(self.ctc_half_bytes, half)
-            need = max(need, 2 * self.ctc_half_bytes)
-        if self.ctc_ws is None or self.ctc_ws.numel() < need:
-            self.ctc_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=eng.device)
-            self.launch_lists = {}
-        if self.labels is None or self.labels.shape[1] < l_max:
-            self.labels = torch.zeros((self.batch, l_max), dtype=torch.int32, device=eng.device)
-
-
-class Engine:
+class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
     """Forward / CTC / backward / Adam on one MI355X.  dtype 'bf16' (bf16 storage, fp32 accumulate, fp32 CTC: the
     benchmarked path), 'f32' (parity path: fp32 storage, exact-fp32 MFMA) or 'bf16x3' (the fast parity path: every value as
     hi + lo bf16 planes, three bf16 MFMA terms per product, fp32 accumulate; csrc/split3.hip)."""
@@ -587,6 +201,7 @@ class Engine:
         self._sharded_reducer = None  # the reducer of the last step, if that step ran Adam on this rank's slices only
 
     # ------------------------------------------------------------------ plumbing
+
     def cu_hints(self):
         """the sl_set_available_cus settings this engine launches under (workspaces are sized for all of them)"""
         return [0, 256 - self.comm_cus] if self.comm_cus else [0]
@@ -748,6 +363,7 @@ class Engine:
         return [r for _, r in self.bucket_plan()]
 
     # ------------------------------------------------------------------ weights
+
     def set_weights(self, weights):
         """weights: [(W (k,Cin,Cout), b (Cout,))] numpy, Keras layout."""
         assert len(weights) == len(self.all_plans)
@@ -763,22 +379,6 @@ class Engine:
             if self._has_ones_output(p):
                 bv[p.cout_pad - 1] = 1.0  # relu(0 * x + 1) = elu(1) = 1: the ones channel (see self.ones_channel)
         self._packed_dirty = True
-
-    def _public_plans(self):
-        """the plans in the public layer order (the reference's layer list): the front layer first"""
-        return ([self.front_plan] if self.front_plan is not None else []) + self.plans
-
-    def _front_to_gemm(self, plan, w):
-        """the front layer's Keras kernel (k, Cin, Cout) as the (1, k * Cin, Cout) matrix it is stored and launched as"""
-        if plan is self.front_plan and np.ndim(w) == 3 and w.shape[0] == self.front_spec.kernel_size:
-            return np.reshape(w, (1, w.shape[0] * w.shape[1], w.shape[2]))
-        return w
-
-    def _front_from_gemm(self, plan, w):
-        if plan is self.front_plan:
-            fs = self.front_spec
-            return np.reshape(w, (fs.kernel_size, fs.cin, fs.cout))
-        return w
 
     def _has_ones_output(self, plan):
         """hidden layer whose output has channel padding: its last padded channel is the constant 1"""
@@ -860,18 +460,6 @@ class Engine:
         self.adam_iterations = int(state["iterations"])
         self._dropout_steps = int(state.get("dropout_steps", 0))
 
-    def _repack_weights_x3(self):
-        """bf16x3 operand copies: rows [w_hi | w_hi | w_lo] in both operand layouts, w_hi = bf16(w), w_lo = bf16(w - w_hi),
-        one launch per layer (sl_split3_pack_weights; the five-launch sequence it replaces -- split, two packs, two
-        assembles -- was 55 launches and 0.45 ms of a 7.1 ms optimisation step)."""
-        st = self._stream()
-        for p in self.plans:
-            wv, _ = self.layer_param_views(self.params, p)
-            wd = self.w_dgrad[p.index]
-            self._launch("pack3:" + p.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
-                         wd.data_ptr() if wd is not None else None, p.spec.kernel_size, p.cin_pad, p.cout_pad, st)
-        self._packed_dirty = False
-
     def repack_weights(self):
         if self.planes > 1:
             return self._repack_weights_x3()
@@ -893,6 +481,7 @@ class Engine:
         return p.spec.kernel_size, p.cin_pad
 
     # ------------------------------------------------------------------ forward
+
     def load_input(self, input_batch):
         """input_batch: (B,T,F) numpy (any float dtype; the reference packs float64, net.py:583) or a float32 torch
         tensor already resident in HBM."""
@@ -920,72 +509,6 @@ class Engine:
         self.cur = buf
         self._src_keepalive = src
         return buf
-
-    # ------------------------------------------------------------------ front layer (raw-wave input, see __init__)
-    def _load_front_input(self, src):
-        """src: float32 (B, T, Cin) samples in HBM.  Gathers the sample windows of the ceil(T / stride) output frames (the
-        weight-independent half of the front layer; its GEMM is part of forward())."""
-        fs = self.front_spec
-        batch, t_audio, f = src.shape
-        if f != fs.cin:
-            raise ValueError("input has {} values per sample, the net expects {}".format(f, fs.cin))
-        t1, pad_l, _ = same_padding(t_audio, fs.kernel_size, fs.stride)
-        buf = self.buffers(batch, t1)
-        buf.front_src, buf.front_geometry = src, (t_audio, t1, pad_l)
-        self._front_gather(buf, src)
-        self.cur = buf
-        self._src_keepalive = src
-        return buf
-
-    def _front_gather(self, buf, src):
-        fs, fp = self.front_spec, self.front_plan
-        t_audio, t1, pad_l = buf.front_geometry
-        self._launch("wave_frames", "sl_wave_frames", src.data_ptr(), buf.frames.data_ptr(), buf.batch, t_audio, fs.cin,
-                     fs.kernel_size, fs.stride, pad_l, t1, fp.cin_pad, buf.frames.stride(0), self.dtype_code, self._stream())
-        buf.front_frames_dropped = False
-
-    def _front_forward(self, buf, rate, seed0, st):
-        """wave_conv: bias + activation epilogue of a 1 x 1 NT launch over the gathered windows, written into x0 where
-        sl_pack_input would have put a spectrogram.  With dropout (a Dropout sits in front of wave_conv too, net.py:301-303)
-        the samples are dropped first (seed offset 63: the stack's layers use 0 .. n) and the windows gathered again."""
-        fp = self.front_plan
-        if rate:
-            if getattr(buf, "front_src_dropped", None) is None or buf.front_src_dropped.shape != buf.front_src.shape:
-                buf.front_src_dropped = torch.empty_like(buf.front_src)
-            self._launch("dropout:samples", "sl_dropout", buf.front_src.data_ptr(), buf.front_src_dropped.data_ptr(),
-                         buf.front_src.numel(), _lib.SL_F32, rate, seed0 + 63, st)
-            self._front_gather(buf, buf.front_src_dropped)
-            buf.front_frames_dropped = True
-        elif buf.front_frames_dropped:
-            self._front_gather(buf, buf.front_src)
-        _, bias = self.layer_param_views(self.params, fp)
-        self._launch("fwd:" + fp.spec.name, "sl_conv1d_nt", buf.frames.data_ptr(), self.w_fwd[fp.index].data_ptr(),
-                     bias.data_ptr(), None, buf.x0.data_ptr(), ctypes.byref(buf.front_geom),
-                     _lib.EPI_BIAS_ELU if fp.spec.activation == "elu" else _lib.EPI_BIAS_RELU, self.dtype_code, 0, 0,
-                     buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-
-    def _front_backward(self, buf, st):
-        """behind the stack's backward: x0's gradient (pair-view NT launch over g[0] with the flipped pair taps, masked by
-        wave_conv's stored activation), then wave_conv's weight and bias gradient from the gathered windows"""
-        fp, p0 = self.front_plan, self.plans[0]
-        x0 = buf.x0_dropped if buf.dropped else buf.x0
-        elu = fp.spec.activation == "elu"
-        elu_dropped = elu and buf.dropped
-        self._launch("dgrad:" + p0.spec.name, "sl_conv1d_nt", buf.g[0].data_ptr(), self.w_dgrad[0].data_ptr(), None,
-                     None if elu_dropped else x0.data_ptr(), buf.gx0.data_ptr(), ctypes.byref(buf.front_dgrad_geom),
-                     _lib.EPI_NONE if elu_dropped else (_lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK), self.dtype_code, 0,
-                     0, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-        if elu_dropped:
-            self._launch("dropout_elu_bwd:" + p0.spec.name, "sl_elu_dropout_backward", buf.gx0.data_ptr(), x0.data_ptr(),
-                         buf.gx0.numel(), self.dtype_code, self.dropout_rate, buf.dropout_seed0, st)
-        elif buf.dropped:
-            self._launch("dropout_scale:" + p0.spec.name, "sl_scale", buf.gx0.data_ptr(), buf.gx0.numel(), self.dtype_code,
-                         1.0 / (1.0 - self.dropout_rate), st)
-        dw, db = self.layer_param_views(self.grads, fp)
-        self._launch("wgrad:" + fp.spec.name, "sl_conv1d_wgrad", buf.frames.data_ptr(), buf.gx0.data_ptr(), dw.data_ptr(),
-                     ctypes.byref(buf.front_geom), self.dtype_code, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
-        self._launch("bgrad:" + fp.spec.name, "sl_bias_grad", buf.gx0.data_ptr(), db.data_ptr(), ctypes.byref(buf.front_geom),
-                     self.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
 
     def _chain_table(self, kind, layers, buf):
         """ctypes pointer tables of sl_conv1d_chain for the given layers (plan indices in launch order), cached on the
@@ -1061,237 +584,6 @@ class Engine:
             return probs
         finally:
             self._rec = None
-
-    # ------------------------------------------------------------------ split top (see self.split_top)
-    def split_top_plan(self, buf):
-        """How the training step on `buf` runs its top three layers and the CTC in two parts of the batch: the number of
-        utterances in the first part, or 0 (whole-batch step)."""
-        state = (self.split_top, bool(self.dropout_rate), self.frozen_layer_count, self.fuse_output_softmax,
-                 self.fuse_output_backward, tuple(sorted(self.nt_cfg)), buf.bwd_ready, buf.bwd1x1_ws is not None,
-                 buf.labels is not None)
-        if getattr(buf, "_split_ok", (None, None))[0] != state:
-            buf._split_ok = (state, self._split_top_ok(buf))
-        return self._split_parts(buf) if buf._split_ok[1] else 0
-
-    def _split_parts(self, buf):
-        """Measured rule (MI355X, tools/split_by_bucket.py, rocprofv3 kernel traces under profiles/r04_trace_*): the top
-        layers run 256 x 256 tiles, ONE work-group per CU, and a CTC lattice wave cannot share a CU with such a work-group
-        (its registers fill the SIMDs) -- so while a part's lattice runs, 3 waves per utterance hold CUs of their own and a
-        launch of exactly 256 tiles needs a second round.  The split pays where the two launches of the widest layer, each
-        next to the other part's lattice waves, take no more rounds of 256 work-groups than the whole-batch launch: config
-        5's buckets of 384 / 896 / 960 tiles in halves (-0.09 / -0.22 / -0.09 ms), 640 tiles as 3 + 5 utterances (240 + 400
-        tiles = 1 + 2 rounds), not 512 / 768 / 1024 (whole rounds already: +0.05 ... +0.11 ms when halved) and not config
-        3 (512 tiles: +0.10 ms).  Among the splits that qualify the most even one is taken (equal halves also keep an
-        utterance's results independent of the part it is in: the two launches then pick the same K split)."""
-        b = buf.batch
-        if self.split_min_tiles is not None:  # measurement hook: halves, from a tile count on (0 = always)
-            return b // 2 if (b % 2 == 0 and self._top_tiles(buf) >= self.split_min_tiles) else 0
-        cus = 256
-        per_utt = self._top_tiles(buf) // b
-        whole = -(-(b * per_utt) // cus)
-        best, best_key = 0, None
-        for a in range(1, b):
-            rounds = -(-(a * per_utt + 3 * (b - a)) // cus) + -(-((b - a) * per_utt + 3 * a) // cus)
-            if rounds <= whole:
-                key = (abs(2 * a - b), a)
-                if best_key is None or key < best_key:
-                    best, best_key = a, key
-        return best
-
-    def _top_tiles(self, buf):
-        widest = max(self.plans[i].cout_pad for i in range(len(self.plans) - 3, len(self.plans) - 1))
-        return buf.batch * (-(-buf.t_out // 256)) * (-(-widest // 256))
-
-    def _split_top_ok(self, buf):
-        n = len(self.plans)
-        if not self.split_top or self.dtype != "bf16" or self.dropout_rate or n < 4 or buf.batch < 2:
-            return False
-        if self.frozen_layer_count >= n - 3 or not self.fuse_output_softmax or not self.fuse_output_backward:
-            return False
-        top = (n - 3, n - 2, n - 1)
-        if any(s0 <= i <= e0 for (s0, e0) in self.runs for i in top) or any(self.plans[i].spec.stride != 1 for i in top):
-            return False
-        if any((kind, self.specs[i].name) in self.nt_cfg for kind in ("fwd", "dgrad", "wgrad") for i in top):
-            return False
-        if any(self.specs[i].activation not in ("relu", "elu") for i in (n - 4, n - 3, n - 2)):
-            return False
-        if not buf.bwd_ready or buf.bwd1x1_ws is None or buf.labels is None:
-            return False
-        return bool(self.lib.raw("sl_output_softmax_supported")(ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size,
-                                                                self.dtype_code)) \
-            and bool(self.lib.raw("sl_conv1d_backward_1x1_supported")(ctypes.byref(buf.wgrad_geom[n - 1]),
-                                                                        self.grapheme_set_size, self.dtype_code))
-
-    def _part_geom(self, buf, kind, i, count):
-        """geometry of layer i (kind 'fwd' / 'dgrad' / 'wgrad') for `count` utterances; follows set_length like the others"""
-        g = buf.half_geoms.get((kind, i, count))
-        if g is None:
-            src = {"fwd": buf.fwd_geom, "dgrad": buf.dgrad_geom, "wgrad": buf.wgrad_geom}[kind][i]
-            g = ConvGeom()
-            for name, _ in ConvGeom._fields_:
-                setattr(g, name, getattr(src, name))
-            g.batch = count
-            buf.half_geoms[(kind, i, count)] = g
-            if kind in ("fwd", "dgrad"):  # (a part of the batch may pick more K splits: make sure the workspace covers it)
-                need = self.lib.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(g), self.dtype_code, 0)
-                if buf.nt_ws is None or buf.nt_ws.numel() < need:
-                    buf.nt_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
-                    buf.launch_lists = {}
-        return g
-
-    @staticmethod
-    def _utt_ptr(t, first):
-        """address of utterance `first` of a tensor whose first dimension is the batch"""
-        return t.data_ptr() + first * t.stride(0) * t.element_size()
-
-    def _forward_top_split(self, buf, x, st, grad_scale, a):
-        """big_conv_1, big_conv_2, output_conv + softmax and the CTC, part by part: utterances [0, a), then [a, B)"""
-        n = len(self.plans)
-        for h, (first, count) in enumerate(((0, a), (a, buf.batch - a))):
-            xin = x
-            for i in (n - 3, n - 2):
-                p = self.plans[i]
-                _, bias = self.layer_param_views(self.params, p)
-                y = buf.y[i]
-                self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", self._utt_ptr(xin, first), self.w_fwd[i].data_ptr(),
-                             bias.data_ptr(), None, self._utt_ptr(y, first),
-                             ctypes.byref(self._part_geom(buf, "fwd", i, count)),
-                             _lib.EPI_BIAS_ELU if p.spec.activation == "elu" else _lib.EPI_BIAS_RELU, self.dtype_code, 0, 0,
-                             buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-                xin = y
-            self._eager_op(self._top_part_tail, buf, h, first, count, grad_scale)
-        buf.split_pending = a
-        return buf.probs
-
-    def _top_part_tail(self, buf, h, first, count, grad_scale):
-        """output layer + softmax of one part on the main stream, then its CTC loss + gradient on a side stream.  Marshalled
-        afresh every step: the dense probability tensors (a part's offset depends on the frame count), the label tensors
-        (the staged pipeline hands over new ones per batch) and the label width are per-batch values."""
-        n = len(self.plans)
-        last = n - 1
-        p = self.plans[last]
-        k = self.grapheme_set_size
-        main = torch.cuda.current_stream(self.device)
-        if self._ctc_streams is None:
-            self._ctc_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
-        side = self._ctc_streams[h]
-        _, bias = self.layer_param_views(self.params, p)
-        dense = first * buf.t_out * k * 4  # probs / log q: [B][T'][K] floats
-        self._launch("fwd:" + p.spec.name, "sl_output_softmax", self._utt_ptr(buf.y[last - 1], first),
-                     self.w_fwd[last].data_ptr(), bias.data_ptr(), buf.probs.data_ptr() + dense, buf.logq.data_ptr() + dense,
-                     None, ctypes.byref(self._part_geom(buf, "fwd", last, count)), k, p.cout_pad, buf.tt_pad * p.cout_pad,
-                     self.ctc_epsilon, self.dtype_code, main.cuda_stream)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        labels = buf.labels if buf.labels.is_contiguous() else buf.labels.contiguous()
-        l_max = labels.shape[1]
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            self._launch("ctc", "sl_ctc_loss_grad", buf.probs.data_ptr() + dense, buf.logq.data_ptr() + dense,
-                         labels.data_ptr() + first * l_max * 4, buf.label_len.data_ptr() + first * 4,
-                         buf.input_len.data_ptr() + first * 4, buf.loss.data_ptr() + first * 4,
-                         self._utt_ptr(buf.g[last], first), count, buf.t_out, k, l_max, HALO, p.cout_pad,
-                         buf.rows * p.cout_pad, self.dtype_code, self.ctc_epsilon, grad_scale,
-                         buf.ctc_ws.data_ptr() + h * buf.ctc_half_bytes, buf.ctc_half_bytes, side.cuda_stream)
-            done = torch.cuda.Event()
-            done.record(side)
-        buf.ctc_done[h] = done
-        buf._split_labels_keepalive = labels
-
-    def _wait_ctc_half(self, buf, h, main):
-        main.wait_event(buf.ctc_done[h])
-
-    def _backward_top_split(self, buf, main, a):
-        """the input gradients of the top three layers (and the output layer's weight gradient) part by part, each part
-        behind its own CTC: the second part's lattice runs under the first part's launches here"""
-        n = len(self.plans)
-        st = main.cuda_stream
-        last = n - 1
-        for h, (first, count) in enumerate(((0, a), (a, buf.batch - a))):
-            self._eager_op(self._wait_ctc_half, buf, h, main)
-            p = self.plans[last]
-            dw, _ = self.layer_param_views(self.grads, p)
-            epi = _lib.EPI_ELU_MASK if self.specs[last - 1].activation == "elu" else _lib.EPI_RELU_MASK
-            self._launch("bwd:" + p.spec.name, "sl_conv1d_backward_1x1_part", self._utt_ptr(buf.y[last - 1], first),
-                         self._utt_ptr(buf.g[last], first), self.w_dgrad[last].data_ptr(),
-                         self._utt_ptr(buf.g[last - 1], first), dw.data_ptr(),
-                         ctypes.byref(self._part_geom(buf, "wgrad", last, count)), epi, self.grapheme_set_size,
-                         self.dtype_code, 0, h, buf.bwd1x1_ws.data_ptr(), buf.bwd1x1_ws.numel(), st)
-            for i in (n - 2, n - 3):
-                q = self.plans[i]
-                elu = self.specs[i - 1].activation == "elu"
-                self._launch("dgrad:" + q.spec.name, "sl_conv1d_nt", self._utt_ptr(buf.g[i], first), self.w_dgrad[i].data_ptr(),
-                             None, self._utt_ptr(buf.y[i - 1], first), self._utt_ptr(buf.g[i - 1], first),
-                             ctypes.byref(self._part_geom(buf, "dgrad", i, count)),
-                             _lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK, self.dtype_code, 0, 0, buf.nt_ws.data_ptr(),
-                             buf.nt_ws.numel(), st)
-
-    def _plane_geom(self, buf, kind, i, channels):
-        """the NT geometry of layer i (kind 'fwd' / 'dgrad') with its OUTPUT side describing a bf16x3 plane tensor of
-        `channels` padded channels (rows of 3 x channels behind HALO halo rows) instead of the fp32 staging buffer"""
-        g = buf.plane_geoms.get((kind, i))
-        if g is None:
-            src = (buf.fwd_geom if kind == "fwd" else buf.dgrad_geom)[i]
-            g = ConvGeom()
-            for name, _ in ConvGeom._fields_:
-                setattr(g, name, getattr(src, name))
-            g.y_row0, g.y_row_stride, g.y_batch_stride = HALO, self.planes * channels, buf.rows * channels * self.planes
-            buf.plane_geoms[(kind, i)] = g
-        return g
-
-    def _dropout_x3(self, tag, src, dst, y, channels, mode, seed, st):
-        """sl_split3_dropout over a whole plane tensor (halo rows and padding included: zeros stay zeros)"""
-        self._launch(tag, "sl_split3_dropout", src.data_ptr(), dst.data_ptr(), y.data_ptr() if y is not None else None,
-                     src.numel() // (self.planes * channels), channels, mode, self.dropout_rate, seed, st)
-
-    def _forward_x3(self, buf, st, rate=None):
-        """bf16x3: every layer = the unchanged NT kernel over the three planes.  ReLU layers: bias, ReLU and the split into
-        planes in the kernel's own epilogue (out_f32 = 2); ELU layers: fp32 into the staging buffer + sl_split3.  The last
-        layer's fp32 logits go to the softmax as on the other paths.  Dropout (training, net.py:301-303): sl_split3_dropout
-        on the packed input (into a second buffer) and in place on every activation that feeds a layer with a Dropout in
-        front of it -- the same (seed, element) keep decisions as sl_dropout draws on the single-plane paths."""
-        n = len(self.plans)
-        x = buf.x0
-        if rate:
-            self._dropout_steps += 1
-            seed0 = buf.dropout_seed0 = (self.dropout_seed * 1000003 + self._dropout_steps) * 64
-            if buf.x0_dropped is None:
-                buf.x0_dropped = torch.zeros_like(buf.x0)
-            self._dropout_x3("dropout:input", buf.x0, buf.x0_dropped, None, self.plans[0].cin_pad, 0, seed0, st)
-            x = buf.x0_dropped
-
-        def drop(p):
-            if rate and (p.index + 1) in self._dropout_layers():
-                y = buf.y[p.index]
-                self._dropout_x3("dropout:" + p.spec.name, y, y, None, p.cout_pad, 0, seed0 + p.index + 1, st)
-
-        for p in self.plans:
-            last = p.index == n - 1
-            _, bias = self.layer_param_views(self.params, p)
-            cfg = self.nt_cfg.get(("fwd", p.spec.name), 0)
-            if not last and p.spec.activation == "relu" and self.x3_fused_epilogue:
-                y = buf.y[p.index]
-                self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(),
-                             bias.data_ptr(), None, y.data_ptr(), ctypes.byref(self._plane_geom(buf, "fwd", p.index, p.cout_pad)),
-                             _lib.EPI_BIAS_RELU, self.dtype_code, 2, cfg, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-                drop(p)
-                x = y
-                continue
-            out = buf.logits if last else buf.stage32
-            self._launch("fwd:" + p.spec.name, "sl_conv1d_nt", x.data_ptr(), self.w_fwd[p.index].data_ptr(), bias.data_ptr(),
-                         None, out.data_ptr(), ctypes.byref(buf.fwd_geom[p.index]), _lib.EPI_BIAS, self.dtype_code, 1,
-                         cfg, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-            if not last:
-                y = buf.y[p.index]
-                self._launch("split:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), y.data_ptr(), None, buf.batch,
-                             buf.t_out, p.cout_pad, buf.tt_pad * p.cout_pad, HALO, buf.rows * p.cout_pad * self.planes,
-                             2 if p.spec.activation == "elu" else 1, st)
-                drop(p)
-                x = y
-        self._launch("softmax", "sl_softmax_logq", buf.logits.data_ptr(), buf.probs.data_ptr(), buf.logq.data_ptr(), buf.batch,
-                     buf.t_out, self.grapheme_set_size, self.plans[-1].cout_pad, buf.tt_pad * self.plans[-1].cout_pad,
-                     self.ctc_epsilon, st)
-        return buf.probs
 
     def _forward_eager(self, buf, rate, fuse_out, st, split_ctc=None):
         if self.planes > 1:
@@ -1376,6 +668,7 @@ class Engine:
         return [list(map(int, dec[i, :lens[i]])) for i in range(buf.batch)], buf.frame_argmax.cpu().numpy()
 
     # ------------------------------------------------------------------ loss + backward
+
     def set_labels(self, label_batch, label_lengths, prediction_lengths):
         """label_batch: int (B,Lmax) padded with anything (reference pads -1); lengths: (B,) or (B,1)."""
         buf = self.cur
@@ -1568,142 +861,6 @@ class Engine:
             # activation is post-dropout; what is left of d dropout / dx is the 1 / (1 - rate) factor
             self._launch("dropout_scale:" + p.spec.name, "sl_scale", buf.g[i - 1].data_ptr(), buf.g[i - 1].numel(),
                          self.dtype_code, 1.0 / (1.0 - self.dropout_rate), st)
-
-    def _backward_x3(self, buf, st, on_bucket_ready=None):
-        """bf16x3 backward: per layer the weight gradient of the [hi | lo] prefixes + sl_split3_wgrad_combine, the input
-        gradient through the unchanged NT kernel (fp32 staging) + sl_split3 with the activation mask.  Bias gradients:
-        row cin_pad - 1 of dW where the input carries the ones channel (hi = 1, lo = 0), sl_split3_bias_grad elsewhere (and
-        everywhere when dropout touched the ones).  Everything runs on ONE stream, so a gradient bucket (bucket_plan) is
-        complete the moment the launches of its lowest layer are enqueued: on_bucket_ready(b) is called there, exactly as
-        _backward_eager does for the single-plane paths."""
-        first = self.frozen_layer_count
-        pl = self.planes
-        ones_in = self._ones_input_layers(first)
-        ones_db = set() if buf.dropped else set(ones_in)  # rows that hold a bias gradient (else: only to be zeroed)
-        main = torch.cuda.current_stream(self.device)
-        bucket_at = {}
-        if on_bucket_ready is not None:
-            for b, (layers, _) in enumerate(self.bucket_plan()):
-                bucket_at[layers[0]] = (b, layers)
-        # the runs of identical layers (inner_conv_1..7): their 2 x 7 partial weight gradients (x planes against g_hi, against
-        # g_lo) in ONE balanced launch (sl_conv1d_wgrad_multi, a job per partial) at the lowest layer of the run -- they
-        # were 14 launches of 31 us + their reductions, 0.6 ms of the 6.8 ms step
-        multi = {}
-        if self.use_wgrad_multi:
-            for (s0, e0) in self.runs:
-                lo = max(s0, first)
-                layers = list(range(lo, e0 + 1))
-                if len(layers) >= 2 and 2 * len(layers) <= 16 and all(
-                        buf.wgrad_geom[i].cin % 256 == 0 and buf.wgrad_geom_b[i].cin % 256 == 0 and
-                        self.plans[i].cout_pad % 256 == 0 and self.plans[i].spec.stride == 1 and
-                        ("wgrad", self.specs[i].name) not in self.nt_cfg for i in layers):
-                    for i in layers:
-                        multi[i] = layers
-
-        def combine(p, ra, rb):
-            dw, _ = self.layer_param_views(self.grads, p)
-            frames = 2 if p.spec.stride == 2 else 1
-            self._launch("combine:" + p.spec.name, "sl_split3_wgrad_combine", ra.data_ptr(), rb.data_ptr(), dw.data_ptr(),
-                         p.spec.kernel_size, p.cin_pad, p.cout_pad, frames, pl * p.cin_pad if frames == 2 else 0,
-                         buf.wgrad_geom[p.index].cin, buf.wgrad_geom_b[p.index].cin, st)
-
-        for p in reversed(self.plans[first:]):
-            i = p.index
-            x = (buf.x0_dropped if buf.dropped else buf.x0) if i == 0 else buf.y[i - 1]
-            dw, db = self.layer_param_views(self.grads, p)
-            wa, wb = buf.wgrad_geom[i], buf.wgrad_geom_b[i]
-            if i in multi:
-                if i == multi[i][0]:  # every gradient tensor of the run is complete here
-                    self._launch_wgrad_multi_x3(buf, multi[i], st, combine)
-            else:
-                ra = buf.wgrad_r
-                rb = buf.wgrad_r[p.taps_view * wa.cin * p.cout_pad:]
-                g_lo = buf.g[i].data_ptr() + p.cout_pad * 2  # plane P1 of every row
-                cfg = self.nt_cfg.get(("wgrad", p.spec.name), 0)
-                self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), ra.data_ptr(),
-                             ctypes.byref(wa), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
-                self._launch("wgrad_lo:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), g_lo, rb.data_ptr(),
-                             ctypes.byref(wb), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
-                combine(p, ra, rb)
-            if i not in ones_db:
-                if self._x3_bias_ws is None:
-                    self._x3_bias_ws = torch.empty((self.lib.raw("sl_split3_bias_grad_workspace_bytes")(
-                        max(q.cout_pad for q in self.plans)),), dtype=torch.uint8, device=self.device)
-                self._launch("bgrad:" + p.spec.name, "sl_split3_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), buf.batch,
-                             buf.t_out, p.cout_pad, HALO, buf.rows * p.cout_pad * pl, self._x3_bias_ws.data_ptr(),
-                             self._x3_bias_ws.numel(), st)
-            if i in bucket_at:
-                b, layers = bucket_at[i]
-                rows = [j for j in layers if j in ones_in]
-                if rows:
-                    self._bias_grads_from_wgrad(rows, bool(ones_db), main)
-                on_bucket_ready(b)
-                if self._rec is not None:
-                    self._rec.append((2, b))
-            dropped_in = buf.dropped and i in self._dropout_layers()  # a Dropout sits between y[i - 1] and layer i
-            if i > first and self.specs[i - 1].activation == "elu" and dropped_in:
-                # a stored zero is ambiguous behind an ELU: plain input gradient, then both factors of the chain rule with the
-                # keep decisions recomputed from the step's seed (cf. sl_elu_dropout_backward)
-                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
-                             None, buf.stage32.data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_NONE, self.dtype_code, 1,
-                             self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-                self._launch("split:dgrad:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
-                             None, buf.batch, buf.t_out, p.cin_pad, buf.tt_pad * p.cin_pad, HALO,
-                             buf.rows * p.cin_pad * pl, 0, st)
-                self._dropout_x3("dropout_elu_bwd:" + p.spec.name, buf.g[i - 1], buf.g[i - 1], buf.y[i - 1], p.cin_pad, 2,
-                                 buf.dropout_seed0 + i, st)
-                continue
-            if i > first and self.specs[i - 1].activation == "relu" and self.x3_fused_epilogue:
-                # the ReLU mask (the hi plane of the stored activation) and the split into planes in the NT kernel's epilogue
-                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
-                             buf.y[i - 1].data_ptr(), buf.g[i - 1].data_ptr(),
-                             ctypes.byref(self._plane_geom(buf, "dgrad", i, p.cin_pad)), _lib.EPI_RELU_MASK, self.dtype_code,
-                             2, self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-            elif i > first:
-                self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
-                             None, buf.stage32.data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_NONE, self.dtype_code, 1,
-                             self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-                self._launch("split:dgrad:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
-                             buf.y[i - 1].data_ptr(), buf.batch, buf.t_out, p.cin_pad, buf.tt_pad * p.cin_pad, HALO,
-                             buf.rows * p.cin_pad * pl, 4 if self.specs[i - 1].activation == "elu" else 3, st)
-            if i > first and dropped_in:
-                # the ReLU mask (stored activation > 0) already applied the keep mask: the stored activation is the
-                # post-dropout one; what is left of d dropout / dx is the factor 1 / (1 - rate)
-                self._dropout_x3("dropout_scale:" + p.spec.name, buf.g[i - 1], buf.g[i - 1], None, p.cin_pad, 1, 0, st)
-        if on_bucket_ready is None and ones_in:
-            self._bias_grads_from_wgrad(ones_in, bool(ones_db), main)
-
-    def _launch_wgrad_multi_x3(self, buf, layers, st, combine):
-        """bf16x3: the partial weight gradients RA (x planes [hi | lo] against g_hi) and RB (x plane hi against g_lo) of
-        every layer of a run as jobs of one sl_conv1d_wgrad_multi launch, then sl_split3_wgrad_combine per layer"""
-        key = ("x3",) + tuple(layers)
-        entry = buf.multi_tables.get(key)
-        if entry is None:
-            sizes = [(self.plans[i].taps_view * buf.wgrad_geom[i].cin * self.plans[i].cout_pad,
-                      self.plans[i].taps_view * buf.wgrad_geom_b[i].cin * self.plans[i].cout_pad) for i in layers]
-            scratch = torch.empty((sum(a + b for a, b in sizes),), dtype=torch.float32, device=self.device)
-            table = (_lib.WgradJob * (2 * len(layers)))()
-            parts, off = [], 0
-            for n, (i, (na, nb)) in enumerate(zip(layers, sizes)):
-                ra, rb = scratch[off:off + na], scratch[off + na:off + na + nb]
-                off += na + nb
-                parts.append((ra, rb))
-                x = buf.y[i - 1]
-                for job, (g_ptr, out, geom) in zip((table[2 * n], table[2 * n + 1]),
-                                                   ((buf.g[i].data_ptr(), ra, buf.wgrad_geom[i]),
-                                                    (buf.g[i].data_ptr() + self.plans[i].cout_pad * 2, rb,
-                                                     buf.wgrad_geom_b[i]))):
-                    job.x, job.g, job.dw = x.data_ptr(), g_ptr, out.data_ptr()
-                    for name, _ in ConvGeom._fields_:
-                        setattr(job.geom, name, getattr(geom, name))
-            need = self.lib.raw("sl_conv1d_wgrad_multi_workspace_bytes")(table, len(table), self.dtype_code)
-            ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=self.device)
-            entry = buf.multi_tables[key] = (table, parts, scratch, ws)
-        table, parts, _, ws = entry
-        self._launch("wgrad:{}..{}".format(self.specs[layers[0]].name, self.specs[layers[-1]].name),
-                     "sl_conv1d_wgrad_multi", table, len(table), self.dtype_code, ws.data_ptr(), ws.numel(), st)
-        for i, (ra, rb) in zip(layers, parts):
-            combine(self.plans[i], ra, rb)
 
     def _wgrad_multi_layers(self, first, grouped=None):
         """layers whose weight gradients go into ONE sl_conv1d_wgrad_multi launch (at the lowest of them): the runs of
