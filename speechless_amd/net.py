@@ -568,6 +568,9 @@ class Wav2Letter:
 
         print_preview_batch()
         stager = None
+        if from_audio and self.use_raw_wave_input:
+            raise ValueError("from_audio=True computes spectrograms on the GPU; a raw-wave net takes the samples themselves "
+                             "(batches of (T, {}) arrays)".format(self.input_size_per_time_step))
         if from_audio:
             from .pipeline import AudioBatchStager
             if prefetch_depth <= 0:

@@ -582,6 +582,12 @@ def test_wav2letter_api_with_raw_wave_input(tmp_path):
         assert after.average_loss < before and isinstance(net.predict(batch[0]), str)
         finals.append(net)
     net = finals[0]
+    # the epoch loop through the staged input pipeline (worker-thread packing of the (T, 1) sample arrays, copy stream)
+    net.train([batch] * 6, preview_labeled_spectrogram_batch=batch[:2], tensor_board_log_directory=None,
+              net_directory=tmp_path / "nets", batches_per_epoch=3, prefetch_depth=2)
+    with pytest.raises(ValueError, match="raw-wave"):
+        net.train([batch], preview_labeled_spectrogram_batch=batch[:2], tensor_board_log_directory=None,
+                  net_directory=tmp_path / "x", batches_per_epoch=1, from_audio=True)
     net.predictive_net.save_weights(tmp_path / "w.h5")
     other = Wav2Letter(1, english_frequent_characters, use_raw_wave_input=True, seed=9, layer_sizes=sizes)
     other.predictive_net.load_weights(str(tmp_path / "w.h5"))
