@@ -86,6 +86,12 @@ class _Buffers:
         # front layer (raw-wave input): gathered sample windows [B][2 tt_pad][K_pad], the gradient w.r.t. the stack's input in
         # the pair-view layout of x0, and the three geometries of the launches around them (Engine._front_*)
         self.frames = self.gx0 = self.front_geom = self.front_dgrad_geom = None
+        self.front_src = self.front_src_dropped = None  # the samples the windows were gathered from (and their dropped copy)
+        self.front_geometry = None                       # (samples, output frames, left padding) of the current batch
+        self.front_frames_dropped = False                # frames hold the windows of DROPPED samples (last training step)
+        self.dropout_seed0 = 0                           # seed base of the last training forward with dropout
+        self._split_ok = (None, False)                   # cached Engine._split_top_ok for the engine state it was computed under
+        self._split_labels_keepalive = self._g0_keepalive = None
         if eng.front_plan is not None:
             fp = eng.front_plan
             self.frames = torch.zeros((batch, 2 * tt_pad, fp.cin_pad), dtype=dt, device=dev)

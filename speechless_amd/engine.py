@@ -560,7 +560,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         rate = self.dropout_rate if training else None
         buf.dropped = bool(rate)
         buf.split_pending = 0
-        if self.front_plan is not None and not rate and getattr(buf, "front_frames_dropped", False):
+        if self.front_plan is not None and not rate and buf.front_frames_dropped:
             self._front_gather(buf, buf.front_src)  # (the last step gathered DROPPED samples; not part of any launch list)
         fuse_out = self.fuse_output_softmax and self.dtype == "bf16" and bool(self.lib.raw("sl_output_softmax_supported")(
             ctypes.byref(buf.fwd_geom[n - 1]), self.grapheme_set_size, self.dtype_code))

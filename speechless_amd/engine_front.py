@@ -55,7 +55,7 @@ class FrontLayerMixin:
         the samples are dropped first (seed offset 63: the stack's layers use 0 .. n) and the windows gathered again."""
         fp = self.front_plan
         if rate:
-            if getattr(buf, "front_src_dropped", None) is None or buf.front_src_dropped.shape != buf.front_src.shape:
+            if buf.front_src_dropped is None or buf.front_src_dropped.shape != buf.front_src.shape:
                 buf.front_src_dropped = torch.empty_like(buf.front_src)
             self._launch("dropout:samples", "sl_dropout", buf.front_src.data_ptr(), buf.front_src_dropped.data_ptr(),
                          buf.front_src.numel(), _lib.SL_F32, rate, seed0 + 63, st)

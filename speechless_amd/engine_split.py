@@ -16,7 +16,7 @@ class SplitTopMixin:
         state = (self.split_top, bool(self.dropout_rate), self.frozen_layer_count, self.fuse_output_softmax,
                  self.fuse_output_backward, tuple(sorted(self.nt_cfg)), buf.bwd_ready, buf.bwd1x1_ws is not None,
                  buf.labels is not None)
-        if getattr(buf, "_split_ok", (None, None))[0] != state:
+        if buf._split_ok[0] != state:
             buf._split_ok = (state, self._split_top_ok(buf))
         return self._split_parts(buf) if buf._split_ok[1] else 0
 
