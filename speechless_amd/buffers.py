@@ -131,6 +131,11 @@ class _Buffers:
             self.x0[:, p0.pad_left + t_in: p0.pad_left + self._clean_in].zero_()
             if self.gx0 is not None:
                 self.gx0[:, p0.pad_left + t_in: p0.pad_left + self._clean_in].zero_()
+            if self.frames is not None:
+                # the front layer's weight gradient contracts whole 64-row chunks of `frames` against gx0, and with ELU the
+                # input-gradient launch leaves non-zero rows of gx0 just past the valid frames (elu'(0) = 1 keeps what
+                # FRONT_DGRAD_EXTRA_ROWS computes): the sample windows of a longer previous batch must not sit under them
+                self.frames[:, t_in: self._clean_in].zero_()
         if t_out < self._clean_out:
             for block in self._blocks:
                 block[:, :, HALO + t_out: HALO + self._clean_out].zero_()

@@ -173,3 +173,33 @@ def test_native_batch_packer_matches_the_numpy_packing():
         assert np.array_equal(got, want)
     with pytest.raises(ValueError):
         pack_spectrograms([rng.randn(60, 37)], np.zeros((1, 50, 37), dtype=np.float32))
+
+
+def test_bench_line_is_compact_enough_for_the_driver():
+    """the round-4 line (20 KB) could not be extracted by the driver.  The last stdout line is now a
+    summary of the full detail; fed with the round-4 detail it must stay far below the driver's limit and keep the
+    contract's keys, `roofline` and `cpu_baseline`."""
+    import json
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import bench
+    detail = json.loads((root / "profiles" / "r04_bench.json").read_text().strip().splitlines()[-1])
+    detail["_config_id"] = 3
+    detail["data_parallel"] = {"world_size": 8, "backend": "nccl", "rccl_version": "2.26.6", "bucket_bytes": [1, 2, 3],
+                               "sharded_optimizer": False, "reduced_gradients_and_weights_identical_on_all_ranks": True,
+                               "allreduce_alone_ms": 1.0, "allreduce_busbw_GBps": 100.0, "step_ms_with_allreduce": 2.2,
+                               "step_ms_without_allreduce": 2.1, "exposed_communication_ms": 0.1, "note": "x" * 500}
+    line = bench.compact_line(detail, "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < 4000, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"], key
+    for key in ("value", "unit", "cores", "kind"):
+        assert key in line["cpu_baseline"], key
+    assert "workload" in line["config"]
+    assert len(json.dumps(line["data_parallel"])) < 2000
