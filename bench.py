@@ -60,30 +60,44 @@ def synthetic_batch(rank, batch):
 LONG_BINS, LONG_BATCH, LONG_CORPUS = 257, 8, 64  # config 5: 257-bin power spectrograms, 8 utterances per GPU and step
 
 
-def long_form_batches(rank):
-    """Config 5 generator: per rank 64 utterances, T_i ~ U{2000..8000} frames (seed 3 + rank),
-    L_i <= min(200, T_i / 4), cut into length-bucketed batches of 8 (speechless_amd.batching.bucket_batches).
-    Returns [(x (8, Tmax, 257) float32 zero padded, labels, label_lengths, prediction_lengths, true_lengths)]."""
-    from speechless_amd.batching import bucket_batches, padding_waste
-    rng = np.random.RandomState(3 + rank)
-    lengths = rng.randint(2000, 8001, size=LONG_CORPUS)
-    corpus = list(range(LONG_CORPUS))
-    batches = bucket_batches(corpus, LONG_BATCH, length_of=lambda i: int(lengths[i]), shuffle=False)
+def long_form_steps(world):
+    """Config 5 step formation (SURVEY.md section 8d/e): ONE global corpus of 64 x world utterances, T_i ~ U{2000..8000}
+    frames (seed 3), cut into steps of 8 x world utterances from one length bucket and dealt to the ranks round-robin in
+    length order (speechless_amd.batching.steps_for_ranks -- the product's cross-rank balancing), every rank of a step
+    zero-padding to the step's longest utterance (batching.step_pad_length) so that all ranks launch the same grids.
+    Returns (steps, lengths, pad_lengths): steps[s][r] = utterance ids of rank r in step s."""
+    from speechless_amd.batching import step_pad_length, steps_for_ranks
+    lengths = np.random.RandomState(3).randint(2000, 8001, size=LONG_CORPUS * world)
+    steps = steps_for_ranks(list(range(LONG_CORPUS * world)), LONG_BATCH, world, length_of=lambda i: int(lengths[i]),
+                            shuffle=False)
+    return steps, lengths, [step_pad_length(step, lambda i: int(lengths[i])) for step in steps]
+
+
+def long_form_batches(rank, world=1):
+    """Rank `rank`'s batches of the config-5 steps (long_form_steps): [(x (8, T_pad, 257) float32 zero padded, labels,
+    label_lengths, prediction_lengths, true_lengths)], and the padding waste over all ranks.  An utterance's samples and
+    labels depend on its global id only (seeds 5000 + id / 7000 + id), L_i <= min(200, T_i / 4)."""
+    steps, lengths, pads = long_form_steps(world)
     out = []
-    for members in batches:
-        t_max = max(int(lengths[i]) for i in members)
-        x = np.zeros((len(members), t_max, LONG_BINS), dtype=np.float32)
+    for step, t_pad in zip(steps, pads):
+        members = step[rank]
+        x = np.zeros((len(members), t_pad, LONG_BINS), dtype=np.float32)
         lab_len = np.zeros(len(members), dtype=np.int32)
+        rows = []
         for j, i in enumerate(members):
-            x[j, :lengths[i]] = np.random.RandomState(5000 + 100 * rank + i).randn(int(lengths[i]), LONG_BINS)
+            x[j, :lengths[i]] = np.random.RandomState(5000 + i).randn(int(lengths[i]), LONG_BINS)
+            rng = np.random.RandomState(7000 + i)
             lab_len[j] = rng.randint(20, min(200, int(lengths[i]) // 4) + 1)
+            rows.append(rng.randint(0, K_CLASSES - 1, size=lab_len[j]))
         labels = -np.ones((len(members), int(lab_len.max())), dtype=np.int32)
-        for j, n in enumerate(lab_len):
-            labels[j, :n] = rng.randint(0, K_CLASSES - 1, size=n)
+        for j, row in enumerate(rows):
+            labels[j, :len(row)] = row
         true_len = np.array([int(lengths[i]) for i in members], dtype=np.int32)
         out.append((x, labels, lab_len, (true_len // 2).astype(np.int32), true_len))
-    waste = padding_waste([[int(lengths[i]) for i in members] for members in batches], length_of=lambda n: n)
-    return out, waste
+    # waste as convolved: every rank's batch padded to the step's longest utterance
+    real = float(sum(int(lengths[i]) for step in steps for b in step for i in b))
+    padded = float(sum(t_pad * sum(len(b) for b in step) for step, t_pad in zip(steps, pads)))
+    return out, 1.0 - real / padded
 
 
 def cpu_model_string():
@@ -253,7 +267,7 @@ class Bench:
         self.waste = 0.0
         if config == 5:
             eng.max_cached_shapes = 16
-            self.host_batches, self.waste = long_form_batches(rank)
+            self.host_batches, self.waste = long_form_batches(rank, world)
             self.resident = [(torch.from_numpy(x).to(device), lab, ll, pl, tl) for (x, lab, ll, pl, tl) in self.host_batches]
             self.batch_per_gpu = LONG_BATCH
             self.cursor = 0
@@ -694,7 +708,7 @@ def compact_line(detail, detail_path):
         dp = detail["data_parallel"]
         line["data_parallel"] = {k: dp[k] for k in (
             "world_size", "backend", "rccl_version", "bucket_bytes", "sharded_optimizer",
-            "reduced_gradients_and_weights_identical_on_all_ranks", "allreduce_alone_ms", "allreduce_busbw_GBps",
+            "reduced_gradients_and_weights_identical_on_all_ranks", "gradient_checksum", "weight_checksum", "allreduce_alone_ms", "allreduce_busbw_GBps",
             "step_ms_with_allreduce", "step_ms_without_allreduce", "exposed_communication_ms") if k in dp}
     if "host_buffers" in detail:
         hb = detail["host_buffers"]
@@ -798,6 +812,10 @@ def main():
                    "frames": FRAMES if args.config != 5 else "2000..8000", "mel": bench.bins,
                    "parallelism": "dp{}".format(world)},
     }
+    if args.config == 5:
+        line["config"]["step_formation"] = ("one global corpus of 64 x N utterances (seed 3), steps of 8 x N from one "
+                                            "length bucket dealt round-robin to the ranks, all ranks of a step padded to "
+                                            "the step's longest utterance (batching.steps_for_ranks)")
     line.update(result)
     if dp is not None:
         line["data_parallel"] = dp

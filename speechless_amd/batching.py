@@ -76,3 +76,14 @@ def steps_for_ranks(examples, batch_size, world_size, length_of=None, bucket_wid
         ordered = sorted(gb, key=length_of)
         steps.append([ordered[r::world_size] for r in range(world_size)])
     return steps
+
+
+def step_pad_length(step, length_of=None):
+    """The frame count every rank of a data-parallel step (one element of steps_for_ranks) pads its batch to: the step's
+    longest utterance.  Ranks dealt round-robin from one bucket differ by a few frames in their own maxima; padding all
+    of them to the same length gives every rank the same padded geometry -- the same buffer set, tile counts and launch
+    grids -- so no rank of a synchronous step runs a longer kernel sequence than the others."""
+    if length_of is None:
+        def length_of(e):
+            return e.z_normalized_transposed_spectrogram().shape[0]
+    return max(length_of(e) for batch in step for e in batch)

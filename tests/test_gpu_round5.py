@@ -46,3 +46,4 @@ def test_raw_wave_elu_shorter_batch_after_a_longer_one():
     for (dw, db), (fw, fb) in zip(grads, grads_fresh):
         assert np.array_equal(dw, fw) and np.array_equal(db, fb)
     assert np.array_equal(losses, losses_fresh)
+

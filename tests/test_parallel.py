@@ -243,6 +243,39 @@ def test_bench_two_ranks_emit_the_data_parallel_diagnostics(shard):
     dp = out["data_parallel"]
     assert dp["world_size"] == 2 and dp["reduced_gradients_and_weights_identical_on_all_ranks"] is True
     assert len(dp["bucket_bytes"]) == 3 and sum(dp["bucket_bytes"]) > 90e6 and dp["sharded_optimizer"] is shard
-    assert dp["bucket_layers"][0] == ["big_conv_2", "output_conv"] and dp["bucket_layers"][-1][0] == "striding_conv" \
-        and len(dp["bucket_layers"][-1]) == 8  # (one launch writes striding_conv + inner_conv_1..7: one bucket)
     assert dp["allreduce_alone_ms"] > 0 and dp["step_ms_with_allreduce"] > 0 and np.isfinite(dp["gradient_checksum"])
+    assert len(line) < 4000 and len(json.dumps(dp)) < 2000  # the driver extracts the LAST stdout line: it must stay small
+    full = json.loads((root / out["detail"]).read_text())["data_parallel"]  # everything else: the detail file
+    assert full["bucket_layers"][0] == ["big_conv_2", "output_conv"] and full["bucket_layers"][-1][0] == "striding_conv" \
+        and len(full["bucket_layers"][-1]) == 8  # (one launch writes striding_conv + inner_conv_1..7: one bucket)
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [3, 5])
+def test_bench_eight_ranks_control_flow(config):
+    """`bench.py --gpus 8` has never run on 8 GPUs; its control flow has -- eight ranks sharing the test
+    box's one GPU over gloo (SL_BENCH_SHARE_GPU=1, never a measurement), configurations 3 and 5: the last stdout line parses,
+    is small, names 8 GPUs and the global batch, every rank ended the step with identical weights, and for configuration 5
+    the steps came from ONE global corpus dealt across the ranks (batching.steps_for_ranks)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, SL_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--profile-steps", "1",
+           "--config", str(config)]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(root), timeout=1500)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(line) < 4000
+    out = json.loads(line)
+    per_gpu = 32 if config == 3 else 8
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 * per_gpu and out["scaling"] == "weak"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
+    dp = out["data_parallel"]
+    assert dp["world_size"] == 8 and dp["reduced_gradients_and_weights_identical_on_all_ranks"] is True
+    assert len(json.dumps(dp)) < 2000
+    if config == 5:
+        assert out["config"]["step_formation"].startswith("one global corpus")
