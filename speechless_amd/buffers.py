@@ -80,26 +80,48 @@ class _Buffers:
                 g.y_batch_stride = self.rows * p.cout_pad
             self.fwd_geom.append(g)
         # bf16x3: fp32 staging buffer of a layer's pre-activations / input gradients (sl_conv1d_nt out_f32 -> sl_split3)
-        self.stage32 = torch.empty((batch * self.tt_pad * max(p.cout_pad for p in eng.plans),), dtype=torch.float32,
-                                   device=dev) if pl > 1 else None
+        stage = batch * self.tt_pad * max(p.cout_pad for p in eng.plans)
+        if eng.front_plan is not None:  # the front layer stages its ELU pre-activations (one row per INPUT frame) and the
+            # pair rows of x0's gradient here (front_stage_geom, front_dgrad_geom)
+            stage = max(stage, batch * 2 * self.tt_pad * eng.front_plan.cout_pad,
+                        batch * (self.tt_pad + eng.FRONT_DGRAD_EXTRA_ROWS) * p0.cin_view)
+        self.stage32 = torch.empty((stage,), dtype=torch.float32, device=dev) if pl > 1 else None
         self.plane_geoms = {}  # bf16x3: (kind, layer) -> geometry whose output side describes a plane tensor
         # front layer (raw-wave input): gathered sample windows [B][2 tt_pad][K_pad], the gradient w.r.t. the stack's input in
         # the pair-view layout of x0, and the three geometries of the launches around them (Engine._front_*)
-        self.frames = self.gx0 = self.front_geom = self.front_dgrad_geom = None
+        self.frames = self.gx0 = self.front_geom = self.front_dgrad_geom = self.front_wgrad_geom_a = None
         self.front_src = self.front_src_dropped = None  # the samples the windows were gathered from (and their dropped copy)
         self.front_geometry = None                       # (samples, output frames, left padding) of the current batch
         self.front_frames_dropped = False                # frames hold the windows of DROPPED samples (last training step)
         self.dropout_seed0 = 0                           # seed base of the last training forward with dropout
         self._split_ok = (None, False)                   # cached Engine._split_top_ok for the engine state it was computed under
         self._split_labels_keepalive = self._g0_keepalive = None
+        self.frames32 = self.front_stage_geom = self.front_wgrad_geom_b = None  # bf16x3 only, see below
         if eng.front_plan is not None:
             fp = eng.front_plan
-            self.frames = torch.zeros((batch, 2 * tt_pad, fp.cin_pad), dtype=dt, device=dev)
+            self.frames = torch.zeros((batch, 2 * tt_pad, fp.cin_pad * pl), dtype=dt, device=dev)
             g = ConvGeom()
-            g.batch, g.t_out, g.taps, g.cin, g.cout = batch, 2 * tt_pad, 1, fp.cin_pad, fp.cout_pad
-            g.x_row0, g.x_row_stride, g.x_batch_stride = 0, fp.cin_pad, 2 * tt_pad * fp.cin_pad
-            g.y_row0, g.y_row_stride, g.y_batch_stride = p0.pad_left, p0.cin_pad, self.rows0 * p0.cin_pad
+            g.batch, g.t_out, g.taps, g.cin, g.cout = batch, 2 * tt_pad, 1, fp.cin_pad * pl, fp.cout_pad
+            g.x_row0, g.x_row_stride, g.x_batch_stride = 0, fp.cin_pad * pl, 2 * tt_pad * fp.cin_pad * pl
+            g.y_row0, g.y_row_stride, g.y_batch_stride = p0.pad_left, p0.cin_pad * pl, self.rows0 * p0.cin_pad * pl
             self.front_geom = g  # forward (x = frames, y = x0) and weight gradient (x = frames, "y" = gx0): t_out = input frames
+            if pl > 1:
+                # bf16x3: the windows are gathered in fp32 and split into planes (sl_wave_frames + sl_split3); an ELU front
+                # layer goes through the fp32 staging buffer (front_stage_geom) like every ELU layer of this path; the weight
+                # gradient is two launches -- the [hi | lo] prefix of the windows against gx0's hi plane (front_geom with
+                # cin = 2 K_pad) and their hi plane against gx0's lo plane (front_wgrad_geom_b) -- plus sl_split3_wgrad_combine
+                self.frames32 = torch.zeros((batch, 2 * tt_pad, fp.cin_pad), dtype=torch.float32, device=dev)
+                sg = ConvGeom()
+                for name, _ in ConvGeom._fields_:
+                    setattr(sg, name, getattr(g, name))
+                sg.y_row0, sg.y_row_stride, sg.y_batch_stride = 0, fp.cout_pad, 2 * tt_pad * fp.cout_pad
+                self.front_stage_geom = sg
+                wa, wb = ConvGeom(), ConvGeom()
+                for w in (wa, wb):
+                    for name, _ in ConvGeom._fields_:
+                        setattr(w, name, getattr(g, name))
+                wa.cin, wb.cin = 2 * fp.cin_pad, fp.cin_pad
+                self.front_wgrad_geom_a, self.front_wgrad_geom_b = wa, wb
         self.half_geoms = {}   # split top (Engine.split_top): (kind, layer) -> the layer's geometry for half the batch
         self.ctc_done = [None, None]  # split top: events behind the CTC launches of the two half-batches
         self.ctc_half_bytes = 0
@@ -160,8 +182,9 @@ class _Buffers:
             g.t_out = t_out
         for g in self.half_geoms.values():
             g.t_out = t_out
-        if self.front_geom is not None:
-            self.front_geom.t_out = t_in
+        for g in (self.front_geom, self.front_stage_geom, getattr(self, "front_wgrad_geom_a", None), self.front_wgrad_geom_b):
+            if g is not None:
+                g.t_out = t_in
         if self.front_dgrad_geom is not None:
             self.front_dgrad_geom.t_out = t_out + eng.FRONT_DGRAD_EXTRA_ROWS
         if t_out not in self._ws_sized_fwd:  # split counts (hence workspace sizes) depend on the number of time tiles
@@ -252,9 +275,15 @@ class _Buffers:
             self.gx0 = torch.zeros_like(self.x0)
             dg = ConvGeom()
             dg.batch, dg.t_out, dg.taps = self.batch, (self.t_out or 0) + eng.FRONT_DGRAD_EXTRA_ROWS, p0.taps_view
-            dg.cin, dg.cout = p0.cout_pad, p0.cin_view
-            dg.x_row0, dg.x_row_stride, dg.x_batch_stride = 0, p0.cout_pad, self.rows * p0.cout_pad
+            pl = eng.planes
+            dg.cin, dg.cout = p0.cout_pad * pl, p0.cin_view
+            dg.x_row0, dg.x_row_stride, dg.x_batch_stride = 0, p0.cout_pad * pl, self.rows * p0.cout_pad * pl
             dg.y_row0, dg.y_row_stride, dg.y_batch_stride = eng.FRONT_DGRAD_ROW0, p0.cin_view, self.rows0 * p0.cin_pad
+            if pl > 1:
+                # bf16x3: fp32 pair rows into the staging buffer (row 0 = pair row FRONT_DGRAD_ROW0; a fixed batch stride for
+                # the longest batch of this buffer set), from where sl_split3 applies the activation mask and writes the planes
+                # of the FRAME rows (a pair row of 2 cin_pad floats = two frame rows of cin_pad)
+                dg.y_row0, dg.y_batch_stride = 0, (self.tt_pad + eng.FRONT_DGRAD_EXTRA_ROWS) * p0.cin_view
             self.front_dgrad_geom = dg
         self.bias_ws = None
         self.bwd1x1_ws = None
@@ -280,17 +309,20 @@ class _Buffers:
         L.call("sl_set_available_cus", 0)
         self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
         if eng.front_plan is not None:
-            for g in (self.front_geom, self.front_dgrad_geom):
+            for g in (self.front_geom, self.front_stage_geom, self.front_dgrad_geom):
                 if g is not None:
                     need = L.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(g), eng.dtype_code, 0)
                     if self.nt_ws.numel() < need:
                         self.nt_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
                         self.launch_lists = {}
-            ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(ctypes.byref(self.front_geom), eng.dtype_code, 0))
+            for g in ((self.front_wgrad_geom_a, self.front_wgrad_geom_b) if eng.planes > 1 else (self.front_geom,)):
+                ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(ctypes.byref(g), eng.dtype_code, 0))
             bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(self.front_geom)))
         if eng.planes > 1:
             need = max(p.taps_view * (self.wgrad_geom[p.index].cin + self.wgrad_geom_b[p.index].cin) * p.cout_pad
                        for p in eng.plans[first:])
+            if eng.front_plan is not None:
+                need = max(need, 3 * eng.front_plan.cin_pad * eng.front_plan.cout_pad)
             if self.wgrad_r is None or self.wgrad_r.numel() < need:
                 self.wgrad_r = torch.empty((need,), dtype=torch.float32, device=eng.device)
             for p in eng.plans[first:]:

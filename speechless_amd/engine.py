@@ -60,8 +60,6 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         self.front_spec = None
         self.front_frozen = False
         if specs and specs[0].stride > 2:
-            if dtype == "bf16x3":
-                raise NotImplementedError("raw-wave input is implemented on the bf16 and f32 paths")
             self.front_spec = specs[0]
             specs = list(specs[1:])
             self.front_frozen = frozen_layer_count >= 1
@@ -195,6 +193,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         # the library's choosers to plan for 256 - comm_cus (sl_set_available_cus) while an exchange can be in flight -- only
         # then: forward runs with the whole chip.  0 = no hint.  Set by train_step_resident from the reducer (comm_cus).
         self.comm_cus = 0
+        self._cu_hint_active = 0  # what sl_set_available_cus was last told by this engine's backward (restored after sizing calls)
         self._ctc_streams = None
         self._rec = None
         self._adam_tables = {}
@@ -216,6 +215,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         self.comm_cus = comm_cus
         for buf in self._buffers.values():
             buf.launch_lists = {}
+            buf.multi_tables = {}  # (their workspaces are sized for the CU settings in use: rebuilt by the next backward)
+            buf.wgrad_multi_ws = None
             buf.size_nt_workspace(self, buf.fwd_geom, "fwd")
             if buf.bwd_ready:
                 buf.size_backward_workspaces(self)
@@ -476,8 +477,10 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         """(taps, input channels) the operand copies of plan p are packed with: the PAIR VIEW for a strided first layer that
         has a dgrad operand (same bytes for the forward operand; the flipped taps of the input-gradient operand are the
         pair view's 24, not the layer's 48)"""
-        if p.index == 0 and p.spec.stride == 2 and self.w_dgrad[0] is not None:
+        if p.index == 0 and p.spec.stride == 2 and self.w_dgrad[0] is not None and self.planes == 1:
             return p.taps_view, p.cin_view
+        # (bf16x3: a frame's three planes sit side by side in a row, so the pair view of the FORWARD operand is the layer's
+        # own (48, cin_pad) packing; the pair view of the input-gradient operand is packed apart, _pack_pair_dgrad_x3)
         return p.spec.kernel_size, p.cin_pad
 
     # ------------------------------------------------------------------ forward
@@ -753,21 +756,29 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
                                         self.use_wgrad_multi, self.multi_overlap_tiles, self.small_bias_pass_on_main,
                                         tuple(sorted(self.nt_cfg.items())),
                                         buf.t_out if self.planes > 1 else None)  # (bf16x3 helpers take it by value)
-        ops = self._launch_list(buf, key) if key is not None else None
-        if ops is not None:
-            self._replay(ops, on_bucket_ready)
-            return
-        record = key is not None and self.use_launch_lists and self.timeline is None and \
-            self.kernel_timeline is None and self._rec is None
-        if not record:
-            self._backward_eager(buf, main, side, on_bucket_ready)
-            return
-        self._rec = []
         try:
-            self._backward_eager(buf, main, side, on_bucket_ready)
-            buf.launch_lists[key] = self._rec
-        finally:
-            self._rec = None
+            ops = self._launch_list(buf, key) if key is not None else None
+            if ops is not None:
+                self._replay(ops, on_bucket_ready)
+                return
+            record = key is not None and self.use_launch_lists and self.timeline is None and \
+                self.kernel_timeline is None and self._rec is None
+            if not record:
+                self._backward_eager(buf, main, side, on_bucket_ready)
+                return
+            self._rec = []
+            try:
+                self._backward_eager(buf, main, side, on_bucket_ready)
+                buf.launch_lists[key] = self._rec
+            finally:
+                self._rec = None
+        except BaseException:
+            if on_bucket_ready is not None and self.comm_cus:
+                # raised between setting and clearing the CU hint: the library's setting is process-wide state shared by
+                # every engine of the process -- do not leave it behind
+                self._cu_hint_active = 0
+                self.lib.raw("sl_set_available_cus")(0)
+            raise
 
     def _grouped_wgrad_runs(self, first):
         """layer index -> (lo, hi) of the run whose weight gradients are one grouped launch (bf16 path)"""
@@ -866,6 +877,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         """layers whose weight gradients go into ONE sl_conv1d_wgrad_multi launch (at the lowest of them): the runs of
         identical layers and the striding layer below them.  The same with and without a data-parallel exchange (the step
         is then bit-identical either way); bucket_plan() closes the striding layer's bucket together with the run's."""
+        if self.planes > 1:
+            return self._wgrad_multi_layers_x3(first)
         if grouped is None:
             grouped = self._grouped_wgrad_runs(first)
         if not self.use_wgrad_multi or self.dtype != "bf16" or not grouped:
@@ -882,6 +895,17 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             layers = [0] + layers
         return layers
 
+    def _wgrad_multi_workspace_need(self, table, n_jobs):
+        """workspace of a balanced weight-gradient launch under EVERY sl_set_available_cus setting this engine launches
+        under: its segment count is 2 * CUs / tiles, so a table first used under the data-parallel CU hint would otherwise
+        get a workspace too small for a later step without the hint"""
+        need = 0
+        for hint in self.cu_hints():
+            self.lib.call("sl_set_available_cus", hint)
+            need = max(need, self.lib.raw("sl_conv1d_wgrad_multi_workspace_bytes")(table, n_jobs, self.dtype_code))
+        self.lib.call("sl_set_available_cus", self._cu_hint_active)
+        return need
+
     def _launch_wgrad_multi(self, buf, layers, st):
         key = (tuple(layers), buf.dropped)
         table = buf.multi_tables.get(key)
@@ -894,7 +918,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
                 for name, _ in ConvGeom._fields_:
                     setattr(job.geom, name, getattr(buf.wgrad_geom[i], name))
             buf.multi_tables[key] = table
-            need = self.lib.raw("sl_conv1d_wgrad_multi_workspace_bytes")(table, len(layers), self.dtype_code)
+            need = self._wgrad_multi_workspace_need(table, len(layers))
             if buf.wgrad_multi_ws is None or buf.wgrad_multi_ws.numel() < need:
                 buf.wgrad_multi_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=self.device)
         self._launch("wgrad:{}..{}".format(self.specs[layers[0]].name, self.specs[layers[-1]].name),
@@ -983,6 +1007,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
                     self._rec.append((2, b))
                 if hint and b == 0:  # from here on communication kernels may own CUs: the choosers plan for the rest
                     self._launch("cu_hint", "sl_set_available_cus", 256 - self.comm_cus)
+                    self._cu_hint_active = 256 - self.comm_cus
             if i in dchain:
                 layers = dchain[i]
                 ys, ws, masks = self._chain_table("dgrad", layers, buf)
@@ -1005,6 +1030,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
                     self._rec.append((2, b))
         if hint:
             self._launch("cu_hint", "sl_set_available_cus", 0)
+            self._cu_hint_active = 0
 
     def adam_step(self, fused=True):
         """Keras-2.0 Adam on the flat fp32 masters.  fused=True: one kernel per trainable layer that applies Adam AND
@@ -1036,6 +1062,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             for entry, i in zip(table, chunk):
                 p = self.all_plans[i]
                 wd = self.w_dgrad[p.index]
+                if self.planes > 1 and p.index == 0 and p is not self.front_plan:
+                    wd = None  # bf16x3 under a raw-wave front layer: _pack_pair_dgrad_x3 rewrites this operand
                 entry.offset = p.w_off
                 entry.w_fwd = self.w_fwd[p.index].data_ptr()
                 entry.w_dgrad = wd.data_ptr() if wd is not None else None
@@ -1056,6 +1084,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
                 self._launch(tag, "sl_split3_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(),
                              self.adam_m.data_ptr(), self.adam_v.data_ptr(), table, len(chunk), self.adam_iterations,
                              self.lr, self.beta_1, self.beta_2, self.adam_epsilon, st)
+                if 0 in chunk and self.w_dgrad[0] is not None:
+                    self._pack_pair_dgrad_x3(st)
             else:
                 self._launch(tag, "sl_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(),
                              self.adam_m.data_ptr(), self.adam_v.data_ptr(), table, len(chunk), self.dtype_code,
@@ -1118,11 +1148,15 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         """both operand copies of the given layers rewritten from the fp32 masters: one launch (sl_pack_layers)"""
         if self.planes == 3:  # bf16x3: one launch per layer
             for i in layers:
-                p = self.plans[i]
+                p = self.all_plans[i]
                 wv, _ = self.layer_param_views(self.params, p)
                 wd = self.w_dgrad[p.index]
+                pair = wd is not None and p.index == 0 and p is not self.front_plan  # (its pair view: _pack_pair_dgrad_x3)
                 self._launch("pack3:" + p.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
-                             wd.data_ptr() if wd is not None else None, p.spec.kernel_size, p.cin_pad, p.cout_pad, st)
+                             wd.data_ptr() if (wd is not None and not pair) else None, p.spec.kernel_size, p.cin_pad,
+                             p.cout_pad, st)
+                if pair:
+                    self._pack_pair_dgrad_x3(st)
             return
         layers = list(layers)
         for lo in range(0, len(layers), 16):

@@ -45,8 +45,14 @@ class FrontLayerMixin:
     def _front_gather(self, buf, src):
         fs, fp = self.front_spec, self.front_plan
         t_audio, t1, pad_l = buf.front_geometry
-        self._launch("wave_frames", "sl_wave_frames", src.data_ptr(), buf.frames.data_ptr(), buf.batch, t_audio, fs.cin,
-                     fs.kernel_size, fs.stride, pad_l, t1, fp.cin_pad, buf.frames.stride(0), self.dtype_code, self._stream())
+        if self.planes > 1:  # bf16x3: fp32 windows, then the planes [hi | lo | hi] of every window row
+            self._launch("wave_frames", "sl_wave_frames", src.data_ptr(), buf.frames32.data_ptr(), buf.batch, t_audio, fs.cin,
+                         fs.kernel_size, fs.stride, pad_l, t1, fp.cin_pad, buf.frames32.stride(0), _lib.SL_F32, self._stream())
+            self._launch("split:wave_frames", "sl_split3", buf.frames32.data_ptr(), buf.frames.data_ptr(), None, buf.batch, t1,
+                         fp.cin_pad, buf.frames32.stride(0), 0, buf.frames.stride(0), 0, self._stream())
+        else:
+            self._launch("wave_frames", "sl_wave_frames", src.data_ptr(), buf.frames.data_ptr(), buf.batch, t_audio, fs.cin,
+                         fs.kernel_size, fs.stride, pad_l, t1, fp.cin_pad, buf.frames.stride(0), self.dtype_code, self._stream())
         buf.front_frames_dropped = False
 
     def _front_forward(self, buf, rate, seed0, st):
@@ -64,6 +70,8 @@ class FrontLayerMixin:
         elif buf.front_frames_dropped:
             self._front_gather(buf, buf.front_src)
         _, bias = self.layer_param_views(self.params, fp)
+        if self.planes > 1:
+            return self._front_forward_x3(buf, bias, st)
         self._launch("fwd:" + fp.spec.name, "sl_conv1d_nt", buf.frames.data_ptr(), self.w_fwd[fp.index].data_ptr(),
                      bias.data_ptr(), None, buf.x0.data_ptr(), ctypes.byref(buf.front_geom),
                      _lib.EPI_BIAS_ELU if fp.spec.activation == "elu" else _lib.EPI_BIAS_RELU, self.dtype_code, 0, 0,
@@ -76,6 +84,8 @@ class FrontLayerMixin:
         x0 = buf.x0_dropped if buf.dropped else buf.x0
         elu = fp.spec.activation == "elu"
         elu_dropped = elu and buf.dropped
+        if self.planes > 1:
+            return self._front_backward_x3(buf, x0, elu, elu_dropped, st)
         self._launch("dgrad:" + p0.spec.name, "sl_conv1d_nt", buf.g[0].data_ptr(), self.w_dgrad[0].data_ptr(), None,
                      None if elu_dropped else x0.data_ptr(), buf.gx0.data_ptr(), ctypes.byref(buf.front_dgrad_geom),
                      _lib.EPI_NONE if elu_dropped else (_lib.EPI_ELU_MASK if elu else _lib.EPI_RELU_MASK), self.dtype_code, 0,
@@ -91,3 +101,56 @@ class FrontLayerMixin:
                      ctypes.byref(buf.front_geom), self.dtype_code, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
         self._launch("bgrad:" + fp.spec.name, "sl_bias_grad", buf.gx0.data_ptr(), db.data_ptr(), ctypes.byref(buf.front_geom),
                      self.dtype_code, buf.bias_ws.data_ptr(), buf.bias_ws.numel(), st)
+
+    # ------------------------------------------------------------------ bf16x3 (round 5)
+    def _front_forward_x3(self, buf, bias, st):
+        """wave_conv on the planes: the unchanged NT kernel over the window rows [hi | lo | hi] against [w_hi | w_hi | w_lo];
+        ReLU: bias, activation and the split into x0's planes in its epilogue (out_f32 = 2); ELU: fp32 staging + sl_split3"""
+        fp, p0 = self.front_plan, self.plans[0]
+        if fp.spec.activation == "relu" and self.x3_fused_epilogue:
+            self._launch("fwd:" + fp.spec.name, "sl_conv1d_nt", buf.frames.data_ptr(), self.w_fwd[fp.index].data_ptr(),
+                         bias.data_ptr(), None, buf.x0.data_ptr(), ctypes.byref(buf.front_geom), _lib.EPI_BIAS_RELU,
+                         self.dtype_code, 2, 0, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+            return
+        self._launch("fwd:" + fp.spec.name, "sl_conv1d_nt", buf.frames.data_ptr(), self.w_fwd[fp.index].data_ptr(),
+                     bias.data_ptr(), None, buf.stage32.data_ptr(), ctypes.byref(buf.front_stage_geom), _lib.EPI_BIAS,
+                     self.dtype_code, 1, 0, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
+        self._launch("split:" + fp.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.x0.data_ptr(), None, buf.batch,
+                     buf.front_geom.t_out, fp.cout_pad, buf.front_stage_geom.y_batch_stride, p0.pad_left, buf.x0.stride(0),
+                     2 if fp.spec.activation == "elu" else 1, st)
+
+    def _front_backward_x3(self, buf, x0, elu, elu_dropped, st):
+        """x0's gradient: the pair-view NT launch over the planes of g[0] (flipped pair taps, _pack_pair_dgrad_x3) into the
+        fp32 staging buffer, sl_split3 through the stored activation of wave_conv into gx0's planes FRAME row by frame row
+        (a pair row of 2 cin_pad floats is two frame rows); then wave_conv's weight gradient as the two partial launches of
+        this path + sl_split3_wgrad_combine, and its bias gradient"""
+        fp, p0 = self.front_plan, self.plans[0]
+        pl = self.planes
+        dg = buf.front_dgrad_geom
+        self._launch("dgrad:" + p0.spec.name, "sl_conv1d_nt", buf.g[0].data_ptr(), self.w_dgrad[0].data_ptr(), None, None,
+                     buf.stage32.data_ptr(), ctypes.byref(dg), _lib.EPI_NONE, self.dtype_code, 1, 0, buf.nt_ws.data_ptr(),
+                     buf.nt_ws.numel(), st)
+        mode = 0 if elu_dropped else (4 if elu else 3)
+        self._launch("split:dgrad:" + p0.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.gx0.data_ptr(),
+                     None if elu_dropped else x0.data_ptr(), buf.batch, 2 * dg.t_out, p0.cin_pad, dg.y_batch_stride,
+                     2 * self.FRONT_DGRAD_ROW0, buf.gx0.stride(0), mode, st)
+        if elu_dropped:
+            self._dropout_x3("dropout_elu_bwd:" + p0.spec.name, buf.gx0, buf.gx0, x0, p0.cin_pad, 2, buf.dropout_seed0, st)
+        elif buf.dropped:
+            self._dropout_x3("dropout_scale:" + p0.spec.name, buf.gx0, buf.gx0, None, p0.cin_pad, 1, 0, st)
+        dw, db = self.layer_param_views(self.grads, fp)
+        ra = buf.wgrad_r
+        rb = buf.wgrad_r[2 * fp.cin_pad * fp.cout_pad:]
+        g_lo = buf.gx0.data_ptr() + p0.cin_pad * 2  # plane P1 of every row
+        self._launch("wgrad:" + fp.spec.name, "sl_conv1d_wgrad", buf.frames.data_ptr(), buf.gx0.data_ptr(), ra.data_ptr(),
+                     ctypes.byref(buf.front_wgrad_geom_a), self.dtype_code, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+        self._launch("wgrad_lo:" + fp.spec.name, "sl_conv1d_wgrad", buf.frames.data_ptr(), g_lo, rb.data_ptr(),
+                     ctypes.byref(buf.front_wgrad_geom_b), self.dtype_code, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
+        self._launch("combine:" + fp.spec.name, "sl_split3_wgrad_combine", ra.data_ptr(), rb.data_ptr(), dw.data_ptr(), 1,
+                     fp.cin_pad, fp.cout_pad, 1, 0, 2 * fp.cin_pad, fp.cin_pad, st)
+        if self._x3_bias_ws is None:
+            self._x3_bias_ws = torch.empty((self.lib.raw("sl_split3_bias_grad_workspace_bytes")(
+                max(q.cout_pad for q in self.plans)),), dtype=torch.uint8, device=self.device)
+        self._launch("bgrad:" + fp.spec.name, "sl_split3_bias_grad", buf.gx0.data_ptr(), db.data_ptr(), buf.batch,
+                     buf.front_geom.t_out, fp.cout_pad, p0.pad_left, buf.gx0.stride(0), self._x3_bias_ws.data_ptr(),
+                     self._x3_bias_ws.numel(), st)

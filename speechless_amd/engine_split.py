@@ -80,7 +80,11 @@ class SplitTopMixin:
             g.batch = count
             buf.half_geoms[(kind, i, count)] = g
             if kind in ("fwd", "dgrad"):  # (a part of the batch may pick more K splits: make sure the workspace covers it)
-                need = self.lib.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(g), self.dtype_code, 0)
+                need = 0
+                for hint in self.cu_hints():
+                    self.lib.call("sl_set_available_cus", hint)
+                    need = max(need, self.lib.raw("sl_conv1d_nt_workspace_bytes")(ctypes.byref(g), self.dtype_code, 0))
+                self.lib.call("sl_set_available_cus", self._cu_hint_active)
                 if buf.nt_ws is None or buf.nt_ws.numel() < need:
                     buf.nt_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
                     buf.launch_lists = {}
@@ -91,9 +95,20 @@ class SplitTopMixin:
         """address of utterance `first` of a tensor whose first dimension is the batch"""
         return t.data_ptr() + first * t.stride(0) * t.element_size()
 
+    def _presize_parts(self, buf, kinds, a):
+        """Creates the part geometries of the top layers for both parts BEFORE any launch of a (possibly recorded) sequence
+        reads buf.nt_ws: _part_geom may have to re-allocate that workspace, and a launch already appended to the list being
+        recorded would keep the freed pointer.  Sized under every CU setting in use."""
+        n = len(self.plans)
+        for count in (a, buf.batch - a):
+            for kind in kinds:
+                for i in (n - 3, n - 2):
+                    self._part_geom(buf, kind, i, count)
+
     def _forward_top_split(self, buf, x, st, grad_scale, a):
         """big_conv_1, big_conv_2, output_conv + softmax and the CTC, part by part: utterances [0, a), then [a, B)"""
         n = len(self.plans)
+        self._presize_parts(buf, ("fwd", "dgrad") if buf.bwd_ready else ("fwd",), a)
         for h, (first, count) in enumerate(((0, a), (a, buf.batch - a))):
             xin = x
             for i in (n - 3, n - 2):
@@ -130,7 +145,12 @@ class SplitTopMixin:
                      self.ctc_epsilon, self.dtype_code, main.cuda_stream)
         ready = torch.cuda.Event()
         ready.record(main)
-        labels = buf.labels if buf.labels.is_contiguous() else buf.labels.contiguous()
+        # ONE contiguous copy per step, made for the first part and kept until the next step's first part replaces it (by
+        # then both parts' CTC launches have been waited for by backward): a copy per part would free part 0's while its
+        # lattice may still be reading it
+        if h == 0 or buf._split_labels_keepalive is None:
+            buf._split_labels_keepalive = buf.labels if buf.labels.is_contiguous() else buf.labels.contiguous()
+        labels = buf._split_labels_keepalive
         l_max = labels.shape[1]
         with torch.cuda.stream(side):
             side.wait_event(ready)
@@ -143,7 +163,6 @@ class SplitTopMixin:
             done = torch.cuda.Event()
             done.record(side)
         buf.ctc_done[h] = done
-        buf._split_labels_keepalive = labels
 
     def _wait_ctc_half(self, buf, h, main):
         main.wait_event(buf.ctc_done[h])
@@ -154,6 +173,7 @@ class SplitTopMixin:
         n = len(self.plans)
         st = main.cuda_stream
         last = n - 1
+        self._presize_parts(buf, ("dgrad",), a)
         for h, (first, count) in enumerate(((0, a), (a, buf.batch - a))):
             self._eager_op(self._wait_ctc_half, buf, h, main)
             p = self.plans[last]

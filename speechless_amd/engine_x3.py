@@ -15,12 +15,29 @@ class X3Mixin:
         one launch per layer (sl_split3_pack_weights; the five-launch sequence it replaces -- split, two packs, two
         assembles -- was 55 launches and 0.45 ms of a 7.1 ms optimisation step)."""
         st = self._stream()
-        for p in self.plans:
+        for p in self.all_plans:  # (the raw-wave front layer included; a striding layer with a dgrad operand: its pair view)
             wv, _ = self.layer_param_views(self.params, p)
             wd = self.w_dgrad[p.index]
+            if p.index == 0 and p is not self.front_plan:
+                wd = None  # (only there under a front layer, and then in the pair view: _pack_pair_dgrad_x3 below)
+            k, cin = self._pack_dims(p)
             self._launch("pack3:" + p.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
-                         wd.data_ptr() if wd is not None else None, p.spec.kernel_size, p.cin_pad, p.cout_pad, st)
+                         wd.data_ptr() if wd is not None else None, k, cin, p.cout_pad, st)
+        if self.w_dgrad[0] is not None:
+            self._pack_pair_dgrad_x3(st)
         self._packed_dirty = False
+
+    def _pack_pair_dgrad_x3(self, st):
+        """the input-gradient operand of the striding layer under a raw-wave front layer: the PAIR VIEW of its taps (24 flipped
+        pair taps x 2 cin_pad pair channels, rows [w_hi | w_hi | w_lo] over the output channels) -- sl_split3_pack_weights on
+        the pair view of the masters; the forward operand it writes beside it goes to a scratch buffer (the layer's real
+        forward operand is packed with its own 48 taps: a frame's planes are contiguous in a row of the input buffer)"""
+        p0 = self.plans[0]
+        if getattr(self, "_w_fwd0_pair_scratch", None) is None:
+            self._w_fwd0_pair_scratch = torch.empty_like(self.w_fwd[0])
+        wv, _ = self.layer_param_views(self.params, p0)
+        self._launch("pack3_pair:" + p0.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self._w_fwd0_pair_scratch.data_ptr(),
+                     self.w_dgrad[0].data_ptr(), p0.taps_view, p0.cin_view, p0.cout_pad, st)
 
     def _plane_geom(self, buf, kind, i, channels):
         """the NT geometry of layer i (kind 'fwd' / 'dgrad') with its OUTPUT side describing a bf16x3 plane tensor of
@@ -48,9 +65,13 @@ class X3Mixin:
         front of it -- the same (seed, element) keep decisions as sl_dropout draws on the single-plane paths."""
         n = len(self.plans)
         x = buf.x0
+        seed0 = 0
         if rate:
             self._dropout_steps += 1
             seed0 = buf.dropout_seed0 = (self.dropout_seed * 1000003 + self._dropout_steps) * 64
+        if self.front_plan is not None:
+            self._front_forward(buf, rate, seed0, st)
+        if rate:
             if buf.x0_dropped is None:
                 buf.x0_dropped = torch.zeros_like(buf.x0)
             self._dropout_x3("dropout:input", buf.x0, buf.x0_dropped, None, self.plans[0].cin_pad, 0, seed0, st)
@@ -108,17 +129,13 @@ class X3Mixin:
         # the runs of identical layers (inner_conv_1..7): their 2 x 7 partial weight gradients (x planes against g_hi, against
         # g_lo) in ONE balanced launch (sl_conv1d_wgrad_multi, a job per partial) at the lowest layer of the run -- they
         # were 14 launches of 31 us + their reductions, 0.6 ms of the 6.8 ms step
+        # Round 5: the striding layer's two partials (0.18 + 0.18 ms as 128 x 128-tile launches with utterance-granular batch
+        # splits) are jobs of the same launch when they fit its 256-wide tiles (_wgrad_multi_layers_x3; bucket_plan() then
+        # closes the striding layer's bucket together with the run's, as on the bf16 path).
         multi = {}
-        if self.use_wgrad_multi:
-            for (s0, e0) in self.runs:
-                lo = max(s0, first)
-                layers = list(range(lo, e0 + 1))
-                if len(layers) >= 2 and 2 * len(layers) <= 16 and all(
-                        buf.wgrad_geom[i].cin % 256 == 0 and buf.wgrad_geom_b[i].cin % 256 == 0 and
-                        self.plans[i].cout_pad % 256 == 0 and self.plans[i].spec.stride == 1 and
-                        ("wgrad", self.specs[i].name) not in self.nt_cfg for i in layers):
-                    for i in layers:
-                        multi[i] = layers
+        launch_layers = self._wgrad_multi_layers_x3(first)
+        for i in launch_layers:
+            multi[i] = launch_layers
 
         def combine(p, ra, rb):
             dw, _ = self.layer_param_views(self.grads, p)
@@ -192,11 +209,44 @@ class X3Mixin:
                 self._dropout_x3("dropout_scale:" + p.spec.name, buf.g[i - 1], buf.g[i - 1], None, p.cin_pad, 1, 0, st)
         if on_bucket_ready is None and ones_in:
             self._bias_grads_from_wgrad(ones_in, bool(ones_db), main)
+        if self.front_plan is not None and first == 0 and not self.front_frozen:
+            self._front_backward(buf, st)
+            if on_bucket_ready is not None:  # the front layer's parameters: the last bucket of bucket_plan()
+                b = len(self.bucket_plan()) - 1
+                on_bucket_ready(b)
+                if self._rec is not None:
+                    self._rec.append((2, b))
+
+    def _wgrad_multi_layers_x3(self, first):
+        """bf16x3: the layers whose 2 partial weight gradients each are jobs of ONE sl_conv1d_wgrad_multi launch at the lowest
+        of them: the first run of identical layers (16 jobs at most) and, when jobs are left, the striding layer below it.
+        Shapes only (the same for every buffer set): x operands of whole 256-wide tiles -- or, for the striding layer's pair
+        view, a last tile overlapping its neighbour (multi_overlap_tiles) -- against 256-wide output tiles."""
+        if not self.use_wgrad_multi or not self.runs:
+            return []
+        pl = self.planes
+        s0, e0 = self.runs[0]
+        lo = max(s0, first)
+        layers = list(range(lo, e0 + 1))
+
+        def fits_run(i):
+            p = self.plans[i]  # A: the [hi | lo] prefix (2 cin_pad) against g_hi, B: x_hi (cin_pad) against g_lo
+            return p.cin_pad % 256 == 0 and p.cout_pad % 256 == 0 and p.spec.stride == 1 and \
+                ("wgrad", self.specs[i].name) not in self.nt_cfg
+        if len(layers) < 2 or 2 * len(layers) > 16 or not all(fits_run(i) for i in layers):
+            return []
+        p0 = self.plans[0]
+        cin0 = p0.cin_view * pl  # the pair view's whole row (planes of two frames) is the x operand of both partials
+        if first == 0 and lo == 1 and p0.spec.stride == 2 and 2 * (len(layers) + 1) <= 16 and cin0 >= 256 and \
+                cin0 % (64 if self.multi_overlap_tiles else 256) == 0 and p0.cout_pad % 256 == 0 and \
+                ("wgrad", self.specs[0].name) not in self.nt_cfg:
+            layers = [0] + layers
+        return layers
 
     def _launch_wgrad_multi_x3(self, buf, layers, st, combine):
         """bf16x3: the partial weight gradients RA (x planes [hi | lo] against g_hi) and RB (x plane hi against g_lo) of
         every layer of a run as jobs of one sl_conv1d_wgrad_multi launch, then sl_split3_wgrad_combine per layer"""
-        key = ("x3",) + tuple(layers)
+        key = ("x3", buf.dropped) + tuple(layers)
         entry = buf.multi_tables.get(key)
         if entry is None:
             sizes = [(self.plans[i].taps_view * buf.wgrad_geom[i].cin * self.plans[i].cout_pad,
@@ -208,7 +258,7 @@ class X3Mixin:
                 ra, rb = scratch[off:off + na], scratch[off + na:off + na + nb]
                 off += na + nb
                 parts.append((ra, rb))
-                x = buf.y[i - 1]
+                x = (buf.x0_dropped if buf.dropped else buf.x0) if i == 0 else buf.y[i - 1]
                 for job, (g_ptr, out, geom) in zip((table[2 * n], table[2 * n + 1]),
                                                    ((buf.g[i].data_ptr(), ra, buf.wgrad_geom[i]),
                                                     (buf.g[i].data_ptr() + self.plans[i].cout_pad * 2, rb,
@@ -216,7 +266,7 @@ class X3Mixin:
                     job.x, job.g, job.dw = x.data_ptr(), g_ptr, out.data_ptr()
                     for name, _ in ConvGeom._fields_:
                         setattr(job.geom, name, getattr(geom, name))
-            need = self.lib.raw("sl_conv1d_wgrad_multi_workspace_bytes")(table, len(table), self.dtype_code)
+            need = self._wgrad_multi_workspace_need(table, len(table))
             ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=self.device)
             entry = buf.multi_tables[key] = (table, parts, scratch, ws)
         table, parts, _, ws = entry

@@ -266,7 +266,9 @@ def test_bf16x3_data_parallel_step_through_rccl_single_rank(shard_optimizer):
             torch.cuda.synchronize()
             if use_reducer:
                 nb = len(eng.bucket_plan())
-                assert nb == 4 and announced == list(range(nb)) * 3, announced
+                # (round 5: the striding layer's partial weight gradients are jobs of the run's balanced launch -> one bucket)
+                merged = eng._wgrad_multi_layers(0)[:1] == [0]
+                assert nb == (3 if merged else 4) and announced == list(range(nb)) * 3, announced
             results.append((np.stack(losses), [w.copy() for w, _ in eng.get_weights()]))
     finally:
         if created:
@@ -495,7 +497,7 @@ def _wave_case(b=3, t_audio=24055, seed=6, cin=1, activation="relu"):
                 prediction_lengths=pred_len, k=29)
 
 
-@pytest.mark.parametrize("dtype,cin", [("f32", 1), ("bf16", 1), ("f32", 2)])
+@pytest.mark.parametrize("dtype,cin", [("f32", 1), ("bf16", 1), ("f32", 2), ("bf16x3", 1), ("bf16x3", 2)])
 def test_raw_wave_input_against_the_float64_oracle(dtype, cin):
     """use_raw_wave_input=True (reference net.py:310-312): `wave_conv` -- 250 filters, 250 taps, stride 160, SAME padding, over
     the samples -- in front of striding_conv, 12 layers, input-to-prediction ratio 320.  The front layer runs as a GEMM over
@@ -526,7 +528,12 @@ def test_raw_wave_input_against_the_float64_oracle(dtype, cin):
         assert len(grads) == 12 and grads[0][0].shape == (250, cin, 250)
         errs = [max(rel_l2(dw, rw), rel_l2(db, rb)) for (dw, db), (rw, rb) in zip(grads, ref["grads"])]
         _report("raw_wave_gradient_errors_{}_cin{}_t{}".format(dtype, cin, t_audio), errs)
-        if dtype == "f32":
+        if dtype == "bf16x3":  # round 5: the fast parity path takes the front layer too (planes, three MFMA terms per product)
+            np.testing.assert_allclose(losses, ref["losses"], rtol=2e-5)
+            assert errs[-1] < 5e-4 and max(errs) < 2e-2, errs
+            decoded, _ = eng.greedy_decode(pred_len)
+            assert decoded == o.greedy_decode_indices(ref["probs"], pred_len)
+        elif dtype == "f32":
             np.testing.assert_allclose(losses, ref["losses"], rtol=2e-5)
             # flip-aware as everywhere on the fp32 path: the top of the stack tight, a prefix below the first flipped ReLU
             # decision looser (75 output frames per utterance)
