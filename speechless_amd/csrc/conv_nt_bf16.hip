@@ -293,6 +293,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if !defined(SL_NO_PRIO_YOUNG)
+    // static priority for the second-dispatched half of the waves (MI355X_MICROARCH.md, "two waves per SIMD", item 4: the younger
+    // wave of a SIMD loses every issue arbitration): same-box A/B of the config-3 step 2.2475 -> 2.2374 ms, three alternations
+    // of the two builds, every one in favour (profiles/r05_prio_young_ab.txt)
+    if (wave >= (int)(blockDim.x >> 7)) __builtin_amdgcn_s_setprio(1);
+#endif
     const int wm = wave / WN;  // which block of time rows
     const int wn = wave % WN;  // which 64-channel block (co)
 
@@ -723,6 +729,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if !defined(SL_NO_PRIO_YOUNG)
+    // static priority for the second-dispatched half of the waves (MI355X_MICROARCH.md, "two waves per SIMD", item 4: the younger
+    // wave of a SIMD loses every issue arbitration): same-box A/B of the config-3 step 2.2475 -> 2.2374 ms, three alternations
+    // of the two builds, every one in favour (profiles/r05_prio_young_ab.txt)
+    if (wave >= (int)(blockDim.x >> 7)) __builtin_amdgcn_s_setprio(1);
+#endif
     const int wm = wave / WN;
     const int wn = wave % WN;
 
