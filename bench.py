@@ -504,8 +504,9 @@ class Bench:
                             "from the committed file named in traffic_source -- rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE "
                             "in separate passes (tools/pmc_traffic.sh), Infinity-Cache hits included, average of the "
                             "kernel's launches per step",
-            "duration_source": "live: HIP events recorded by the library immediately around the kernel on its launch "
-                               "stream (sl_profile_next_kernel) in otherwise un-instrumented steps of THIS run",
+            "duration_source": "live: HIP events attached by the library to the kernel's own dispatch (sl_profile_next_kernel, "
+                               "hipExtLaunchKernelGGL: the kernel's begin / end timestamps) in otherwise un-instrumented "
+                               "steps of THIS run",
             "rocprof_avg_launch_ms": rocprof_ms, "rocprof_calls": rocprof_calls, "rocprof_source": rocprof_source,
             "frac_from_rocprof": (dom_flops / (rocprof_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS) if rocprof_ms else None,
             "duration_note": "avg_launch_ms / frac are measured live in this run; rocprof_avg_launch_ms is the same kernel's "

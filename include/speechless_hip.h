@@ -76,10 +76,11 @@ typedef struct sl_conv_geom {
 int sl_version(void);
 const char* sl_last_error(void);
 
-/* Measurement hook (bench.py's roofline leg): the two HIP events (hipEvent_t, created with timing enabled) are recorded on
- * the launch stream immediately before and after the MAIN kernel of the next sl_conv1d_nt / sl_conv1d_wgrad /
- * sl_conv1d_wgrad_grouped call -- not around its split-K epilogue or reduction tail -- and the hook disarms itself.  The
- * duration between them is what `rocprofv3 --kernel-trace --stats` reports for that kernel.  Either pointer may be NULL. */
+/* Measurement hook (bench.py's roofline leg): the two HIP events (hipEvent_t, created with timing enabled) are attached to
+ * the dispatch of the MAIN kernel of the next sl_conv1d_nt / sl_conv1d_wgrad / sl_conv1d_wgrad_grouped call
+ * (hipExtLaunchKernelGGL: they carry the kernel's own begin and end timestamps) -- not to its split-K epilogue or reduction
+ * tail -- and the hook disarms itself.  The duration between them is what `rocprofv3 --kernel-trace --stats` reports for
+ * that kernel.  Either pointer may be NULL. */
 int sl_profile_next_kernel(void* start_event, void* stop_event);
 
 /* ---- conv forward and input-gradient (both are the same row-shifted NT GEMM) ---------------------------------

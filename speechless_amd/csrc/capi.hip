@@ -22,13 +22,10 @@ extern "C" int sl_profile_next_kernel(void* start_event, void* stop_event) {
     g_prof_stop = (hipEvent_t)stop_event;
     return SL_OK;
 }
-void sl_prof_begin(hipStream_t s) {
-    if (g_prof_start) (void)hipEventRecord(g_prof_start, s);
-    g_prof_start = nullptr;
-}
-void sl_prof_end(hipStream_t s) {
-    if (g_prof_stop) (void)hipEventRecord(g_prof_stop, s);
-    g_prof_stop = nullptr;
+void sl_prof_take(hipEvent_t* start, hipEvent_t* stop) {
+    *start = g_prof_start;
+    *stop = g_prof_stop;
+    g_prof_start = g_prof_stop = nullptr;
 }
 extern "C" const char* sl_last_error(void) { return g_last_error; }
 

@@ -1,6 +1,7 @@
 // common.h -- shared device/host helpers for the gfx950 kernels of the speechless hot path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -28,10 +29,21 @@ void sl_set_error(const char* fmt, ...);
         }                                       \
     } while (0)
 
-// measurement hook (sl_profile_next_kernel, capi.hip): HIP events recorded on the launch stream immediately around the
-// MAIN kernel of the next sl_conv1d_nt / sl_conv1d_wgrad[_grouped] call (not around its split-K / reduction tail)
-void sl_prof_begin(hipStream_t s);
-void sl_prof_end(hipStream_t s);
+// measurement hook (sl_profile_next_kernel, capi.hip): HIP events attached to the MAIN kernel of the next sl_conv1d_nt /
+// sl_conv1d_wgrad[_grouped] call (not to its split-K / reduction tail)
+void sl_prof_take(hipEvent_t* start, hipEvent_t* stop);
+// Launch of a call's MAIN kernel.  When events are armed they are attached to the dispatch itself (hipExtLaunchKernelGGL): they
+// carry the kernel's own begin / end timestamps -- the duration rocprofv3 --kernel-trace reports for it.  (Until round 4 the
+// events were recorded on the stream in front of and behind the launch, which adds the dispatch gap: 10 % on a 0.2 ms kernel.)
+#define SL_LAUNCH_MAIN(kernel, grid, block, lds, s, ...)                                         \
+    do {                                                                                         \
+        hipEvent_t sl_e0_, sl_e1_;                                                               \
+        sl_prof_take(&sl_e0_, &sl_e1_);                                                          \
+        if (sl_e0_ != nullptr || sl_e1_ != nullptr)                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, s, sl_e0_, sl_e1_, 0, __VA_ARGS__);  \
+        else                                                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                        \
+    } while (0)
 
 static inline int sl_check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -359,12 +359,10 @@ int conv1x1_bwd_bf16(const void* x, const void* gr, const void* w_dgrad, void* d
     a.slabs = (float*)ws;
     const int grid = xcd_grid(a.splits * a.n_cb);
     const int lds = SLOTS * SLOT_BYTES;
-    sl_prof_begin(s);
     if (epilogue == SL_EPI_ELU_MASK)
-        hipLaunchKernelGGL((conv1x1_bwd_kernel<SL_EPI_ELU_MASK>), dim3(grid), dim3(256), lds, s, a);
+        SL_LAUNCH_MAIN((conv1x1_bwd_kernel<SL_EPI_ELU_MASK>), dim3(grid), dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL((conv1x1_bwd_kernel<SL_EPI_RELU_MASK>), dim3(grid), dim3(256), lds, s, a);
-    sl_prof_end(s);
+        SL_LAUNCH_MAIN((conv1x1_bwd_kernel<SL_EPI_RELU_MASK>), dim3(grid), dim3(256), lds, s, a);
     int rc = sl_check_launch("sl_conv1d_backward_1x1");
     if (rc != SL_OK) return rc;
     const int n4 = g->cin * (KC / 4);

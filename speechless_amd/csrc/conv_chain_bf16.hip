@@ -510,11 +510,9 @@ int conv_chain_bf16(const void* x, void* const* ys, const void* const* ws, const
         attr_set = true;
     }
     const dim3 grid(a.batch * a.t_tiles);
-    sl_prof_begin(s);
     if (epilogue == SL_EPI_RELU_MASK)
-        hipLaunchKernelGGL(conv_chain_bf16_kernel<true>, grid, dim3(512), CHAIN_LDS, s, a);
+        SL_LAUNCH_MAIN(conv_chain_bf16_kernel<true>, grid, dim3(512), CHAIN_LDS, s, a);
     else
-        hipLaunchKernelGGL(conv_chain_bf16_kernel<false>, grid, dim3(512), CHAIN_LDS, s, a);
-    sl_prof_end(s);
+        SL_LAUNCH_MAIN(conv_chain_bf16_kernel<false>, grid, dim3(512), CHAIN_LDS, s, a);
     return sl_check_launch("sl_conv1d_chain");
 }

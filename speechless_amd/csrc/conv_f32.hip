@@ -244,9 +244,7 @@ int launch_nt_mfma(F32NtArgs a, int t_out, hipStream_t s) {
     a.n_tiles = a.n_tiles * FT / MT;
     a.chunks = a.chunks * FK / MK;
     a.nsteps = a.nsteps * FK / MK;
-    sl_prof_begin(s);
-    hipLaunchKernelGGL((conv_nt_f32_mfma_kernel<EPI>), dim3(a.batch * a.t_tiles * a.n_tiles), dim3(256), 0, s, a);
-    sl_prof_end(s);
+    SL_LAUNCH_MAIN((conv_nt_f32_mfma_kernel<EPI>), dim3(a.batch * a.t_tiles * a.n_tiles), dim3(256), 0, s, a);
     return sl_check_launch("sl_conv1d_nt(f32, mfma)");
 }
 
@@ -492,12 +490,10 @@ int wgrad_tn_f32(const void* x, const void* gr, float* dw, const sl_conv_geom* g
     a.b_per_split = (g->batch + splits - 1) / splits;
     a.split_stride = (long)g->taps * g->cin * g->cout;
     a.out = splits > 1 ? ws : dw;
-    sl_prof_begin(s);
     if (tile == MT)
-        hipLaunchKernelGGL(wgrad_tn_f32_mfma_kernel, dim3(a.tiles * splits), dim3(256), 0, s, a);
+        SL_LAUNCH_MAIN(wgrad_tn_f32_mfma_kernel, dim3(a.tiles * splits), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(wgrad_tn_f32_kernel, dim3(a.tiles * splits), dim3(256), 0, s, a);
-    sl_prof_end(s);
+        SL_LAUNCH_MAIN(wgrad_tn_f32_kernel, dim3(a.tiles * splits), dim3(256), 0, s, a);
     int rc = sl_check_launch("sl_conv1d_wgrad(f32)");
     if (rc != SL_OK) return rc;
     if (splits > 1) return wgrad_reduce(ws, dw, a.split_stride, splits, s);

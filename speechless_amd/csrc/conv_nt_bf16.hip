@@ -1632,9 +1632,7 @@ int launch_main(const NtArgs& a, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             attr_set = true;
         }
-        sl_prof_begin(s);
-        hipLaunchKernelGGL((conv_nt_ks2_bf16_kernel<(STAGES & 7), MODE, OUT_F32>), dim3(grid), dim3(512), LDS_BYTES, s, a);
-        sl_prof_end(s);
+        SL_LAUNCH_MAIN((conv_nt_ks2_bf16_kernel<(STAGES & 7), MODE, OUT_F32>), dim3(grid), dim3(512), LDS_BYTES, s, a);
         return sl_check_launch("sl_conv1d_nt(bf16, k-half pairs)");
     } else if constexpr (!M32 && IT >= 100) {  // slab variant: IT - 100 is the real IT (IT - 200: interleaved schedule)
         constexpr bool ILV = IT >= 200;
@@ -1647,10 +1645,8 @@ int launch_main(const NtArgs& a, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             attr_set = true;
         }
-        sl_prof_begin(s);
-        hipLaunchKernelGGL((conv_nt_slab_bf16_kernel<RIT, WM, WN, STAGES, MODE, OUT_F32, ILV>), dim3(grid),
+        SL_LAUNCH_MAIN((conv_nt_slab_bf16_kernel<RIT, WM, WN, STAGES, MODE, OUT_F32, ILV>), dim3(grid),
                            dim3(64 * WM * WN), LDS_BYTES, s, a);
-        sl_prof_end(s);
         return sl_check_launch("sl_conv1d_nt(bf16, slab)");
     } else {
         constexpr int LDS_BYTES = (STAGES & 7) * ((M32 ? 64 : 16 * IT) * WM + 64 * WN) * 128;
@@ -1661,10 +1657,8 @@ int launch_main(const NtArgs& a, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             attr_set = true;
         }
-        sl_prof_begin(s);
-        hipLaunchKernelGGL((conv_nt_bf16_kernel<M32, IT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid), dim3(64 * WM * WN),
+        SL_LAUNCH_MAIN((conv_nt_bf16_kernel<M32, IT, WM, WN, STAGES, MODE, OUT_F32>), dim3(grid), dim3(64 * WM * WN),
                            LDS_BYTES, s, a);
-        sl_prof_end(s);
         return sl_check_launch("sl_conv1d_nt(bf16)");
     }
 }

@@ -680,9 +680,7 @@ int launch_ilv32(const TnArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)wgrad_tn_ilv32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    sl_prof_begin(s);
-    hipLaunchKernelGGL(wgrad_tn_ilv32_kernel, dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(512), LDS_BYTES, s, a);
-    sl_prof_end(s);
+    SL_LAUNCH_MAIN(wgrad_tn_ilv32_kernel, dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(512), LDS_BYTES, s, a);
     return sl_check_launch("sl_conv1d_wgrad(bf16, interleaved, 4-slot ring)");
 }
 
@@ -693,9 +691,7 @@ int launch_ilv(const TnArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)wgrad_tn_ilv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    sl_prof_begin(s);
-    hipLaunchKernelGGL(wgrad_tn_ilv_kernel, dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(512), LDS_BYTES, s, a);
-    sl_prof_end(s);
+    SL_LAUNCH_MAIN(wgrad_tn_ilv_kernel, dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(512), LDS_BYTES, s, a);
     return sl_check_launch("sl_conv1d_wgrad(bf16, interleaved)");
 }
 
@@ -945,10 +941,8 @@ int launch(const TnArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    sl_prof_begin(s);
-    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<WM, WN, STAGES>), dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(64 * WM * WN),
+    SL_LAUNCH_MAIN((wgrad_tn_bf16_kernel<WM, WN, STAGES>), dim3(xcd_grid(a.tiles * a.splits * a.groups)), dim3(64 * WM * WN),
                        LDS_BYTES, s, a);
-    sl_prof_end(s);
     return sl_check_launch("sl_conv1d_wgrad(bf16)");
 }
 
@@ -1198,9 +1192,7 @@ int wgrad_multi_bf16(const sl_wgrad_job* jobs, int n_jobs, void* ws, size_t ws_b
         (void)hipFuncSetAttribute((const void*)wgrad_tn_ilv_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    sl_prof_begin(s);
-    hipLaunchKernelGGL(wgrad_tn_ilv_multi_kernel, dim3(xcd_grid(a.workers)), dim3(512), LDS_BYTES, s, a);
-    sl_prof_end(s);
+    SL_LAUNCH_MAIN(wgrad_tn_ilv_multi_kernel, dim3(xcd_grid(a.workers)), dim3(512), LDS_BYTES, s, a);
     rc = sl_check_launch("sl_conv1d_wgrad_multi");
     if (rc != SL_OK) return rc;
     hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3(64, a.total_tiles), dim3(256), 0, s, a);

@@ -6,6 +6,7 @@ TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+cp gpurun_out/bench_detail.json gpurun_out/${TAG}_bench_detail.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -o p -- python bench.py --no-cpu-baseline --no-also > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_prof.err
 cp gpurun_out/${TAG}_prof/*kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
 TAG=$TAG bash tools/pmc_traffic.sh > gpurun_out/${TAG}_pmc_traffic.log 2>&1
