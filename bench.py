@@ -346,8 +346,12 @@ class Bench:
         """ms per step of the MAIN kernel(s) behind each tag: events recorded by the library immediately around that
         kernel on its stream (sl_profile_next_kernel), nothing else instrumented"""
         eng = self.eng
+        # the timeline pass before this one launched eagerly (gaps between the kernels, the chip clocks down in them): a few
+        # un-instrumented steps from the recorded lists bring the chip back to the state of the timed region first
+        for _ in range(10):
+            self.step()
         eng.kernel_timeline = (set(tags), [])
-        n_steps = self.args.profile_steps if self.config != 5 else len(self.resident)
+        n_steps = max(10, self.args.profile_steps) if self.config != 5 else len(self.resident)
         for _ in range(n_steps):
             self.step()
         self.torch.cuda.synchronize()

@@ -129,13 +129,10 @@ class X3Mixin:
         # the runs of identical layers (inner_conv_1..7): their 2 x 7 partial weight gradients (x planes against g_hi, against
         # g_lo) in ONE balanced launch (sl_conv1d_wgrad_multi, a job per partial) at the lowest layer of the run -- they
         # were 14 launches of 31 us + their reductions, 0.6 ms of the 6.8 ms step
-        # Round 5: the striding layer's two partials (0.18 + 0.18 ms as 128 x 128-tile launches with utterance-granular batch
-        # splits) are jobs of the same launch when they fit its 256-wide tiles (_wgrad_multi_layers_x3; bucket_plan() then
-        # closes the striding layer's bucket together with the run's, as on the bf16 path).
         multi = {}
-        launch_layers = self._wgrad_multi_layers_x3(first)
-        for i in launch_layers:
-            multi[i] = launch_layers
+        for launch_layers in self._x3_multi_runs(first):
+            for i in launch_layers:
+                multi[i] = launch_layers
 
         def combine(p, ra, rb):
             dw, _ = self.layer_param_views(self.grads, p)
@@ -218,30 +215,30 @@ class X3Mixin:
                     self._rec.append((2, b))
 
     def _wgrad_multi_layers_x3(self, first):
-        """bf16x3: the layers whose 2 partial weight gradients each are jobs of ONE sl_conv1d_wgrad_multi launch at the lowest
-        of them: the first run of identical layers (16 jobs at most) and, when jobs are left, the striding layer below it.
-        Shapes only (the same for every buffer set): x operands of whole 256-wide tiles -- or, for the striding layer's pair
-        view, a last tile overlapping its neighbour (multi_overlap_tiles) -- against 256-wide output tiles."""
-        if not self.use_wgrad_multi or not self.runs:
-            return []
-        pl = self.planes
-        s0, e0 = self.runs[0]
-        lo = max(s0, first)
-        layers = list(range(lo, e0 + 1))
+        """bf16x3: no launch writes the weight gradients of the striding layer AND of a run (bucket_plan() merges nothing)"""
+        return []
 
-        def fits_run(i):
-            p = self.plans[i]  # A: the [hi | lo] prefix (2 cin_pad) against g_hi, B: x_hi (cin_pad) against g_lo
-            return p.cin_pad % 256 == 0 and p.cout_pad % 256 == 0 and p.spec.stride == 1 and \
-                ("wgrad", self.specs[i].name) not in self.nt_cfg
-        if len(layers) < 2 or 2 * len(layers) > 16 or not all(fits_run(i) for i in layers):
-            return []
-        p0 = self.plans[0]
-        cin0 = p0.cin_view * pl  # the pair view's whole row (planes of two frames) is the x operand of both partials
-        if first == 0 and lo == 1 and p0.spec.stride == 2 and 2 * (len(layers) + 1) <= 16 and cin0 >= 256 and \
-                cin0 % (64 if self.multi_overlap_tiles else 256) == 0 and p0.cout_pad % 256 == 0 and \
-                ("wgrad", self.specs[0].name) not in self.nt_cfg:
-            layers = [0] + layers
-        return layers
+    def _x3_multi_runs(self, first):
+        """bf16x3: the runs of identical layers whose 2 partial weight gradients per layer are jobs of ONE
+        sl_conv1d_wgrad_multi launch at the lowest layer of the run (16 jobs at most): x operands of whole 256-wide tiles
+        against 256-wide output tiles.  Shapes only (the same for every buffer set)."""
+        out = []
+        if not self.use_wgrad_multi:
+            return out
+        for (s0, e0) in self.runs:
+            lo = max(s0, first)
+            layers = list(range(lo, e0 + 1))
+
+            def fits_run(i):
+                p = self.plans[i]  # A: the [hi | lo] prefix (2 cin_pad) against g_hi, B: x_hi (cin_pad) against g_lo
+                return p.cin_pad % 256 == 0 and p.cout_pad % 256 == 0 and p.spec.stride == 1 and \
+                    ("wgrad", self.specs[i].name) not in self.nt_cfg
+            if len(layers) >= 2 and 2 * len(layers) <= 16 and all(fits_run(i) for i in layers):
+                # (round 5: striding_conv's two partials as jobs of the same launch -- 144 more tiles over the 768-wide pair
+                # rows -- were measured SLOWER: 6.328 against 6.215 ms per config-3 step in a same-box A/B,
+                # profiles/r05_x3_multi_striding_ab.txt; they stay two 128 x 128-tile launches)
+                out.append(layers)
+        return out
 
     def _launch_wgrad_multi_x3(self, buf, layers, st, combine):
         """bf16x3: the partial weight gradients RA (x planes [hi | lo] against g_hi) and RB (x plane hi against g_lo) of

@@ -266,9 +266,7 @@ def test_bf16x3_data_parallel_step_through_rccl_single_rank(shard_optimizer):
             torch.cuda.synchronize()
             if use_reducer:
                 nb = len(eng.bucket_plan())
-                # (round 5: the striding layer's partial weight gradients are jobs of the run's balanced launch -> one bucket)
-                merged = eng._wgrad_multi_layers(0)[:1] == [0]
-                assert nb == (3 if merged else 4) and announced == list(range(nb)) * 3, announced
+                assert nb == 4 and announced == list(range(nb)) * 3, announced
             results.append((np.stack(losses), [w.copy() for w, _ in eng.get_weights()]))
     finally:
         if created:

@@ -162,8 +162,7 @@ def _engine_worker(rank, world, port, out_dir, shard=False, dtype="f32"):
     eng = Engine(specs, 29, dtype=dtype, device="cuda:0", lr=1e-3)
     eng.set_weights(weights)
     ranges = eng.bucket_ranges()
-    # fp32 path: 4 buckets; bf16x3 since round 5: 3 (striding_conv's partials are jobs of the inner run's balanced launch)
-    assert len(ranges) == (3 if dtype == "bf16x3" else 4) and sum(hi - lo for lo, hi in ranges) == eng.param_numel
+    assert len(ranges) == 4 and sum(hi - lo for lo, hi in ranges) == eng.param_numel  # (fp32 / bf16x3 paths: 4 buckets) cover every parameter
     reducer = GradBucketReducer(eng.grads, ranges, shard_optimizer=shard)
     lo, hi = shard_range(x.shape[0], rank, world)
     for _ in range(2):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(3, 5),
                     help="3: the resident 32 x 1000-frame step; 5: bench.py's long-form bucketed batches (8 x 2000..8000 x 257)")
     ap.add_argument("--force-split", action="store_true", help="split_top on every geometry (not only where the rule says)")
+    ap.add_argument("--dtype", default="bf16", help="config 3 only: bf16 | bf16x3 | f32")
     args = ap.parse_args()
     import torch
     if args.config == 5:
@@ -29,7 +30,7 @@ def main():
     from speechless_amd.engine import Engine, wav2letter_layer_specs
     from speechless_amd.net import Wav2Letter
     specs = wav2letter_layer_specs(128, 29)
-    eng = Engine(specs, 29, dtype="bf16")
+    eng = Engine(specs, 29, dtype=args.dtype)
     eng.set_weights(Wav2Letter._glorot_uniform(specs, 2))
     rng = np.random.RandomState(0)
     b = 32
@@ -60,6 +61,8 @@ def main():
     for _ in range(args.reps):
         for value in (True, False):
             setattr(eng, args.attr, value)
+            for buf in eng._buffers.values():  # (attributes that change the launch sequence: lists and job tables are rebuilt)
+                buf.launch_lists, buf.multi_tables = {}, {}
             res[value].append(timed())
     for value in (True, False):
         v = res[value]
