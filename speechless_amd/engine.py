@@ -23,6 +23,7 @@ from .buffers import _Buffers
 from .engine_front import FrontLayerMixin
 from .engine_split import SplitTopMixin
 from .engine_x3 import X3Mixin
+from ._hipevents import TimingEvent
 from .plan import HALO, TIME_TILE, LayerPlan, LayerSpec, _round_up, same_padding, wav2letter_layer_specs  # noqa: F401
 
 
@@ -241,10 +242,9 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         if self.timeline is None:
             self.lib.call(name, *args)
             if self._rec is not None:  # building a launch list (see _replay): the raw entry point and its arguments
-                self._rec.append((0, self.lib.raw(name), args, name, tag))
+                self._rec.append((0, self.lib.raw(name), args, name, tag, torch.cuda.current_stream(self.device)))
             return
-        start = torch.cuda.Event(enable_timing=True)
-        stop = torch.cuda.Event(enable_timing=True)
+        start, stop = TimingEvent(), TimingEvent()  # (timestamps only: no system-scope release between the launches)
         start.record()
         self.lib.call(name, *args)
         stop.record()
@@ -259,6 +259,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             self._rec.append((1, ev, src, dst))
 
     def _replay(self, ops, callback=None):
+        if self.timeline is not None:
+            return self._replay_timeline(ops, callback)
         if self.kernel_timeline is not None:
             return self._replay_profiled(ops, callback)
         for op in ops:
@@ -273,6 +275,30 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             elif kind == 2:
                 callback(op[1])
             else:  # a step of the sequence that has to be marshalled afresh every time (pointers / sizes that change per batch)
+                op[1](*op[2])
+
+    def _replay_timeline(self, ops, callback):
+        """_replay with HIP events on the launch stream around every C-ABI call (self.timeline, bench.py's per-launch table):
+        the step still runs from its recorded lists -- marshalled eagerly, the Python between the launches starves the GPU and
+        the MFMA-bound kernels behind the gaps run at lower clocks (round 5: their durations came out 17 % above the kernel's
+        own timestamps)"""
+        out = self.timeline
+        for op in ops:
+            kind = op[0]
+            if kind == 0:
+                start, stop = TimingEvent(), TimingEvent()
+                start.record(op[5])  # (the stream the launch was recorded on: bias passes run on the side stream)
+                rc = op[1](*op[2])
+                stop.record(op[5])
+                out.append((op[4], start, stop))
+                if rc != 0:
+                    raise _lib.HipLibraryError("{} failed with status {}: {}".format(op[3], rc, self.lib.last_error()))
+            elif kind == 1:
+                op[1].record(op[2])
+                op[3].wait_event(op[1])
+            elif kind == 2:
+                callback(op[1])
+            else:
                 op[1](*op[2])
 
     def _replay_profiled(self, ops, callback):
@@ -316,9 +342,9 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
     def _launch_list(self, buf, key):
         """The recorded launch list of `key` for this buffer set, or None (then the caller runs eagerly; with
         self._rec set by start_recording() that run records the list)."""
-        if not self.use_launch_lists or self.timeline is not None or self._rec is not None:
+        if not self.use_launch_lists or self._rec is not None:
             return None
-        return buf.launch_lists.get(key)  # (with self.kernel_timeline set: replayed by _replay_profiled)
+        return buf.launch_lists.get(key)  # (with self.timeline / self.kernel_timeline set: _replay_timeline / _replay_profiled)
 
     def buffers(self, batch, t_in):
         """Buffers for batches of `batch` utterances padded to t_in frames: one set per (batch, output frames rounded
