@@ -27,11 +27,19 @@ def main():
                     help="also the bf16 path with Engine.split_top forced on every batch of >= 2 utterances, in a random split "
                          "a + (B - a) (the CTC of one part under the top layers of the other): loss within 2e-5 of the "
                          "whole-batch bf16 step, gradients within 1e-2, deterministic")
+    ap.add_argument("--wave", action="store_true",
+                    help="the raw-wave topology (use_raw_wave_input: wave_conv over --bins sample channels, 256 output filters in "
+                         "the wide layers to keep it quick): --max-frames then counts SAMPLES / 100 (1400 -> up to 140 000)")
     args = ap.parse_args()
     import torch
     from speechless_amd.engine import Engine, wav2letter_layer_specs
     from speechless_amd.net import Wav2Letter
-    specs = wav2letter_layer_specs(args.bins, 29)
+    if args.wave:
+        if args.bins > 4:
+            args.bins = 1
+        specs = wav2letter_layer_specs(args.bins, 29, use_raw_wave_input=True, out_filter_count=256)
+    else:
+        specs = wav2letter_layer_specs(args.bins, 29)
     weights = Wav2Letter._glorot_uniform(specs, 2)
     engines = {}
     for dtype in ("bf16", "f32") + (("bf16x3",) if args.x3 else ()):
@@ -43,8 +51,12 @@ def main():
         b = int(rng.randint(1, args.max_batch + 1))
         t = int(rng.choice([rng.randint(20, 80), rng.randint(80, 600), rng.randint(600, max(601, args.max_frames))]))
         t_out = -(-t // 2)
+        if args.wave:  # t input frames of the stack <- a sample count that is (mostly) no multiple of the stride
+            t = t * 160 - int(rng.randint(0, 160))
+            t_out = -(-(-(-t // 160)) // 2)
         x = rng.randn(b, t, args.bins).astype(np.float32)
-        pred_len = np.array([int(rng.randint(max(1, t_out // 3), t_out + 1)) for _ in range(b)], dtype=np.int32)
+        t_max_pred = t_out if not args.wave else max(1, t // 320)
+        pred_len = np.array([int(rng.randint(max(1, t_max_pred // 3), t_max_pred + 1)) for _ in range(b)], dtype=np.int32)
         lab_len = np.array([int(rng.randint(0, max(1, min(200, p // 2)) + 1)) for p in pred_len], dtype=np.int32)
         labels = -np.ones((b, max(1, int(lab_len.max()))), dtype=np.int32)
         for i, n in enumerate(lab_len):
