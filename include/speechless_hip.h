@@ -376,7 +376,9 @@ int sl_adam_pack_layer(float* param, const float* grad, float* m, float* v, void
  *   sl_split3_assemble   rows of `width` bf16: dst[r] = [a[r] | a[r] | b[r]]
  *   sl_split3_wgrad_combine  RA = sl_conv1d_wgrad of (x planes [hi | lo ...], g_hi), RB = of (x planes [hi ...], g_lo), float
  *                        [taps / frames][r*_cin][c_out] -> dw[tap][ci][co] = hh + hl + lh;  frames = 2, fstride = 3 * c_in for
- *                        the pair view of a stride-2 layer (two frames' planes per row)
+ *                        the pair view of a stride-2 layer (two frames' planes per row); rb_fstride = the frame stride inside
+ *                        RB's rows (= fstride, or c_in when RB's x operand was the [hi of frame 0 | hi of frame 1] window
+ *                        in the middle of the pair row)
  *   sl_split3_bias_grad  db[co] = sum over valid frames of g_hi + g_lo (two stages, fixed order; workspace from
  *                        sl_split3_bias_grad_workspace_bytes) */
 int sl_split3(const float* src, void* dst, const void* mask, int batch, int t_out, int channels, int64_t src_batch_stride,
@@ -395,7 +397,7 @@ int sl_split3_pack_weights(const float* w_master, void* w_fwd3, void* w_dgrad3, 
 int sl_split3_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers, int n_layers,
                                int step, float lr, float beta1, float beta2, float eps, void* stream);
 int sl_split3_wgrad_combine(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out, int frames,
-                            int fstride, int ra_cin, int rb_cin, void* stream);
+                            int fstride, int ra_cin, int rb_cin, int rb_fstride, void* stream);
 size_t sl_split3_bias_grad_workspace_bytes(int channels);
 int sl_split3_bias_grad(const void* g, float* db, int batch, int t_out, int channels, int g_row0, int64_t g_batch_stride,
                         void* workspace, size_t workspace_bytes, void* stream);

@@ -125,7 +125,7 @@ SIGNATURES = {
     "sl_split3_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sl_split3_adam_pack_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AdamLayer), c_int, c_int, c_float,
                                            c_float, c_float, c_float, c_void_p]),
-    "sl_split3_wgrad_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    "sl_split3_wgrad_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),
     "sl_split3_bias_grad_workspace_bytes": (c_size_t, [c_int]),
     "sl_split3_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, ctypes.c_uint64, c_void_p]),

@@ -241,12 +241,18 @@ class _Buffers:
             if pl > 1:
                 # bf16x3: two launches.  A: the [hi | lo] prefix of x against g_hi (hh and lh in one (2 Cin) x Cout product),
                 # B: x_hi against g_lo (hl); sl_split3_wgrad_combine adds the three blocks.  The pair view of the striding
-                # layer has the planes of two frames in a row, so there the whole row is the x operand of both.
+                # layer has the planes of two frames in a row -- [hi0 | lo0 | hi0 | hi1 | lo1 | hi1] -- so there A takes the row
+                # up to lo1 (five planes where that is a whole number of 128-wide tiles, else all six) and B the window
+                # [hi0 | hi1] in its middle (Engine.x3_b_window: x pointer + 2 cin_pad, frame stride cin_pad inside RB): two
+                # planes instead of six (round 5; the whole row for both was 0.18 + 0.18 ms at config 3)
                 wb = ConvGeom()
                 for name, _ in ConvGeom._fields_:
                     setattr(wb, name, getattr(wg, name))
-                wg.cin = p.cin_view * pl if p.index == 0 else 2 * p.cin_pad
-                wb.cin = p.cin_view * pl if p.index == 0 else p.cin_pad
+                if p.index == 0:
+                    wg.cin = 5 * p.cin_pad if (eng.x3_b_window and (5 * p.cin_pad) % 128 == 0) else p.cin_view * pl
+                    wb.cin = 2 * p.cin_pad if eng.x3_b_window else p.cin_view * pl
+                else:
+                    wg.cin, wb.cin = 2 * p.cin_pad, p.cin_pad
                 self.wgrad_geom_b[p.index] = wb
             if p.index > first:
                 dg = ConvGeom()

@@ -147,12 +147,13 @@ __global__ __launch_bounds__(256) void assemble3_kernel(const unsigned short* __
     *(u32x4*)(o + 2 * width) = vb;
 }
 
-// dw[tap][ci][co] = RA[tap'][f * fstride + ci][co] + RB[tap'][f * fstride + ci][co] + RA[tap'][f * fstride + c_in + ci][co],
+// dw[tap][ci][co] = RA[tap'][f * fstride + ci][co] + RB[tap'][f * rb_fstride + ci][co] + RA[tap'][f * fstride + c_in + ci][co],
 // tap = frames * tap' + f.  RA = weight gradient of (x planes, g_hi), RB = of (x planes, g_lo), both float
-// [taps / frames][r_cin][c_out]: the hh, hl and lh terms.
+// [taps / frames][r_cin][c_out]: the hh, hl and lh terms.  (rb_fstride: the x operand of RB may be a narrower window of the
+// row than RA's -- the two hi planes that meet in the middle of a pair row of the striding layer.)
 __global__ __launch_bounds__(256) void wgrad_combine3_kernel(const float* __restrict__ ra, const float* __restrict__ rb,
                                                              float* __restrict__ dw, int taps, int c_in, int c_out,
-                                                             int frames, int fstride, int ra_cin, int rb_cin) {
+                                                             int frames, int fstride, int ra_cin, int rb_cin, int rb_fstride) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= (long)taps * c_in * c_out) return;
     const int co = (int)(i % c_out);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void wgrad_combine3_kernel(const float* __rest
     const int ci = (int)(rest % c_in), tap = (int)(rest / c_in);
     const int tv = tap / frames, f = tap % frames;
     const float* a = ra + ((long)tv * ra_cin + f * fstride + ci) * c_out + co;
-    const float* b = rb + ((long)tv * rb_cin + f * fstride + ci) * c_out + co;
+    const float* b = rb + ((long)tv * rb_cin + f * rb_fstride + ci) * c_out + co;
     const f32x4 hh = *(const f32x4*)a, hl = *(const f32x4*)b, lh = *(const f32x4*)(a + (long)c_in * c_out);
     *(f32x4*)(dw + i) = (hh + hl) + lh;
 }
@@ -326,13 +327,14 @@ extern "C" int sl_split3_assemble(const void* a, const void* b, void* dst, int64
 }
 
 extern "C" int sl_split3_wgrad_combine(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out,
-                                       int frames, int fstride, int ra_cin, int rb_cin, void* stream) {
+                                       int frames, int fstride, int ra_cin, int rb_cin, int rb_fstride, void* stream) {
     SL_CHECK_ARG(ra && rb && dw && taps > 0 && c_in > 0 && c_out > 0 && c_out % 4 == 0 && (frames == 1 || frames == 2) &&
-                     taps % frames == 0 && ra_cin >= (frames - 1) * fstride + 2 * c_in && rb_cin >= (frames - 1) * fstride + c_in,
+                     taps % frames == 0 && fstride >= 0 && rb_fstride >= 0 && ra_cin >= (frames - 1) * fstride + 2 * c_in &&
+                     rb_cin >= (frames - 1) * rb_fstride + c_in,
                  "sl_split3_wgrad_combine: bad arguments");
     const long n4 = (long)taps * c_in * c_out / 4;
     hipLaunchKernelGGL(wgrad_combine3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ra, rb,
-                       dw, taps, c_in, c_out, frames, fstride, ra_cin, rb_cin);
+                       dw, taps, c_in, c_out, frames, fstride, ra_cin, rb_cin, rb_fstride);
     return sl_check_launch("sl_split3_wgrad_combine");
 }
 

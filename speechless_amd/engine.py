@@ -166,6 +166,9 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         self.multi_overlap_tiles = True
         self.small_bias_pass_on_main = os.environ.get("SL_BIAS_MAIN", "1") != "0"  # A/B knob
         self.x3_fused_epilogue = os.environ.get("SL_X3_FUSED_EPILOGUE", "1") != "0"  # bf16x3: activation + plane split in the NT epilogue
+        # bf16x3, striding layer: the g_lo partial of its weight gradient against the [hi0 | hi1] window of the pair rows
+        # instead of the whole row (buffers.py; A/B knob, read when a buffer set's backward geometries are built)
+        self.x3_b_window = os.environ.get("SL_X3_B_WINDOW", "1") != "0"
         self.nt_cfg = {}  # optional per-launch tile configuration overrides {("fwd"|"dgrad", layer name): cfg word}
         # Launch lists: the ~60 C-ABI calls and 4 stream hand-overs of a step are recorded the first time a buffer set
         # runs them and replayed afterwards with their arguments already marshalled -- the Python around each launch

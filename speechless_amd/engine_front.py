@@ -147,7 +147,7 @@ class FrontLayerMixin:
         self._launch("wgrad_lo:" + fp.spec.name, "sl_conv1d_wgrad", buf.frames.data_ptr(), g_lo, rb.data_ptr(),
                      ctypes.byref(buf.front_wgrad_geom_b), self.dtype_code, 0, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
         self._launch("combine:" + fp.spec.name, "sl_split3_wgrad_combine", ra.data_ptr(), rb.data_ptr(), dw.data_ptr(), 1,
-                     fp.cin_pad, fp.cout_pad, 1, 0, 2 * fp.cin_pad, fp.cin_pad, st)
+                     fp.cin_pad, fp.cout_pad, 1, 0, 2 * fp.cin_pad, fp.cin_pad, 0, st)
         if self._x3_bias_ws is None:
             self._x3_bias_ws = torch.empty((self.lib.raw("sl_split3_bias_grad_workspace_bytes")(
                 max(q.cout_pad for q in self.plans)),), dtype=torch.uint8, device=self.device)
