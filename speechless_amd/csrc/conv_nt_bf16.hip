@@ -1777,6 +1777,13 @@ Cfg auto_cfg(const sl_conv_geom* g) {
     // eight waves in k-half pairs 18.4, interleaved slab 19.5-20.4: profiles/r01j_tune_kernels.json, r01j_nt_scaling.json);
     // striding_conv 48.5 us (54.0)
     Cfg c{2, 2, 11, 1, 4, 0, 0, 0, 1};
+#if !defined(SL_NO_WIDE_ROW_SLAB)
+    // rows of >= 512 input channels under several taps (the inner layers on the bf16x3 path: 7 taps x 768 plane channels, 84
+    // steps): the interleaved SLAB variant of the same tile -- a chunk's activation rows brought into LDS once for all taps --
+    // 50.1 against 55.0 us back to back (54.5 for the k-half pairs below; at 256 channels the order is the other way round:
+    // 19.8 against 18.5); tools/nt_wide_cost.py --taps 7 --cout 256 --cins 256,768, round 5
+    if (g->taps >= 3 && g->taps <= 33 && g->cin >= 512 && nsteps >= 64) return Cfg{2, 2, 11, 1, 4, 0, 0, 1, 1};
+#endif
     // long contractions on this tile (striding_conv: 96 steps): the eight-wave k-half-pair variant's shorter step
     // outweighs its dearer epilogue (49.5 vs 51.7 us right behind the producer of the input)
     if (nsteps >= 64 && g->cout % 128 == 0) c.ks2 = 1;
