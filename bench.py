@@ -662,7 +662,11 @@ def tracked_rocprof_average(kernel_substring, pattern="r*_kernel_stats.csv"):
     """(average launch ms, calls, file) of the kernel in the newest tracked rocprofv3 --kernel-trace --stats summary under
     profiles/ -- printed beside the live HIP-event duration so that `roofline.frac` can be recomputed from profiles/."""
     import csv
-    files = sorted((f for f in (ROOT / "profiles").glob(pattern) if "config" not in f.name), reverse=True)
+    import re
+    # r05_kernel_stats.csv, r01k_kernel_stats.csv ... -- not the statistics of other configurations / paths (r05_kernel_stats_config5.csv,
+    # r05_kernel_stats_bf16x3.csv)
+    files = sorted((f for f in (ROOT / "profiles").glob(pattern) if re.fullmatch(r"r\d+[a-z]?_kernel_stats\.csv", f.name)),
+                   reverse=True)
     for f in files:
         try:
             with open(f, newline="") as fh:
