@@ -203,3 +203,8 @@ def test_bench_line_is_compact_enough_for_the_driver():
         assert key in line["cpu_baseline"], key
     assert "workload" in line["config"]
     assert len(json.dumps(line["data_parallel"])) < 2000
+    # the tracked rocprofv3 average printed beside the live duration comes from the config-3 bf16 statistics, not from the files
+    # of other configurations / arithmetic paths kept next to them
+    ms, calls, source = bench.tracked_rocprof_average("wgrad_tn_ilv_kernel")
+    import re
+    assert re.fullmatch(r"profiles/r\d+[a-z]?_kernel_stats\.csv", source) and 0.15 < ms < 0.30 and calls > 0, (ms, calls, source)
