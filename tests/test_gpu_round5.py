@@ -166,3 +166,30 @@ def test_random_shapes_through_the_raw_wave_topology():
                           "--max-frames", "400", "--max-batch", "4"], capture_output=True, text=True, cwd=str(root), timeout=600)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
     assert "all 10 cases passed" in res.stdout
+
+
+def test_wav2letter_api_with_raw_wave_input_on_the_bf16x3_path(tmp_path):
+    """Wav2Letter(use_raw_wave_input=True, compute_dtype="bf16x3"): the reference's constructor surface on the fast parity path --
+    training steps lower the loss, predict() returns text, an HDF5 checkpoint with the `wave_conv` layer round-trips into the
+    fp32 path and both paths then give the same greedy transcription and the same loss to 1e-5."""
+    from speechless_amd import Wav2Letter, english_frequent_characters
+    from speechless_amd.net import Adam, LabeledSpectrogram
+    rng = np.random.RandomState(4)
+    words = ["she", "was", "abc", "a", "zoo"]
+    batch = [LabeledSpectrogram(id="u{}".format(i), label=" ".join(rng.choice(words, size=rng.randint(1, 3))),
+                                spectrogram=0.1 * rng.randn(int(rng.randint(9000, 12000)), 1)) for i in range(4)]
+    sizes = dict(out_filter_count=256)
+    net = Wav2Letter(1, english_frequent_characters, use_raw_wave_input=True, optimizer=Adam(1e-3), seed=5,
+                     compute_dtype="bf16x3", layer_sizes=sizes)
+    assert net.input_to_prediction_length_ratio == 320 and net.engine.dtype == "bf16x3"
+    before = net.test_and_predict_batch(batch).average_loss
+    for _ in range(10):
+        net.train_on_batch(batch)
+    after = net.test_and_predict_batch(batch)
+    assert after.average_loss < before and isinstance(net.predict(batch[0]), str)
+    net.predictive_net.save_weights(tmp_path / "w.h5")
+    other = Wav2Letter(1, english_frequent_characters, use_raw_wave_input=True, seed=9, compute_dtype="f32", layer_sizes=sizes)
+    other.predictive_net.load_weights(str(tmp_path / "w.h5"))
+    same = other.test_and_predict_batch(batch)
+    assert [r.predicted for r in same.results] == [r.predicted for r in after.results]
+    np.testing.assert_allclose([r.loss for r in same.results], [r.loss for r in after.results], rtol=1e-5)
