@@ -112,6 +112,13 @@ __device__ __forceinline__ void wait_frags(bf16x8 (&a)[4], bf16x8 (&b)[2]) {
                  : "n"(CNT));
 }
 
+// fp32 -> bf16 in the main epilogue: v_cvt_pk_bf16_f32 (round to nearest even like the software form, which costs five VALU
+// instructions per value: 640 of a wave's epilogue at the 256 x 256 tile)
+#if defined(SL_NT_SOFT_PACK)
+#define SL_NT_PACK pack_bf16x2
+#else
+#define SL_NT_PACK pack_bf16x2_hw
+#endif
 enum { MODE_PARTIAL = 100 };  // besides the SL_EPI_* values: raw fp32 accumulators to the split-K workspace
 
 __device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
@@ -208,8 +215,8 @@ __device__ __forceinline__ void store_run16(const NtArgs& a, float (&v)[16], con
         u32x4 p0, p1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            p0[i] = pack_bf16x2(v[i * 2], v[i * 2 + 1]);
-            p1[i] = pack_bf16x2(v[8 + i * 2], v[8 + i * 2 + 1]);
+            p0[i] = SL_NT_PACK(v[i * 2], v[i * 2 + 1]);
+            p1[i] = SL_NT_PACK(v[8 + i * 2], v[8 + i * 2 + 1]);
         }
         *(u32x4*)(yo) = p0;  // (nontemporal stores measured: step 2.35 vs 2.30 ms)
         *(u32x4*)(yo + 8) = p1;
