@@ -591,15 +591,17 @@ class Bench:
         bucket_bytes = [int((hi - lo) * 4) for lo, hi in ranges]
         scratch = torch.zeros_like(eng.grads)
         per_bucket_ms = []
+        # (the shared-GPU test hook moves the bytes through gloo on the host: two repetitions there, not thirteen)
+        warm_reps, timed_reps = (1, 1) if os.environ.get("SL_BENCH_SHARE_GPU") == "1" else (3, 10)
         for lo, hi in ranges:
-            for _ in range(3):
+            for _ in range(warm_reps):
                 dist.all_reduce(scratch[lo:hi])
             self.sync()
             t1 = time.perf_counter()
-            for _ in range(10):
+            for _ in range(timed_reps):
                 dist.all_reduce(scratch[lo:hi])
             self.sync()
-            per_bucket_ms.append((time.perf_counter() - t1) / 10 * 1e3)
+            per_bucket_ms.append((time.perf_counter() - t1) / timed_reps * 1e3)
         del scratch
         ar_ms = sum(per_bucket_ms)
         alg = sum(bucket_bytes) / (ar_ms * 1e-3) / 1e9
@@ -615,6 +617,9 @@ class Bench:
                 "bucket_bytes": bucket_bytes, "bucket_layers": [[self.names[i] for i in layers]
                                                                  for layers, _ in eng.bucket_plan()],
                 "sharded_optimizer": bool(reducer.shard_optimizer),
+                "options": {"comm_cus": int(reducer.comm_cus), "compress": reducer.compress,
+                            "split_last_bucket": bool(eng.split_last_bucket),
+                            "rccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))}},
                 "reduced_gradients_and_weights_identical_on_all_ranks": same,
                 "gradient_checksum": float(gathered[0][0].item()), "weight_checksum": float(gathered[0][2].item()),
                 "allreduce_alone_ms": ar_ms, "allreduce_alone_ms_per_bucket": per_bucket_ms,
@@ -721,6 +726,8 @@ def compact_line(detail, detail_path):
             "world_size", "backend", "rccl_version", "bucket_bytes", "sharded_optimizer",
             "reduced_gradients_and_weights_identical_on_all_ranks", "gradient_checksum", "weight_checksum", "allreduce_alone_ms", "allreduce_busbw_GBps",
             "step_ms_with_allreduce", "step_ms_without_allreduce", "exposed_communication_ms") if k in dp}
+        if "options" in dp:  # (the knobs of tools/first_dp_run.sh; the RCCL environment stays in the detail file)
+            line["data_parallel"]["options"] = {k: v for k, v in dp["options"].items() if k != "rccl_env"}
     if "host_buffers" in detail:
         hb = detail["host_buffers"]
         line["host_buffers"] = {k: hb[k] for k in ("h2d_ms_per_step", "utterances_per_sec_including_h2d_serial")}
@@ -770,6 +777,15 @@ def main():
                     help="N > 1: reduce-scatter the gradient buckets, Adam on this rank's slice, all-gather the masters "
                          "(speechless_amd/parallel.py) instead of all-reduce + full Adam on every rank")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra event-instrumented steps for the roofline leg")
+    # knobs of the data-parallel exchange for the first real N > 1 run (tools/first_dp_run.sh sweeps them; defaults = the
+    # configuration every figure in DESIGN.md was taken with)
+    ap.add_argument("--comm-cus", type=int, default=None,
+                    help="N > 1: CUs the collectives are expected to own while a bucket is on the wire (0 = no hint; default "
+                         "SL_COMM_CUS or 0): backward's grid choosers plan for the rest (sl_set_available_cus)")
+    ap.add_argument("--compress", choices=("bf16",), default=None, help="N > 1: gradients travel as bf16 (half the bytes per link)")
+    ap.add_argument("--split-last-bucket", action="store_true",
+                    help="N > 1: close inner_conv_4..7's gradients as a bucket of their own (Engine.split_last_bucket: the "
+                         "fused input-gradient launch and the balanced weight-gradient launch cut in two)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -802,7 +818,10 @@ def main():
     def reducer_factory(eng):
         if world == 1:
             return None
-        return GradBucketReducer(eng.grads, eng.bucket_ranges(), shard_optimizer=args.shard_optimizer)
+        if args.split_last_bucket:
+            eng.split_last_bucket = True  # (before the bucket plan is read)
+        return GradBucketReducer(eng.grads, eng.bucket_ranges(), shard_optimizer=args.shard_optimizer,
+                                 compress=args.compress, comm_cus=args.comm_cus)
 
     bench = Bench(args.config, args, world, rank, device, reducer_factory)
     result = bench.run(args.steps, args.warmup)

@@ -181,8 +181,8 @@ int sl_conv1d_backward_1x1_part(const void* x, const void* g, const void* w_dgra
                                 const sl_conv_geom* geom, int epilogue, int k_real, int dtype, int cfg, int accumulate,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
-/* How many CUs the library's grid choosers may count on: 0 = all (default 256), else 64 .. 256.  Process-wide, read when a
- * launch is enqueued.  The MFMA kernels take a whole CU per work-group and size their grids to whole rounds of the chip; when
+/* How many CUs the library's grid choosers may count on: 0 = all (default 256), else 64 .. 256.  Per calling THREAD
+ * (thread-local; round 6 -- it was process-wide), read when a launch is enqueued on that thread.  The MFMA kernels take a whole CU per work-group and size their grids to whole rounds of the chip; when
  * communication kernels own some CUs during backward (data-parallel runs: GradBucketReducer sets 256 - its channel count) the
  * split / segment / tile-height choosers of sl_conv1d_nt, sl_conv1d_wgrad[_grouped|_multi], sl_conv1d_chain and
  * sl_conv1d_backward_1x1 plan their rounds for that many CUs instead.  (No reference counterpart: the reference is

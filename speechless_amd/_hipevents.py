@@ -17,7 +17,12 @@ def _hip():
     global _HIP
     if _HIP is None:
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
-        lib = ctypes.CDLL(path)
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError:
+            # a torch build linked against the system ROCm ships no copy of its own: the soname resolves to the runtime the
+            # process already holds
+            lib = ctypes.CDLL("libamdhip64.so")
         lib.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
         lib.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]

@@ -128,6 +128,7 @@ class _Buffers:
         self.split_pending = 0        # utterances in the first part if the last forward ran the CTC in two parts (else 0)
         self.wgrad_r = None  # bf16x3: the two partial weight gradients (RA | RB) in front of sl_split3_wgrad_combine
         self.wgrad_geom_b = [None] * n
+        self.x3_window = False  # bf16x3, striding layer: RB's x operand is the [hi0 | hi1] window of the pair row (ensure_backward)
         self.wgrad_geom = [None] * n
         self.dgrad_geom = [None] * n
         self.bwd_ready = False
@@ -201,7 +202,7 @@ class _Buffers:
                 if g is not None:
                     need = max(need, lib().raw("sl_conv1d_nt_workspace_bytes")(
                         ctypes.byref(g), eng.dtype_code, eng.nt_cfg.get((kind, p.spec.name), 0)))
-        lib().call("sl_set_available_cus", 0)
+        lib().call("sl_set_available_cus", eng._cu_hint_active)
         if self.nt_ws is None or self.nt_ws.numel() < need:
             self.nt_ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)
             self.launch_lists = {}
@@ -248,10 +249,13 @@ class _Buffers:
                 wb = ConvGeom()
                 for name, _ in ConvGeom._fields_:
                     setattr(wb, name, getattr(wg, name))
-                if p.index == 0:
-                    wg.cin = 5 * p.cin_pad if (eng.x3_b_window and (5 * p.cin_pad) % 128 == 0) else p.cin_view * pl
-                    wb.cin = 2 * p.cin_pad if eng.x3_b_window else p.cin_view * pl
-                else:
+                if p.index == 0 and p.spec.stride == 2:
+                    # (the window decision is frozen HERE, with the geometries: the launch-time pointer offset and the
+                    # combine read it back from the buffer set, not from the engine attribute -- ADVICE r5)
+                    self.x3_window = bool(eng.x3_b_window)
+                    wg.cin = 5 * p.cin_pad if (self.x3_window and (5 * p.cin_pad) % 128 == 0) else p.cin_view * pl
+                    wb.cin = 2 * p.cin_pad if self.x3_window else p.cin_view * pl
+                else:  # (a stride-1 first layer included: its rows are one frame's [hi | lo | hi] like everyone's)
                     wg.cin, wb.cin = 2 * p.cin_pad, p.cin_pad
                 self.wgrad_geom_b[p.index] = wb
             if p.index > first:
@@ -312,7 +316,7 @@ class _Buffers:
                 ws_bytes = max(ws_bytes, L.raw("sl_conv1d_wgrad_workspace_bytes")(
                     ctypes.byref(wg), eng.dtype_code, eng.nt_cfg.get(("wgrad", p.spec.name), 0)))
                 bias_ws = max(bias_ws, L.raw("sl_bias_grad_workspace_bytes")(ctypes.byref(wg)))
-        L.call("sl_set_available_cus", 0)
+        L.call("sl_set_available_cus", eng._cu_hint_active)
         self.size_nt_workspace(eng, self.dgrad_geom, "dgrad")
         if eng.front_plan is not None:
             for g in (self.front_geom, self.front_stage_geom, self.front_dgrad_geom):

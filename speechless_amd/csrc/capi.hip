@@ -168,7 +168,9 @@ extern "C" int sl_conv1d_wgrad_multi(const sl_wgrad_job* jobs, int n_jobs, int d
     return wgrad_multi_bf16(jobs, n_jobs, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-static int g_available_cus = 256;
+// per THREAD: the engine brackets the launches it wants planned for fewer CUs on the thread that enqueues them; a stager
+// thread or another engine's thread of the same process never sees the setting
+static thread_local int g_available_cus = 256;
 int sl_cus() { return g_available_cus; }
 extern "C" int sl_set_available_cus(int cus) {
     SL_CHECK_ARG(cus == 0 || (cus >= 64 && cus <= 256), "sl_set_available_cus: 0 (all) or 64 .. 256");

@@ -462,18 +462,37 @@ __global__ __launch_bounds__(512, 2) void wgrad_tn_ilv_kernel(TnArgs a) {
             if constexpr (Q == 13) move_x(0);
             if constexpr (Q == 14) move_x(4);
         };
+#if defined(SL_PROBE_SKEW)
+        // TIMING PROBE (wrong results by construction): the second-dispatched half of
+        // the waves runs ONE PHASE behind the first -- a barrier per phase instead of one per step, so that in every phase
+        // one wave of a SIMD issues MFMAs on fragments it holds while the other issues its fragment reads / requests.  The
+        // data hazards a real version would have to solve (requests into a slot the other half still reads: the request
+        // stream split by k-half) are ignored here: same instruction stream, same bytes, the timing of the skewed loop.
+        if (wave >= 4) __builtin_amdgcn_s_barrier();
+#endif
         for (int i = 0; i < n; ++i) {
             const int nxt = cur ^ 1;
             slot_delta = (nxt - cur) * STAGE_BYTES;
             wait_trfrags(f0);
             TrPhase<1, 0, 16>::run(acc, f0, f1, ga, xa, hook_a);  // k-half 0 multiplies, k-half 1 is read
             wait_trfrags(f1);  // my reads of slot cur are complete
+#if defined(SL_PROBE_SKEW)
+            __builtin_amdgcn_s_barrier();
+            wait_vmcnt<0>();
+#else
             wait_vmcnt<0>();   // tile i+1 has landed (2-slot ring)
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
             TrPhase<0, 0, 16>::run(acc, f1, f0, ga, xa, dma_piece);  // k-half 1 multiplies, next tile's k-half 0 is read
+#if defined(SL_PROBE_SKEW)
+            __builtin_amdgcn_s_barrier();
+#endif
             cur = nxt;
         }
+#if defined(SL_PROBE_SKEW)
+        if (wave < 4) __builtin_amdgcn_s_barrier();
+#endif
         wait_vmcnt<0>();   // the surplus requests still target this work-group's LDS
         wait_trfrags(f0);  // ... and the surplus fragment reads these registers
     }

@@ -36,7 +36,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
     FRONT_DGRAD_EXTRA_ROWS = 17   # pair rows computed beyond the output frames: up to row T' + 23 = the last frame's
 
     def __init__(self, specs, grapheme_set_size, dtype="bf16", device="cuda:0", ctc_epsilon=1e-8,
-                 frozen_layer_count=0, lr=1e-4, beta_1=0.9, beta_2=0.999, adam_epsilon=1e-8):
+                 frozen_layer_count=0, lr=1e-4, beta_1=0.9, beta_2=0.999, adam_epsilon=1e-8, forward_only=False):
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("speechless_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
                                        "there is no CPU fallback for the hot path")
@@ -87,7 +87,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         self.plans = []
         off = 0
         # pair view of the striding layer = 2*cin_pad channels; the wgrad tile needs that to be a multiple of 128
-        cin_pad = _round_up(specs[0].cin, 64)
+        # (a first layer that does not stride reads plain rows: its own padded width must be that multiple -- ADVICE r5)
+        cin_pad = _round_up(specs[0].cin, 64 if specs[0].stride == 2 else 128)
         for i, s in enumerate(specs):
             cout_pad = _round_up(s.cout, 128)
             w_off = off
@@ -124,9 +125,15 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         self.group_wgrad = True
         dev = self.device
         self.params = torch.zeros((off,), dtype=torch.float32, device=dev)
-        self.grads = torch.zeros((off,), dtype=torch.float32, device=dev)
-        self.adam_m = torch.zeros((off,), dtype=torch.float32, device=dev)
-        self.adam_v = torch.zeros((off,), dtype=torch.float32, device=dev)
+        # forward_only: an evaluation engine (forward, CTC loss, decode) over masters another engine trains -- no gradient
+        # buffer, no moments (Wav2Letter.eval_engine aliases `params` to the training engine's)
+        self.forward_only = bool(forward_only)
+        self.grads = self.adam_m = self.adam_v = None
+        if not self.forward_only:
+            self.grads = torch.zeros((off,), dtype=torch.float32, device=dev)
+            self.adam_m = torch.zeros((off,), dtype=torch.float32, device=dev)
+            self.adam_v = torch.zeros((off,), dtype=torch.float32, device=dev)
+        self._weights_set_count = 0
         pl = self.planes  # bf16x3: packed weight rows are [w_hi | w_hi | w_lo]
         self.w_fwd = [torch.zeros((p.cout_pad, p.spec.kernel_size, p.cin_pad * pl), dtype=self.torch_dtype, device=dev)
                       for p in self.all_plans]
@@ -197,6 +204,13 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         # the library's choosers to plan for 256 - comm_cus (sl_set_available_cus) while an exchange can be in flight -- only
         # then: forward runs with the whole chip.  0 = no hint.  Set by train_step_resident from the reducer (comm_cus).
         self.comm_cus = 0
+        # Data-parallel runs, A/B knob for the first N > 1 run (SL_SPLIT_LAST_BUCKET=1): the one exchange
+        # nothing covers is the last bucket {striding_conv, inner_conv_1..7} (19 MB), closed by the last kernel of backward.
+        # With the flag the run of identical layers is cut at `split_last_at`: its fused input-gradient launch and the balanced
+        # weight-gradient launch become two each (+2 launches per step), and the upper part's gradients (inner_conv_4..7,
+        # 7 MB) close as a bucket of their own under the lower part's launches.  Off by default: on one GPU it only costs.
+        self.split_last_bucket = os.environ.get("SL_SPLIT_LAST_BUCKET", "0") == "1"
+        self.split_last_at = 4
         self._cu_hint_active = 0  # what sl_set_available_cus was last told by this engine's backward (restored after sizing calls)
         self._ctc_streams = None
         self._rec = None
@@ -224,6 +238,18 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             buf.size_nt_workspace(self, buf.fwd_geom, "fwd")
             if buf.bwd_ready:
                 buf.size_backward_workspaces(self)
+
+    @property
+    def weights_version(self):
+        """changes whenever the fp32 masters changed (set_weights, every optimizer step): what an engine sharing them compares"""
+        return (self._weights_set_count, self.adam_iterations)
+
+    def _set_cu_hint(self, cus):
+        """sl_set_available_cus for the launches this THREAD enqueues from here on (the library keeps the setting per thread)
+        and this engine's record of it -- one op of a recorded backward, so that a replayed step tracks it too and the sizing
+        helpers that run in between (_part_geom, _wgrad_multi_workspace_need) restore the right value"""
+        self.lib.call("sl_set_available_cus", cus)
+        self._cu_hint_active = cus
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -404,8 +430,13 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             # range nor reduced twice; the merged layers are then contiguous from layer 0 up
             span = set(range(multi[0], multi[-1] + 1))
             merged = sorted(set(l for g in groups if set(g) & span for l in g))
-            groups = [g for g in groups if not set(g) & span] + [merged]
+            groups = [g for g in groups if not set(g) & span]
             assert merged == list(range(merged[0], merged[-1] + 1)), merged
+            parts = self._wgrad_multi_groups(first)
+            if len(parts) == 2 and sorted(parts[0] + parts[1]) == merged:
+                groups += parts  # split_last_bucket: the upper part of the run closes first, as a bucket of its own
+            else:
+                groups.append(merged)
         plan = []
         for layers in groups:
             if layers:
@@ -437,6 +468,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             if self._has_ones_output(p):
                 bv[p.cout_pad - 1] = 1.0  # relu(0 * x + 1) = elu(1) = 1: the ones channel (see self.ones_channel)
         self._packed_dirty = True
+        self._weights_set_count += 1
 
     def _has_ones_output(self, plan):
         """hidden layer whose output has channel padding: its last padded channel is the constant 1"""
@@ -628,6 +660,10 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         # softmax, which gets it by value -> then the list is per length
         key = None if rate else ("fwd", st, fuse_out, self.use_chain, tuple(sorted(self.nt_cfg.items())),
                                  None if fuse_out else buf.t_out, split_ctc)
+        if split_ctc is not None:
+            # the part geometries (and the workspace they may re-allocate) exist BEFORE a list is looked up or recorded: a
+            # launch of the lower layers already in the list being recorded would keep a freed nt_ws pointer
+            self._presize_parts(buf, ("fwd", "dgrad") if buf.bwd_ready else ("fwd",), split_ctc[1])
         ops = self._launch_list(buf, key) if key is not None else None
         if ops is not None:
             self._replay(ops)
@@ -803,6 +839,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         on_bucket_ready(b) is called once every launch that writes gradient bucket b (bucket_plan) is enqueued on the main
         stream -- the data-parallel reducer starts that bucket's exchange there."""
         buf = self.cur
+        if self.forward_only:
+            raise RuntimeError("this engine was built forward_only (evaluation): it has no gradient buffers")
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)  # (ROCm offers no priority below the default)
@@ -811,6 +849,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         key = None if buf.dropped else ("bwd", main.cuda_stream, buf.split_pending, on_bucket_ready is not None, self.ones_channel,
                                         self.frozen_layer_count, self.group_wgrad, self.use_chain, self.fuse_output_backward,
                                         self.use_wgrad_multi, self.multi_overlap_tiles, self.small_bias_pass_on_main,
+                                        self.split_last_bucket, self.split_last_at,
                                         tuple(sorted(self.nt_cfg.items())),
                                         buf.t_out if self.planes > 1 else None)  # (bf16x3 helpers take it by value)
         try:
@@ -854,15 +893,49 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         dchain, skip = {}, set()
         if buf.dropped or not self.use_chain or self.dtype != "bf16":
             return dchain, skip
+        cut = self._split_last_cut(first)
         for (s0, e0) in self.runs:
             layers = list(range(e0, max(s0, first + 1) - 1, -1))
             if len(layers) >= 2 and all(self.specs[i - 1].activation == "relu" for i in layers) and \
                     not any(("dgrad", self.specs[i].name) in self.nt_cfg for i in layers) and \
                     bool(self.lib.raw("sl_conv1d_chain_supported")(ctypes.byref(buf.dgrad_geom[e0]), len(layers),
                                                                    self.dtype_code)):
-                dchain[e0] = layers
-                skip.update(layers[1:])
+                pieces = [layers]
+                if cut is not None and s0 < cut <= e0:
+                    # split_last_bucket: input gradients of layers e0 .. cut first (they complete g[cut .. e0 - 1], all the
+                    # upper weight-gradient launch still needs), the rest behind that launch
+                    upper, lower = [i for i in layers if i >= cut], [i for i in layers if i < cut]
+                    ok = all(len(q) == 1 or bool(self.lib.raw("sl_conv1d_chain_supported")(
+                        ctypes.byref(buf.dgrad_geom[q[0]]), len(q), self.dtype_code)) for q in (upper, lower) if q)
+                    if ok:
+                        pieces = [q for q in (upper, lower) if q]
+                for q in pieces:
+                    if len(q) >= 2:
+                        dchain[q[0]] = q
+                        skip.update(q[1:])
         return dchain, skip
+
+    def _split_last_cut(self, first):
+        """split_last_bucket: the layer at which the balanced weight-gradient launch (and the fused input-gradient launch of
+        the run it covers) is cut in two, or None"""
+        if not self.split_last_bucket or self.planes > 1:
+            return None
+        multi = self._wgrad_multi_layers(first)
+        cut = self.split_last_at
+        if not multi or multi[0] != 0 or not (multi[0] < cut <= multi[-1]) or cut <= first:
+            return None
+        return cut
+
+    def _wgrad_multi_groups(self, first, grouped=None):
+        """the balanced weight-gradient launches of backward, in the order they are enqueued: one for all of
+        _wgrad_multi_layers, or -- split_last_bucket -- the layers from the cut up first, then the rest"""
+        multi = self._wgrad_multi_layers(first, grouped)
+        if not multi:
+            return []
+        cut = self._split_last_cut(first)
+        if cut is None:
+            return [multi]
+        return [[i for i in multi if i >= cut], [i for i in multi if i < cut]]
 
     def _launch_wgrad(self, buf, i, grouped, st):
         """weight gradient of layer i -- or, at the lowest layer of a grouped run, of the whole run"""
@@ -963,7 +1036,10 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         self.lib.call("sl_set_available_cus", self._cu_hint_active)
         return need
 
-    def _launch_wgrad_multi(self, buf, layers, st):
+    def _wgrad_multi_table(self, buf, layers):
+        """job table of a balanced weight-gradient launch over `layers`, built once per buffer set; makes sure the shared
+        workspace covers it.  backward() builds the tables of ALL its balanced launches before the first of them is enqueued:
+        a workspace re-allocated for the second launch would leave the first one's recorded launch with a freed pointer."""
         key = (tuple(layers), buf.dropped)
         table = buf.multi_tables.get(key)
         if table is None:
@@ -978,6 +1054,11 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             need = self._wgrad_multi_workspace_need(table, len(layers))
             if buf.wgrad_multi_ws is None or buf.wgrad_multi_ws.numel() < need:
                 buf.wgrad_multi_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=self.device)
+                buf.launch_lists = {}
+        return table
+
+    def _launch_wgrad_multi(self, buf, layers, st):
+        table = self._wgrad_multi_table(buf, layers)
         self._launch("wgrad:{}..{}".format(self.specs[layers[0]].name, self.specs[layers[-1]].name),
                      "sl_conv1d_wgrad_multi", table, len(layers), self.dtype_code, buf.wgrad_multi_ws.data_ptr(),
                      buf.wgrad_multi_ws.numel(), st)
@@ -988,7 +1069,11 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         first = self.frozen_layer_count
         grouped = self._grouped_wgrad_runs(first)
         dchain, dchain_skip = self._dgrad_chains(buf, first)
-        multi = self._wgrad_multi_layers(first, grouped)
+        multi = {}  # layer -> the layers of the balanced launch that writes its weight gradient (at the lowest of them)
+        for launch_layers in self._wgrad_multi_groups(first, grouped):
+            self._wgrad_multi_table(buf, launch_layers)
+            for i in launch_layers:
+                multi[i] = launch_layers
         # bias gradients out of the weight-gradient GEMM (self.ones_channel): which layers, and whether the row holds the
         # bias gradient (the ones were not touched by dropout) or only has to be zeroed before the optimizer sees it
         ones_in = self._ones_input_layers(first)
@@ -1049,8 +1134,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             elif fused_bwd:
                 self._launch_output_backward(buf, i, main.cuda_stream)
             elif i in multi:
-                if i == multi[0]:  # every gradient tensor the launch reads is complete at its lowest layer
-                    self._launch_wgrad_multi(buf, multi, main.cuda_stream)
+                if i == multi[i][0]:  # every gradient tensor the launch reads is complete at its lowest layer
+                    self._launch_wgrad_multi(buf, multi[i], main.cuda_stream)
             else:
                 self._launch_wgrad(buf, i, grouped, main.cuda_stream)
             if closes_bucket:
@@ -1063,8 +1148,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
                 if self._rec is not None:
                     self._rec.append((2, b))
                 if hint and b == 0:  # from here on communication kernels may own CUs: the choosers plan for the rest
-                    self._launch("cu_hint", "sl_set_available_cus", 256 - self.comm_cus)
-                    self._cu_hint_active = 256 - self.comm_cus
+                    self._eager_op(self._set_cu_hint, 256 - self.comm_cus)
             if i in dchain:
                 layers = dchain[i]
                 ys, ws, masks = self._chain_table("dgrad", layers, buf)
@@ -1086,13 +1170,14 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
                 if self._rec is not None:
                     self._rec.append((2, b))
         if hint:
-            self._launch("cu_hint", "sl_set_available_cus", 0)
-            self._cu_hint_active = 0
+            self._eager_op(self._set_cu_hint, 0)
 
     def adam_step(self, fused=True):
         """Keras-2.0 Adam on the flat fp32 masters.  fused=True: one kernel per trainable layer that applies Adam AND
         rewrites the layer's two bf16 operand copies in the same pass (no separate repack); fused=False: one flat
         elementwise launch, operands repacked lazily by the next forward()."""
+        if self.forward_only:
+            raise RuntimeError("this engine was built forward_only (evaluation): it has no optimizer state")
         self.adam_iterations += 1
         st = self._stream()
         if not fused:

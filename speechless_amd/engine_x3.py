@@ -138,7 +138,7 @@ class X3Mixin:
             dw, _ = self.layer_param_views(self.grads, p)
             frames = 2 if p.spec.stride == 2 else 1
             fstride = pl * p.cin_pad if frames == 2 else 0
-            window = frames == 2 and self.x3_b_window  # RB's x operand was the [hi0 | hi1] window of the pair row
+            window = frames == 2 and buf.x3_window  # RB's x operand was the [hi0 | hi1] window of the pair row
             self._launch("combine:" + p.spec.name, "sl_split3_wgrad_combine", ra.data_ptr(), rb.data_ptr(), dw.data_ptr(),
                          p.spec.kernel_size, p.cin_pad, p.cout_pad, frames, fstride,
                          buf.wgrad_geom[p.index].cin, buf.wgrad_geom_b[p.index].cin, p.cin_pad if window else fstride, st)
@@ -158,7 +158,7 @@ class X3Mixin:
                 cfg = self.nt_cfg.get(("wgrad", p.spec.name), 0)
                 self._launch("wgrad:" + p.spec.name, "sl_conv1d_wgrad", x.data_ptr(), buf.g[i].data_ptr(), ra.data_ptr(),
                              ctypes.byref(wa), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
-                x_b = x.data_ptr() + (2 * p.cin_pad * 2 if (i == 0 and p.spec.stride == 2 and self.x3_b_window) else 0)
+                x_b = x.data_ptr() + (2 * p.cin_pad * 2 if (i == 0 and p.spec.stride == 2 and buf.x3_window) else 0)
                 self._launch("wgrad_lo:" + p.spec.name, "sl_conv1d_wgrad", x_b, g_lo, rb.data_ptr(),
                              ctypes.byref(wb), self.dtype_code, cfg, buf.wgrad_ws.data_ptr(), buf.wgrad_ws.numel(), st)
                 combine(p, ra, rb)

@@ -244,8 +244,8 @@ class Wav2Letter:
                  reinitialize_trainable_loaded_layers=False, use_asg=False, asg_transition_probabilities=None,
                  asg_initial_probabilities=None, kenlm_directory=None,
                  # --- extensions of this implementation (keyword-only in spirit) ---
-                 compute_dtype="bf16", device="cuda:0", seed=None, ctc_epsilon=1e-8, layer_sizes=None,
-                 load_optimizer_state=False):
+                 compute_dtype=None, device="cuda:0", seed=None, ctc_epsilon=1e-8, layer_sizes=None,
+                 load_optimizer_state=False, eval_dtype=None):
         if frozen_layer_count > 0 and load_model_from_directory is None:
             raise ValueError("Layers cannot be frozen if model is trained from scratch.")
         if use_asg:
@@ -263,7 +263,17 @@ class Wav2Letter:
         self.optimizer = optimizer if optimizer is not None else Adam(1e-4)
         self.load_epoch = load_epoch
         self.dropout = dropout
-        self.compute_dtype = compute_dtype
+        # Arithmetic (round 6).  The reference has ONE arithmetic -- fp32 (net.py:389,402-406).  Called with
+        # the reference's own signature (compute_dtype not given) this class TRAINS on the benchmarked bf16 engine and
+        # EVALUATES -- prediction_batch, predict*, test_and_predict* -- on a second, lazily built `bf16x3` engine (the fast
+        # parity path: greedy decode bit-exact against the fp32 CPU port, loss to 2e-7) that shares the fp32 master weights
+        # in HBM and re-packs its operand copies whenever they changed.  compute_dtype="bf16" / "f32" / "bf16x3" given
+        # explicitly: that one engine does everything (eval_dtype overrides the evaluation side alone).
+        self.compute_dtype = compute_dtype if compute_dtype is not None else "bf16"
+        if eval_dtype is None:
+            eval_dtype = "bf16x3" if compute_dtype is None else self.compute_dtype
+        self.eval_dtype = eval_dtype
+        compute_dtype = self.compute_dtype
         self.device = device
         self.ctc_epsilon = ctc_epsilon
         self._layer_sizes = dict(layer_sizes or {})
@@ -279,6 +289,8 @@ class Wav2Letter:
         self.engine.dropout_seed = int(seed) if seed is not None else \
             int(np.random.SeedSequence().entropy & 0x7fffffff)
         self.engine.set_weights(self._glorot_uniform(specs, seed))
+        self._eval_engine = None
+        self._eval_weights_version = None
         self.predictive_net = PredictiveNet(self.engine)
         for layer in self.predictive_net.layers[:frozen_layer_count]:
             layer.trainable = False
@@ -369,7 +381,8 @@ class Wav2Letter:
                               activation=self.activation, output_activation=self.output_activation,
                               optimizer=self.optimizer, load_model_from_directory=load_model_from_directory,
                               load_epoch=load_epoch, frozen_layer_count=self.frozen_layer_count,
-                              compute_dtype=self.compute_dtype, device=self.device, layer_sizes=self._layer_sizes)
+                              compute_dtype=self.compute_dtype, device=self.device, layer_sizes=self._layer_sizes,
+                              use_raw_wave_input=self.use_raw_wave_input)
         log("Loading first {} layers of {}, epoch {}, reinitializing the last {}.".format(
             loaded_first_layers_count, load_model_from_directory, load_epoch, layer_count - loaded_first_layers_count))
         source = original.predictive_net.get_weights()
@@ -424,14 +437,38 @@ class Wav2Letter:
         }
 
     # ------------------------------------------------------------------ inference (net.py:350-357, 461-498)
+    @property
+    def eval_engine(self):
+        """The engine every forward-only entry point runs on (net.py:350-357, 461-498: learning phase 0).  Same object as
+        self.engine when training and evaluation share a dtype; otherwise a second Engine of self.eval_dtype over the SAME
+        flat fp32 master buffer (no copy: `params` is aliased), whose packed operand copies are refreshed when the training
+        engine's weights_version moved (a training step, set_weights, a loaded checkpoint)."""
+        if self.eval_dtype == self.compute_dtype:
+            return self.engine
+        train = self.engine
+        if self._eval_engine is None:
+            ev = Engine(list(train.all_specs), self.grapheme_encoding.grapheme_set_size, dtype=self.eval_dtype,
+                        device=self.device, ctc_epsilon=self.ctc_epsilon, frozen_layer_count=self.frozen_layer_count,
+                        forward_only=True)
+            ev.params = train.params  # the masters themselves: same plan, same offsets (Engine.__init__ does not depend on dtype)
+            assert ev.param_numel == train.param_numel
+            self._eval_engine = ev
+            self._eval_weights_version = None
+        ev = self._eval_engine
+        if self._eval_weights_version != train.weights_version:
+            ev._packed_dirty = True  # (its next forward re-packs from the shared masters, on the same stream as the step)
+            self._eval_weights_version = train.weights_version
+        return ev
+
     def prediction_batch(self, input_batch):
         """Grapheme probabilities (B, T', K) for a (B, T, F) spectrogram batch."""
-        return self.engine.forward(np.asarray(input_batch)).cpu().numpy()
+        return self.eval_engine.forward(np.asarray(input_batch)).cpu().numpy()
 
     def predict_batch_greedily(self, spectrograms):
         input_batch, prediction_lengths = self._input_batch_and_prediction_lengths(spectrograms)
-        self.engine.forward(input_batch)
-        decoded, _ = self.engine.greedy_decode(prediction_lengths)
+        engine = self.eval_engine
+        engine.forward(input_batch)
+        decoded, _ = engine.greedy_decode(prediction_lengths)
         return [self.grapheme_encoding.decode_graphemes(d, merge_repeated=False) for d in decoded]
 
     def predict_batch_greedily_from_audio(self, raw_audio_batch, sample_rate=16000, fourier_window_length=512,
@@ -444,23 +481,25 @@ class Wav2Letter:
         mel = None if self.input_size_per_time_step == bins else self.input_size_per_time_step
         extractor = shared_extractor(sample_rate, fourier_window_length, hop_length, mel, self.device)
         x, frames = extractor.batch(raw_audio_batch)
-        self.engine.forward(x)
-        decoded, _ = self.engine.greedy_decode([n // self.input_to_prediction_length_ratio for n in frames])
+        engine = self.eval_engine
+        engine.forward(x)
+        decoded, _ = engine.greedy_decode([n // self.input_to_prediction_length_ratio for n in frames])
         return [self.grapheme_encoding.decode_graphemes(d, merge_repeated=False) for d in decoded]
 
     def test_and_predict_batch(self, labeled_spectrogram_batch):
         """ONE forward pass yields both the greedy transcription and the per-utterance CTC loss."""
         inputs = self._input_dictionary_for_loss_net(labeled_spectrogram_batch)
         names = Wav2Letter.InputNames
-        self.engine.forward(inputs[names.input_batch])
-        self.engine.set_labels(inputs[names.label_batch], inputs[names.label_lengths],
-                               inputs[names.prediction_lengths])
-        losses = self.engine.ctc().cpu().numpy()
+        engine = self.eval_engine
+        engine.forward(inputs[names.input_batch])
+        engine.set_labels(inputs[names.label_batch], inputs[names.label_lengths],
+                          inputs[names.prediction_lengths])
+        losses = engine.ctc().cpu().numpy()
         if self._beam_decoder is not None:  # net.py:444-451: beam search scored by the language model
-            decoded, _ = self._beam_decoder.decode(self.engine.cur.probs.cpu().numpy(),
+            decoded, _ = self._beam_decoder.decode(engine.cur.probs.cpu().numpy(),
                                                    inputs[names.prediction_lengths])
         else:
-            decoded, _ = self.engine.greedy_decode()
+            decoded, _ = engine.greedy_decode()
         predictions = [self.grapheme_encoding.decode_graphemes(d, merge_repeated=False) for d in decoded]
         return ExpectationsVsPredictions(
             [ExpectationVsPrediction(predicted=p, expected=x.label, loss=float(l))
