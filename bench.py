@@ -199,7 +199,7 @@ def parity_object(specs, weights, names, cpu_first, device):
            "relu_decisions_per_layer": {n: int(m.numel()) for n, m in zip(hidden, exact["masks"])}}
     out["torch_cpu_f32"] = {"vs_f64": against_f64(ref_losses, cpu_first["grads"], cpu_first["masks"], ref_argmax,
                                                   ref_decoded)}
-    for dtype in ("bf16", "bf16x3", "f32"):
+    for dtype in ("bf16", "bf16x3", "f16x3", "f32"):
         g = gpu_first_step(specs, weights, dtype, device)
         leg = {"loss_rel_max": float(np.max(np.abs(g["losses"] - ref_losses) / np.abs(ref_losses))),
                "grad_rel_l2": {n: _rel_l2(gw, rw) for n, (gw, _), (rw, _) in zip(names, g["grads"], cpu_first["grads"])},
@@ -221,7 +221,8 @@ def parity_object(specs, weights, names, cpu_first, device):
     out["note"] = ("bf16 = the benchmarked path (bf16 storage, fp32 accumulate): the loss meets north_star's 1e-3, its "
                    "gradients carry the ReLU sign flips of bf16-rounded activations (DESIGN.md section 1); f32 = the "
                    "parity path (exact-fp32 MFMA), the one held to bit-exact decode and 1e-3 gradients; bf16x3 = the fast "
-                   "parity path (hi + lo bf16 planes, three bf16 MFMA terms per product).  vs_f64: each implementation "
+                   "parity path (hi + lo bf16 planes, three bf16 MFMA terms per product); f16x3 = the same scheme on fp16 "
+                   "planes (22 operand bits instead of 16-17, power-of-two scales for range).  vs_f64: each implementation "
                    "against the float64 run -- torch_cpu_f32.vs_f64 is how far the REFERENCE side's float32 arithmetic "
                    "is from exact on this batch; a HIP parity path at or below that level is as right as the CPU path")
     return out
@@ -709,7 +710,7 @@ def compact_line(detail, detail_path):
     line["cpu_baseline"] = None if not cpu else {k: cpu[k] for k in ("value", "unit", "cores", "kind", "cpu_model", "sample")}
     if "parity" in detail:
         line["parity"] = {path: _parity_summary(detail["parity"][path])
-                          for path in ("torch_cpu_f32", "f32", "bf16x3", "bf16") if path in detail["parity"]}
+                          for path in ("torch_cpu_f32", "f32", "f16x3", "bf16x3", "bf16") if path in detail["parity"]}
         line["parity"]["checker"] = "float64 run of the same 32 x 1000 step (oracle/w2l_float64.py); rel-L2 per weight-gradient tensor"
     if "also" in detail:
         line["also"] = {}
@@ -880,6 +881,16 @@ def main():
                               "see parity.bf16x3); step_mfma_frac counts ALGORITHMIC FLOPs, step_mfma_frac_executed the "
                               "3 x it issues"})
         also["config3_bf16x3"] = r
+        del b
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        b = Bench(3, args, 1, 0, device, dtype="f16x3")
+        r = b.run(10, 3)
+        r.update({"step_mfma_frac_executed": 3.0 * r["step_mfma_frac"], "metric": METRICS[3], "steps": 10, "warmup": 3,
+                  "leg_seconds": round(time.perf_counter() - t0, 2),
+                  "workload": "BASELINE config 3 on the f16x3 path (hi + lo fp16 planes: 22 operand bits, three fp16 MFMA terms "
+                              "per product, weights and gradients stored under power-of-two scales; see parity.f16x3)"})
+        also["config3_f16x3"] = r
         del b
         torch.cuda.empty_cache()
         line["also"] = also

@@ -39,7 +39,10 @@ typedef enum sl_status {
     SL_ERR_LAUNCH_FAILED = -4
 } sl_status;
 
-typedef enum sl_dtype { SL_BF16 = 0, SL_F32 = 1 } sl_dtype;
+/* SL_F16 (round 6): fp16 operands on v_mfma_f32_16x16x32_f16 with fp32 or hi + lo PLANE outputs -- sl_conv1d_nt (out_f32 = 1
+ * or 2), sl_conv1d_wgrad and sl_conv1d_wgrad_multi only: the "f16x3" parity path (every fp32 value as two fp16 planes, three
+ * MFMA terms per product; speechless_amd/engine_x3.py).  No reference counterpart: the reference computes in fp32. */
+typedef enum sl_dtype { SL_BF16 = 0, SL_F32 = 1, SL_F16 = 2 } sl_dtype;
 
 /* epilogue of sl_conv1d_nt */
 typedef enum sl_epilogue {
@@ -71,6 +74,8 @@ typedef struct sl_conv_geom {
     int32_t y_row0;         /* output row of t = 0                                                       */
     int32_t y_row_stride;   /* elements between output rows (>= cout)                                    */
     int64_t y_batch_stride; /* elements between utterances in y (and in mask)                            */
+    float acc_scale;        /* SL_F16 only: sl_conv1d_nt multiplies the accumulator by this before bias / mask (the f16x3 path
+                             * stores weights and gradients scaled by powers of two); 0 = 1.  Ignored by the other dtypes. */
 } sl_conv_geom;
 
 int sl_version(void);
@@ -409,6 +414,32 @@ int sl_split3_bias_grad(const void* g, float* db, int batch, int t_out, int chan
  * post-dropout activation (cf. sl_elu_dropout_backward).  dst may be src. */
 int sl_split3_dropout(const void* src, void* dst, const void* y, int64_t rows, int channels, int mode, float rate,
                       uint64_t seed, void* stream);
+
+/* ---- "f16x3" (round 6): the same three-plane scheme on fp16 pairs -- hi = fp16(v), lo = fp16(v - hi): 22 significand bits
+ * where |v| >= 2^-3 and an absolute 2^-25 below (the lo plane runs into fp16 denormals, which v_mfma_f32_16x16x32_f16 keeps:
+ * tools/f16_denorm_probe.hip) against bf16x3's 16-17, at the same three MFMA terms and the same rate; range 65504, so the engine
+ * stores weights and back-propagated gradients multiplied by powers of two (exact) and the kernels divide them out again:
+ * sl_conv1d_nt(dtype = SL_F16) through sl_conv_geom.acc_scale, the helpers below through `scale`.  Same reference rows as
+ * bf16x3 (net.py:304, 389, 402-406: one fp32 arithmetic).  Twins of the sl_split3* entry points above, fp16 planes:
+ *   sl_splitf16, sl_splitf16_pack_input, sl_splitf16_dropout    as sl_split3, sl_split3_pack_input, sl_split3_dropout
+ *   sl_splitf16_pack_weights   operand copies of scale * w
+ *   sl_splitf16_adam_pack_layers  Adam on the masters, operand copies of w_scale * w
+ *   sl_splitf16_bias_grad      db = scale * sum over valid frames of (g_hi + g_lo)
+ *   sl_split3_wgrad_combine_scaled  dw = scale * (hh + hl + lh)   (fp32 in and out: either plane format) */
+int sl_splitf16(const float* src, void* dst, const void* mask, int batch, int t_out, int channels, int64_t src_batch_stride,
+                int dst_row0, int64_t dst_batch_stride, int mode, void* stream);
+int sl_splitf16_pack_input(const float* src, void* dst, int batch, int t_in, int f, int channels, int dst_row0,
+                           int64_t dst_batch_stride, void* stream);
+int sl_splitf16_pack_weights(const float* w_master, void* w_fwd3, void* w_dgrad3, int k, int cin_pad, int cout_pad, float scale,
+                             void* stream);
+int sl_splitf16_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers, int n_layers,
+                                 int step, float lr, float beta1, float beta2, float eps, float w_scale, void* stream);
+int sl_split3_wgrad_combine_scaled(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out, int frames,
+                                   int fstride, int ra_cin, int rb_cin, int rb_fstride, float scale, void* stream);
+int sl_splitf16_bias_grad(const void* g, float* db, int batch, int t_out, int channels, int g_row0, int64_t g_batch_stride,
+                          float scale, void* workspace, size_t workspace_bytes, void* stream);
+int sl_splitf16_dropout(const void* src, void* dst, const void* y, int64_t rows, int channels, int mode, float rate,
+                        uint64_t seed, void* stream);
 
 /* ---- audio front end (speechless/labeled_example.py:99-160, 28-29) ---------------------------
  * sl_stft_power_db: librosa.stft(y, n_fft, hop_length) with its defaults (periodic Hann window of n_fft samples,

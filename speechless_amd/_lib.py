@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("SL_LIB_PATH") or Path(__file__).resolve().parent
 
 SL_BF16 = 0
 SL_F32 = 1
+SL_F16 = 2
 
 EPI_NONE = 0
 EPI_BIAS = 1
@@ -51,6 +52,7 @@ class ConvGeom(ctypes.Structure):
         ("y_row0", c_int32),
         ("y_row_stride", c_int32),
         ("y_batch_stride", c_int64),
+        ("acc_scale", c_float),
     ]
 
 
@@ -133,6 +135,16 @@ SIGNATURES = {
     "sl_conv1d_wgrad_multi_workspace_bytes": (c_size_t, [POINTER(WgradJob), c_int, c_int]),
     "sl_conv1d_wgrad_multi": (c_int, [POINTER(WgradJob), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "sl_pack_layers": (c_int, [c_void_p, POINTER(AdamLayer), c_int, c_int, c_void_p]),
+    "sl_splitf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "sl_splitf16_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "sl_splitf16_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "sl_splitf16_adam_pack_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AdamLayer), c_int, c_int, c_float,
+                                             c_float, c_float, c_float, c_float, c_void_p]),
+    "sl_split3_wgrad_combine_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               c_int, c_float, c_void_p]),
+    "sl_splitf16_bias_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p, c_size_t,
+                                      c_void_p]),
+    "sl_splitf16_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, ctypes.c_uint64, c_void_p]),
 }
 
 

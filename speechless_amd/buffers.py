@@ -78,6 +78,7 @@ class _Buffers:
                 g.y_row0 = HALO
                 g.y_row_stride = p.cout_pad
                 g.y_batch_stride = self.rows * p.cout_pad
+            g.acc_scale = 1.0 / eng.w_scale  # (f16x3: the operand copies hold w_scale * w; 1 on every other path)
             self.fwd_geom.append(g)
         # bf16x3: fp32 staging buffer of a layer's pre-activations / input gradients (sl_conv1d_nt out_f32 -> sl_split3)
         stage = batch * self.tt_pad * max(p.cout_pad for p in eng.plans)
@@ -276,6 +277,7 @@ class _Buffers:
                     dg.y_row0 = HALO
                     dg.y_row_stride = p.cin_pad
                     dg.y_batch_stride = self.rows * p.cin_pad
+                dg.acc_scale = 1.0 / eng.w_scale  # (f16x3: g_scale * g in, g_scale * g out; the weights' scale is divided out)
                 self.dgrad_geom[p.index] = dg
         if eng.front_plan is not None and first == 0 and not eng.front_frozen:
             # dL/d(x0) in x0's own pair-view layout: pair row r = sum over the 24 pair taps j of g0[r - j] . Wpair[j]^T, as an

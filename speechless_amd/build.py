@@ -13,6 +13,9 @@ HOST_SOURCES = [PACKAGE_DIR / "csrc_host" / "pack_batch.cpp", PACKAGE_DIR / "csr
 CXX = os.environ.get("CXX", "g++")
 SOURCES = ["capi.hip", "conv_nt_bf16.hip", "wgrad_tn_bf16.hip", "conv_f32.hip", "ctc.hip", "misc.hip", "spectrogram.hip", "conv_chain_bf16.hip",
            "conv1x1_bwd_bf16.hip", "split3.hip"]
+# translation units built a SECOND time from the same source with -DSL_ELEM_F16: the NT / TN kernels on v_mfma_*_f16 for the
+# f16x3 parity path (csrc/common.h: SL_MFMA16; only the fp32 / plane-output instantiations, about a third of the bf16 build)
+F16_VARIANTS = {"conv_nt_f16": "conv_nt_bf16.hip", "wgrad_tn_f16": "wgrad_tn_bf16.hip"}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("SL_EXTRA_FLAGS", "").split()  # experiments only (e.g. -DSL_NT_SETPRIO); the default build has none
@@ -47,9 +50,12 @@ def _scratch_users(remarks):
 FILE_FLAGS = {"ctc.hip": ["-fno-slp-vectorize"]}
 
 
-def _compile(src):
-    obj = CSRC / (src.replace(".hip", ".o"))
-    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", str(CSRC / src), "-o", str(obj)]
+def _compile(unit):
+    """unit: a source file name, or a key of F16_VARIANTS (the same source compiled with -DSL_ELEM_F16 into <key>.o)"""
+    src = F16_VARIANTS.get(unit, unit)
+    obj = CSRC / ((unit + ".o") if unit in F16_VARIANTS else src.replace(".hip", ".o"))
+    extra = ["-DSL_ELEM_F16"] if unit in F16_VARIANTS else []
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + extra + ["-c", str(CSRC / src), "-o", str(obj)]
     if src in NO_SCRATCH:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -84,11 +90,14 @@ def build(force=False, verbose=False):
     build_host(force)
     if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= _newest_source_mtime():
         return LIB_PATH
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
-        results = list(pool.map(_compile, SOURCES))
+    units = SOURCES + list(F16_VARIANTS)
+    # (the two big files first: each of their translation units takes minutes, the rest seconds)
+    units.sort(key=lambda u: 0 if F16_VARIANTS.get(u, u) in ("conv_nt_bf16.hip", "wgrad_tn_bf16.hip") else 1)
+    with ThreadPoolExecutor(max_workers=len(units)) as pool:
+        results = list(pool.map(_compile, units))
     objs = [str(o) for o, _ in results]
     if verbose:
-        for (_, err), src in zip(results, SOURCES):
+        for (_, err), src in zip(results, units):
             if err.strip():
                 print("[{}]\n{}".format(src, err), file=sys.stderr)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + objs

@@ -43,10 +43,10 @@ static int check_geom(const sl_conv_geom* g, const char* who, int cin_mult, int 
 }
 
 extern "C" size_t sl_conv1d_nt_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg) {
-    if (!geom || dtype != SL_BF16 || geom->taps <= 0 || geom->cin <= 0 || geom->cin % 64 || geom->cout <= 0 ||
+    if (!geom || (dtype != SL_BF16 && dtype != SL_F16) || geom->taps <= 0 || geom->cin <= 0 || geom->cin % 64 || geom->cout <= 0 ||
         geom->cout % 128 || geom->batch <= 0 || geom->t_out <= 0)
         return 0;
-    return conv_nt_bf16_workspace_bytes(geom, cfg);
+    return dtype == SL_F16 ? conv_nt_f16_workspace_bytes(geom, cfg) : conv_nt_bf16_workspace_bytes(geom, cfg);
 }
 
 extern "C" int sl_conv1d_nt(const void* x, const void* w, const float* bias, const void* mask, void* y,
@@ -62,6 +62,10 @@ extern "C" int sl_conv1d_nt(const void* x, const void* w, const float* bias, con
     if (dtype == SL_BF16)
         return conv_nt_bf16(x, w, bias, mask, y, geom, epilogue, out_f32, cfg, workspace, workspace_bytes,
                             (hipStream_t)stream);
+    if (dtype == SL_F16) {
+        SL_CHECK_ARG(out_f32 == 1 || out_f32 == 2, "sl_conv1d_nt(f16): fp32 or plane outputs only (out_f32 = 1 or 2)");
+        return conv_nt_f16(x, w, bias, mask, y, geom, epilogue, out_f32, cfg, workspace, workspace_bytes, (hipStream_t)stream);
+    }
     if (dtype == SL_F32) return conv_nt_f32(x, w, bias, mask, y, geom, epilogue, cfg, (hipStream_t)stream);
     sl_set_error("sl_conv1d_nt: unknown dtype %d", dtype);
     return SL_ERR_INVALID_ARGUMENT;
@@ -125,9 +129,9 @@ extern "C" int sl_conv1d_chain(const void* x, void* const* ys, const void* const
 
 extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int dtype, int cfg) {
     if (!geom || geom->taps <= 0 || geom->cin <= 0 || geom->cout <= 0 || geom->batch <= 0) return 0;
-    if (dtype == SL_BF16) {
+    if (dtype == SL_BF16 || dtype == SL_F16) {
         if (geom->cin % 128 || geom->cout % 128) return 0;
-        return wgrad_tn_bf16_workspace_bytes(geom, cfg, 1);
+        return dtype == SL_F16 ? wgrad_tn_f16_workspace_bytes(geom, cfg, 1) : wgrad_tn_bf16_workspace_bytes(geom, cfg, 1);
     }
     if (geom->cin % 64 || geom->cout % 64) return 0;
     const int splits = wgrad_split_count(geom, wgrad_f32_tile(geom, cfg));
@@ -137,13 +141,15 @@ extern "C" size_t sl_conv1d_wgrad_workspace_bytes(const sl_conv_geom* geom, int 
 
 extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl_conv_geom* geom, int dtype, int cfg,
                                void* workspace, size_t workspace_bytes, void* stream) {
-    SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32, "sl_conv1d_wgrad: unknown dtype %d", dtype);
-    const int tile = dtype == SL_BF16 ? 128 : 64;
+    SL_CHECK_ARG(dtype == SL_BF16 || dtype == SL_F32 || dtype == SL_F16, "sl_conv1d_wgrad: unknown dtype %d", dtype);
+    const int tile = dtype == SL_F32 ? 64 : 128;
     int rc = check_geom(geom, "sl_conv1d_wgrad", tile, tile);
     if (rc != SL_OK) return rc;
     SL_CHECK_ARG(x && g && dw, "sl_conv1d_wgrad: null tensor pointer");
     if (dtype == SL_BF16)
         return wgrad_tn_bf16(x, g, dw, geom, cfg, 1, 0, 0, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    if (dtype == SL_F16)
+        return wgrad_tn_f16(x, g, dw, geom, cfg, 1, 0, 0, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
     const int splits = wgrad_split_count(geom, wgrad_f32_tile(geom, cfg));
     const size_t need = sl_conv1d_wgrad_workspace_bytes(geom, dtype, cfg);
     if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
@@ -154,15 +160,16 @@ extern "C" int sl_conv1d_wgrad(const void* x, const void* g, float* dw, const sl
 }
 
 extern "C" size_t sl_conv1d_wgrad_multi_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs, int dtype) {
-    if (!jobs || dtype != SL_BF16) return 0;
-    return wgrad_multi_bf16_workspace_bytes(jobs, n_jobs);
+    if (!jobs || (dtype != SL_BF16 && dtype != SL_F16)) return 0;
+    return dtype == SL_F16 ? wgrad_multi_f16_workspace_bytes(jobs, n_jobs) : wgrad_multi_bf16_workspace_bytes(jobs, n_jobs);
 }
 
 extern "C" int sl_conv1d_wgrad_multi(const sl_wgrad_job* jobs, int n_jobs, int dtype, void* workspace,
                                      size_t workspace_bytes, void* stream) {
     SL_CHECK_ARG(jobs != nullptr, "sl_conv1d_wgrad_multi: jobs is null");
+    if (dtype == SL_F16) return wgrad_multi_f16(jobs, n_jobs, workspace, workspace_bytes, (hipStream_t)stream);
     if (dtype != SL_BF16) {
-        sl_set_error("sl_conv1d_wgrad_multi: bf16 only");
+        sl_set_error("sl_conv1d_wgrad_multi: bf16 / f16 only");
         return SL_ERR_UNSUPPORTED;
     }
     return wgrad_multi_bf16(jobs, n_jobs, workspace, workspace_bytes, (hipStream_t)stream);

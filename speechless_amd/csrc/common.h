@@ -15,6 +15,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+// Element type of the 16-bit MFMA operands of conv_nt_bf16.hip / wgrad_tn_bf16.hip: bf16 -- or, in the translation units that
+// build.py compiles a second time with -DSL_ELEM_F16 (conv_nt_f16.o, wgrad_tn_f16.o), fp16: the "f16x3" parity path
+// (DESIGN.md section 1).  Tiles move as 16-bit words either way; only the matrix instruction and the plane conversions differ.
+typedef _Float16 sl_half8 __attribute__((ext_vector_type(8)));
+#if defined(SL_ELEM_F16)
+#define SL_MFMA16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sl_half8, (a)), __builtin_bit_cast(sl_half8, (b)), (c), 0, 0, 0)
+#define SL_MFMA32(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sl_half8, (a)), __builtin_bit_cast(sl_half8, (b)), (c), 0, 0, 0)
+#else
+#define SL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define SL_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
+
 #define SL_LDS __attribute__((address_space(3)))
 #define SL_GLOBAL __attribute__((address_space(1)))
 
@@ -75,6 +89,19 @@ __device__ __forceinline__ unsigned int pack_bf16x2_hw(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
 
+// fp32 <-> fp16 (round to nearest even, v_cvt_f16_f32; clamped to the largest finite fp16 so that an out-of-range value of the
+// f16x3 planes stays a number -- the scales of that path keep everything far inside)
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f) {
+    const _Float16 h = (_Float16)fminf(fmaxf(f, -65504.f), 65504.f);
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
+    return (unsigned int)f32_to_f16_bits(lo) | ((unsigned int)f32_to_f16_bits(hi) << 16);
+}
+__device__ __forceinline__ float f16_lo_to_f32(unsigned int u) { return f16_bits_to_f32((unsigned short)(u & 0xFFFFu)); }
+__device__ __forceinline__ float f16_hi_to_f32(unsigned int u) { return f16_bits_to_f32((unsigned short)(u >> 16)); }
+
 // dropout: counter-based generator, one 64-bit mix (splitmix64 finaliser) of (seed, element index) -> 32 uniform bits.  The
 // mask of an element depends only on (seed, index), so a step is reproducible from its seed and no state is kept.
 __device__ __forceinline__ unsigned int dropout_bits(unsigned long long seed, unsigned long long idx) {
@@ -122,3 +149,12 @@ int conv1x1_bwd_bf16(const void* x, const void* gr, const void* w_dgrad, void* d
                      int epilogue, int cfg, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t wgrad_multi_bf16_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs);
 int wgrad_multi_bf16(const sl_wgrad_job* jobs, int n_jobs, void* ws, size_t ws_bytes, hipStream_t s);
+// the same entry points of the -DSL_ELEM_F16 translation units (fp16 operands: SL_F16)
+int conv_nt_f16(const void* x, const void* w, const float* bias, const void* mask, void* y, const sl_conv_geom* g,
+                int epilogue, int out_f32, int cfg, void* workspace, size_t workspace_bytes, hipStream_t s);
+size_t conv_nt_f16_workspace_bytes(const sl_conv_geom* g, int cfg);
+int wgrad_tn_f16(const void* x, const void* gr, float* dw, const sl_conv_geom* g, int cfg, int groups, long x_gs,
+                 long g_gs, long dw_gs, float* ws, size_t ws_bytes, hipStream_t s);
+size_t wgrad_tn_f16_workspace_bytes(const sl_conv_geom* g, int cfg, int groups);
+size_t wgrad_multi_f16_workspace_bytes(const sl_wgrad_job* jobs, int n_jobs);
+int wgrad_multi_f16(const sl_wgrad_job* jobs, int n_jobs, void* ws, size_t ws_bytes, hipStream_t s);

@@ -57,6 +57,7 @@ struct NtArgs {
     int y_row0, y_rs;
     long y_bs;
     int cout;
+    float acc_scale;  // SL_ELEM_F16 build only: the accumulator is multiplied by this before bias / mask (sl_conv_geom.acc_scale)
     int out_planes;  // fp32-output kernels only: 0 = fp32 store; bf16x3 planes [hi | lo | hi] instead: 1 = after ReLU, 2 = as is, 3 = after the ReLU mask
     int w_rs;    // taps * cin
     int taps, cin;
@@ -127,12 +128,34 @@ __device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_floa
 __device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
 __device__ __forceinline__ float elu_grad_from_y(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
+// ---- hi + lo planes of the fp32-output kernels (out_planes): bf16 pairs ("bf16x3"), or -- the translation unit built with
+// -DSL_ELEM_F16 ("f16x3") -- fp16 pairs: hi = fp16(v), lo = fp16(v - hi), 22 significand bits where |v| >= 2^-3 and an
+// absolute 2^-25 below (the lo plane runs into fp16's denormals, which v_mfma_f32_16x16x32_f16 keeps: tools/f16_denorm_probe.hip)
+#if defined(SL_ELEM_F16)
+__device__ __forceinline__ unsigned int plane_pack_hi(float a0, float a1) { return pack_f16x2(a0, a1); }
+__device__ __forceinline__ unsigned int plane_pack_lo(float a0, float a1, unsigned int h) {
+    return pack_f16x2(a0 - f16_lo_to_f32(h), a1 - f16_hi_to_f32(h));
+}
+#define SL_NT_ACC_SCALE(v, a) ((v) * (a).acc_scale)
+#define SL_NT_ACC_SCALE_BIAS(v, b, a) fmaf((v), (a).acc_scale, (b))
+#else
+__device__ __forceinline__ unsigned int plane_pack_hi(float a0, float a1) { return pack_bf16x2(a0, a1); }
+__device__ __forceinline__ unsigned int plane_pack_lo(float a0, float a1, unsigned int h) {
+    return pack_bf16x2(a0 - __uint_as_float(h << 16), a1 - __uint_as_float(h & 0xFFFF0000u));
+}
+#define SL_NT_ACC_SCALE(v, a) (v)
+#define SL_NT_ACC_SCALE_BIAS(v, b, a) ((v) + (b))
+#endif
+
 // epilogue of one run of 16 consecutive output channels of one time row
 template <int MODE, bool OUT_F32>
 __device__ __forceinline__ void store_run16(const NtArgs& a, float (&v)[16], const float (&bias_v)[16], long yidx) {
     if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU || MODE == SL_EPI_BIAS_ELU) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] += bias_v[i];
+        for (int i = 0; i < 16; ++i) v[i] = SL_NT_ACC_SCALE_BIAS(v[i], bias_v[i], a);
+    } else if (MODE != MODE_PARTIAL) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = SL_NT_ACC_SCALE(v[i], a);
     }
     if (MODE == SL_EPI_BIAS_RELU) {
 #pragma unroll
@@ -193,10 +216,10 @@ __device__ __forceinline__ void store_run16(const NtArgs& a, float (&v)[16], con
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float a0 = v[i * 2], a1 = v[i * 2 + 1], b0 = v[8 + i * 2], b1 = v[8 + i * 2 + 1];
-                h0[i] = pack_bf16x2(a0, a1);
-                h1[i] = pack_bf16x2(b0, b1);
-                l0[i] = pack_bf16x2(a0 - __uint_as_float(h0[i] << 16), a1 - __uint_as_float(h0[i] & 0xFFFF0000u));
-                l1[i] = pack_bf16x2(b0 - __uint_as_float(h1[i] << 16), b1 - __uint_as_float(h1[i] & 0xFFFF0000u));
+                h0[i] = plane_pack_hi(a0, a1);
+                h1[i] = plane_pack_hi(b0, b1);
+                l0[i] = plane_pack_lo(a0, a1, h0[i]);
+                l1[i] = plane_pack_lo(b0, b1, h1[i]);
             }
             __bf16* yo = (__bf16*)a.y + yidx;
             *(u32x4*)(yo) = h0;
@@ -259,7 +282,7 @@ struct IlvPhase {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int m = G * Q + j;
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[m / IT], cb[m % IT], acc[m], 0, 0, 0);
+            acc[m] = SL_MFMA16(ca[m / IT], cb[m % IT], acc[m]);
         }
         // (a fence here, forcing the group's MFMAs to issue before its read / request, measured slower: 2.291 vs 2.283 ms)
         read_one<RPG * Q>(na, nb, a_addr, b_addr);
@@ -437,14 +460,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
                 for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
-                        acc32[jn * 2 + it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2 * 2 + jn], bfr[k2 * 2 + it],
-                                                                                     acc32[jn * 2 + it], 0, 0, 0);
+                        acc32[jn * 2 + it] = SL_MFMA32(af[k2 * 2 + jn], bfr[k2 * 2 + it],
+                                                                                     acc32[jn * 2 + it]);
         } else {
 #pragma unroll
             for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
                 for (int it = 0; it < IT; ++it)
-                    acc[jn * IT + it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn * IT + it], 0, 0, 0);
+                    acc[jn * IT + it] = SL_MFMA16(af[jn], bfr[it], acc[jn * IT + it]);
         }
     };
 
@@ -818,7 +841,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void conv_nt
         for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
             for (int it = 0; it < IT; ++it)
-                acc[jn * IT + it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[jn], bfr[it], acc[jn * IT + it], 0, 0, 0);
+                acc[jn * IT + it] = SL_MFMA16(af[jn], bfr[it], acc[jn * IT + it]);
     };
 
     NtArgs e = a;  // epilogue arguments pinned in SGPRs before the loop, see conv_nt_bf16_kernel
@@ -1407,10 +1430,10 @@ __global__ __launch_bounds__(256, 1) void output_softmax_kernel(const __bf16* __
         ds_read128<0>(bfr[0], b_addr);
         ds_read128<0>(bfr[1], b_addr ^ 64);
         wait_frags<0>(af, bfr);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bfr[0], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[1], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3], bfr[1], acc[1], 0, 0, 0);
+        acc[0] = SL_MFMA16(af[0], bfr[0], acc[0]);
+        acc[1] = SL_MFMA16(af[2], bfr[0], acc[1]);
+        acc[0] = SL_MFMA16(af[1], bfr[1], acc[0]);
+        acc[1] = SL_MFMA16(af[3], bfr[1], acc[1]);
         slot = (slot + 1 == SLOTS) ? 0 : slot + 1;
     }
 
@@ -1509,7 +1532,7 @@ __global__ __launch_bounds__(256, 1) void output_softmax_regw_kernel(const __bf1
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2 * c + h], bfr[4 * h + i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SL_MFMA16(wf[j][2 * c + h], bfr[4 * h + i], acc[i][j]);
     }
 #endif
     // ---- the four waves' partial tiles meet in LDS (the rings are drained): part[wave][row tile][class tile][lane] f32x4
@@ -1563,7 +1586,10 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
     const long yidx = (long)b * a.y_bs + (long)(a.y_row0 + t) * a.y_rs + co;
     if (MODE == SL_EPI_BIAS || MODE == SL_EPI_BIAS_RELU || MODE == SL_EPI_BIAS_ELU) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += a.bias[co + j];
+        for (int j = 0; j < 8; ++j) v[j] = SL_NT_ACC_SCALE_BIAS(v[j], a.bias[co + j], a);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = SL_NT_ACC_SCALE(v[j], a);
     }
     if (MODE == SL_EPI_BIAS_RELU) {
 #pragma unroll
@@ -1608,8 +1634,8 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(NtArgs a, int r
             u32x4 h, l;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                h[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-                l[j] = pack_bf16x2(v[2 * j] - __uint_as_float(h[j] << 16), v[2 * j + 1] - __uint_as_float(h[j] & 0xFFFF0000u));
+                h[j] = plane_pack_hi(v[2 * j], v[2 * j + 1]);
+                l[j] = plane_pack_lo(v[2 * j], v[2 * j + 1], h[j]);
             }
             __bf16* yo = (__bf16*)a.y + yidx;
             *(u32x4*)yo = h;
@@ -1691,6 +1717,7 @@ int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
             if (epilogue == SL_EPI_BIAS) return launch_tail<SL_EPI_BIAS, true>(a, rows, s);
             if (epilogue == SL_EPI_NONE) return launch_tail<SL_EPI_NONE, true>(a, rows, s);
         } else {
+#if !defined(SL_ELEM_F16)  // (the fp16 build serves the plane path only: fp32 or plane outputs)
             switch (epilogue) {
                 case SL_EPI_NONE: return launch_tail<SL_EPI_NONE, false>(a, rows, s);
                 case SL_EPI_BIAS: return launch_tail<SL_EPI_BIAS, false>(a, rows, s);
@@ -1699,11 +1726,13 @@ int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
                 case SL_EPI_BIAS_ELU: return launch_tail<SL_EPI_BIAS_ELU, false>(a, rows, s);
                 case SL_EPI_ELU_MASK: return launch_tail<SL_EPI_ELU_MASK, false>(a, rows, s);
             }
+#endif
         }
     } else if (out_f32) {
         if (epilogue == SL_EPI_BIAS) return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS, true>(a, s);
         if (epilogue == SL_EPI_NONE) return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_NONE, true>(a, s);
     } else {
+#if !defined(SL_ELEM_F16)
         switch (epilogue) {
             case SL_EPI_NONE: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_NONE, false>(a, s);
             case SL_EPI_BIAS: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS, false>(a, s);
@@ -1712,6 +1741,7 @@ int launch_cfg(NtArgs& a, int epilogue, int out_f32, hipStream_t s) {
             case SL_EPI_BIAS_ELU: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_BIAS_ELU, false>(a, s);
             case SL_EPI_ELU_MASK: return launch_main<M32, IT, WM, WN, STAGES, SL_EPI_ELU_MASK, false>(a, s);
         }
+#endif
     }
     sl_set_error("sl_conv1d_nt(bf16): unsupported epilogue %d with out_f32=%d", epilogue, out_f32);
     return SL_ERR_UNSUPPORTED;
@@ -1850,6 +1880,11 @@ bool valid_cfg(const Cfg& full, const sl_conv_geom* g) {
 
 }  // namespace
 
+#if defined(SL_ELEM_F16)  // the second translation unit of this file: same kernels on v_mfma_*_f16, exported under these names
+#define conv_nt_bf16_workspace_bytes conv_nt_f16_workspace_bytes
+#define conv_nt_bf16 conv_nt_f16
+#endif
+
 size_t conv_nt_bf16_workspace_bytes(const sl_conv_geom* g, int cfg) {
     Cfg c = cfg ? decode_cfg(cfg) : auto_cfg(g);
     if (!valid_cfg(c, g) || c.ksplit <= 1) return 0;
@@ -1868,6 +1903,7 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
     }
     NtArgs a;
     a.out_planes = 0;
+    a.acc_scale = g->acc_scale != 0.f ? g->acc_scale : 1.f;
     if (out_f32 == 2) {  // bf16x3 planes out of the fp32-output kernels: the activation moves from the template to a.out_planes
         if (epilogue == SL_EPI_BIAS_RELU) {
             a.out_planes = 1;
@@ -2000,6 +2036,7 @@ int conv_nt_bf16(const void* x, const void* w, const float* bias, const void* ma
     return SL_ERR_UNSUPPORTED;
 }
 
+#if !defined(SL_ELEM_F16)  // (the fused output layer belongs to the bf16 path: one definition, in the bf16 translation unit)
 // ---- fused output layer (declared in capi.hip's dispatch: sl_output_softmax)
 bool output_softmax_supported(const sl_conv_geom* g, int k) {
     if (g->taps != 1 || k < 1 || k > 32 || g->cout < 32 || g->cin % BK) return false;
@@ -2061,3 +2098,4 @@ int output_softmax_bf16(const void* x, const void* w, const float* bias, float* 
                            logit_batch_stride, eps);
     return sl_check_launch("sl_output_softmax");
 }
+#endif  // !SL_ELEM_F16

@@ -191,15 +191,26 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // 4 fp32 reads + 3 fp32 writes + 2 narrow writes per parameter instead of Adam (4r+3w) followed by pack (1r+2w).
 // grid (cout/64, cin/32, k + 1): z == k is the bias block (only y == 0 works there).
 // PLANES = 3 (bf16x3, T = unsigned short): the operand rows are [w_hi | w_hi | w_lo], w_hi = bf16(w), w_lo = bf16(w - w_hi).
+// FMT (PLANES = 3 only): 0 = bf16 planes, 1 = fp16 planes of wscale * w (f16x3: wscale a power of two, see split3.hip)
+template <int FMT>
+__device__ __forceinline__ u32x2 pack_hi4(float a0, float a1, float a2, float a3) {
+    if (FMT == 1) return (u32x2){pack_f16x2(a0, a1), pack_f16x2(a2, a3)};
+    return (u32x2){pack_bf16x2(a0, a1), pack_bf16x2(a2, a3)};
+}
+template <int FMT>
 __device__ __forceinline__ u32x2 pack_lo4(float a0, float a1, float a2, float a3) {
+    if (FMT == 1) {
+        auto lo = [](float v) { return v - f16_bits_to_f32(f32_to_f16_bits(v)); };
+        return (u32x2){pack_f16x2(lo(a0), lo(a1)), pack_f16x2(lo(a2), lo(a3))};
+    }
     auto lo = [](float v) { return v - bf16_bits_to_f32(f32_to_bf16_bits(v)); };
     return (u32x2){pack_bf16x2(lo(a0), lo(a1)), pack_bf16x2(lo(a2), lo(a3))};
 }
-template <typename T, bool ADAM = true, int PLANES = 1>
+template <typename T, bool ADAM = true, int PLANES = 1, int FMT = 0>
 __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __restrict__ p, const float* __restrict__ g,
                                                 float* __restrict__ m, float* __restrict__ v, T* __restrict__ wf,
                                                 T* __restrict__ wd, int k, int cin, int cout, float lr_t, float b1,
-                                                float b2, float eps, int bx, int by, int bz) {
+                                                float b2, float eps, int bx, int by, int bz, float wscale = 1.f) {
     const int tap = bz;
     const int co0 = bx * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -227,16 +238,17 @@ __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __
     for (int r = 0; r < 2; ++r) {
         const int cil = ty + r * 16;
         const long idx = ((long)tap * cin + ci0 + cil) * cout + co0 + tx * 4;
-        const f32x4 pv = adam4(idx);
+        f32x4 pv = adam4(idx);
+        if (FMT == 1) pv = pv * wscale;  // (the operand copies hold wscale * w; the masters were written by adam4)
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[cil][tx * 4 + j] = pv[j];
         if (wd) {
             T* o = wd + ((long)(ci0 + cil) * k + (k - 1 - tap)) * (PLANES * cout) + co0 + tx * 4;
             if (PLANES == 3) {
-                const u32x2 h = (u32x2){pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+                const u32x2 h = pack_hi4<FMT>(pv[0], pv[1], pv[2], pv[3]);
                 *(u32x2*)o = h;
                 *(u32x2*)(o + cout) = h;
-                *(u32x2*)(o + 2 * cout) = pack_lo4(pv[0], pv[1], pv[2], pv[3]);
+                *(u32x2*)(o + 2 * cout) = pack_lo4<FMT>(pv[0], pv[1], pv[2], pv[3]);
             } else if (sizeof(T) == 2) {
                 *(u32x2*)o = (u32x2){pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
             } else {
@@ -253,10 +265,10 @@ __device__ __forceinline__ void adam_pack_block(float (&tile)[32][65], float* __
         T* o = wf + ((long)(co0 + col) * k + tap) * (PLANES * cin) + ci0 + ci4;
         const float a0 = tile[ci4][col], a1 = tile[ci4 + 1][col], a2 = tile[ci4 + 2][col], a3 = tile[ci4 + 3][col];
         if (PLANES == 3) {
-            const u32x2 h = (u32x2){pack_bf16x2(a0, a1), pack_bf16x2(a2, a3)};
+            const u32x2 h = pack_hi4<FMT>(a0, a1, a2, a3);
             *(u32x2*)o = h;
             *(u32x2*)(o + cin) = h;
-            *(u32x2*)(o + 2 * cin) = pack_lo4(a0, a1, a2, a3);
+            *(u32x2*)(o + 2 * cin) = pack_lo4<FMT>(a0, a1, a2, a3);
         } else if (sizeof(T) == 2) {
             *(u32x2*)o = (u32x2){pack_bf16x2(a0, a1), pack_bf16x2(a2, a3)};
         } else {
@@ -285,10 +297,10 @@ struct AdamTable {
     int k[SL_ADAM_MAX_LAYERS], cin[SL_ADAM_MAX_LAYERS], cout[SL_ADAM_MAX_LAYERS];
 };
 
-template <typename T, bool ADAM = true, int PLANES = 1>
+template <typename T, bool ADAM = true, int PLANES = 1, int FMT = 0>
 __global__ __launch_bounds__(256) void adam_pack_multi_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ m, float* __restrict__ v, AdamTable t,
-                                                              float lr_t, float b1, float b2, float eps) {
+                                                              float lr_t, float b1, float b2, float eps, float wscale = 1.f) {
     __shared__ float tile[32][65];
     int layer = 0;
     while (layer + 1 < t.n && (int)blockIdx.x >= t.block_begin[layer + 1]) ++layer;
@@ -298,8 +310,9 @@ __global__ __launch_bounds__(256) void adam_pack_multi_kernel(float* __restrict_
     const int bx = local % nx, by = (local / nx) % ny, bz = local / (nx * ny);
     const long off = t.offset[layer];
     if (!ADAM && bz == k) return;  // (the bias block has no operand copy)
-    adam_pack_block<T, ADAM, PLANES>(tile, p + off, ADAM ? g + off : nullptr, ADAM ? m + off : nullptr, ADAM ? v + off : nullptr,
-                             (T*)t.wf[layer], (T*)t.wd[layer], k, cin, cout, lr_t, b1, b2, eps, bx, by, bz);
+    adam_pack_block<T, ADAM, PLANES, FMT>(tile, p + off, ADAM ? g + off : nullptr, ADAM ? m + off : nullptr,
+                                          ADAM ? v + off : nullptr, (T*)t.wf[layer], (T*)t.wd[layer], k, cin, cout, lr_t, b1, b2,
+                                          eps, bx, by, bz, wscale);
 }
 
 }  // namespace
@@ -358,8 +371,24 @@ extern "C" int sl_split3_adam_pack_layers(float* param, const float* grad, float
     if (rc != SL_OK) return rc;
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
     hipLaunchKernelGGL((adam_pack_multi_kernel<unsigned short, true, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, param,
-                       grad, m, v, t, (float)lr_t, beta1, beta2, eps);
+                       grad, m, v, t, (float)lr_t, beta1, beta2, eps, 1.f);
     return sl_check_launch("sl_split3_adam_pack_layers");
+}
+
+extern "C" int sl_splitf16_adam_pack_layers(float* param, const float* grad, float* m, float* v, const sl_adam_layer* layers,
+                                            int n_layers, int step, float lr, float beta1, float beta2, float eps,
+                                            float w_scale, void* stream) {
+    SL_CHECK_ARG(param && grad && m && v && layers && w_scale > 0.f, "sl_splitf16_adam_pack_layers: null pointer or bad scale");
+    SL_CHECK_ARG(n_layers >= 1 && n_layers <= SL_ADAM_MAX_LAYERS && step >= 1, "sl_splitf16_adam_pack_layers: 1..%d layers per call",
+                 SL_ADAM_MAX_LAYERS);
+    AdamTable t;
+    int blocks = 0;
+    const int rc = adam_table_from(layers, n_layers, "sl_splitf16_adam_pack_layers", &t, &blocks);
+    if (rc != SL_OK) return rc;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    hipLaunchKernelGGL((adam_pack_multi_kernel<unsigned short, true, 3, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       param, grad, m, v, t, (float)lr_t, beta1, beta2, eps, w_scale);
+    return sl_check_launch("sl_splitf16_adam_pack_layers");
 }
 
 extern "C" int sl_pack_layers(const float* param, const sl_adam_layer* layers, int n_layers, int dtype, void* stream) {

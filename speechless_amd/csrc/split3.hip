@@ -16,15 +16,32 @@
 
 namespace {
 
+// The two plane formats.  bf16 pairs ("bf16x3"): 16-17 significand bits at fp32's range.  fp16 pairs ("f16x3", round 6): hi =
+// fp16(v), lo = fp16(v - hi) -- 22 bits where |v| >= 2^-3, an absolute 2^-25 below that (lo runs into fp16's denormals, which
+// v_mfma_f32_16x16x32_f16 keeps: tools/f16_denorm_probe.hip), range 65504: the engine keeps weights and back-propagated
+// gradients scaled by powers of two so that typical magnitudes sit near 1 (speechless_amd/engine_x3.py).
+struct PlaneBf16 {
+    static __device__ __forceinline__ unsigned short enc(float v) { return f32_to_bf16_bits(v); }
+    static __device__ __forceinline__ float dec(unsigned short b) { return bf16_bits_to_f32(b); }
+};
+struct PlaneF16 {
+    static __device__ __forceinline__ unsigned short enc(float v) { return f32_to_f16_bits(v); }
+    static __device__ __forceinline__ float dec(unsigned short b) { return f16_bits_to_f32(b); }
+};
+template <typename F>
 __device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
-    hi = f32_to_bf16_bits(v);
-    lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+    hi = F::enc(v);
+    lo = F::enc(v - F::dec(hi));
 }
+template <typename F>
+__device__ __forceinline__ float dec_lo16(unsigned int w) { return F::dec((unsigned short)(w & 0xFFFFu)); }
+template <typename F>
+__device__ __forceinline__ float dec_hi16(unsigned int w) { return F::dec((unsigned short)(w >> 16)); }
 
 // src: fp32 [B][src_rows][C] (row t of utterance b at b * src_bs + t * C), valid rows t < t_out
 // dst: planes [B][dst_rows][3 C] at row dst_row0 + t; rows outside [0, t_out) are never written (they stay zero)
 // mode 0: none, 1: relu, 2: elu, 3: relu mask, 4: elu mask (mask: a plane tensor of dst's geometry -- the stored activation)
-template <int MODE>
+template <int MODE, typename F>
 __global__ __launch_bounds__(256) void split3_act_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                          const unsigned short* __restrict__ mask, int t_out, int c,
                                                          long src_bs, int dst_row0, long dst_bs) {
@@ -42,8 +59,8 @@ __global__ __launch_bounds__(256) void split3_act_kernel(const float* __restrict
         if (MODE == 4) ml = *(const u32x4*)(mask + row + c + ch);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            y[2 * j] = __uint_as_float(mh[j] << 16) + (MODE == 4 ? __uint_as_float(ml[j] << 16) : 0.f);
-            y[2 * j + 1] = __uint_as_float(mh[j] & 0xFFFF0000u) + (MODE == 4 ? __uint_as_float(ml[j] & 0xFFFF0000u) : 0.f);
+            y[2 * j] = dec_lo16<F>(mh[j]) + (MODE == 4 ? dec_lo16<F>(ml[j]) : 0.f);
+            y[2 * j + 1] = dec_hi16<F>(mh[j]) + (MODE == 4 ? dec_hi16<F>(ml[j]) : 0.f);
         }
     }
     unsigned short hi[8], lo[8];
@@ -54,7 +71,7 @@ __global__ __launch_bounds__(256) void split3_act_kernel(const float* __restrict
         if (MODE == 2) v = v > 0.f ? v : expm1f(v);
         if (MODE == 3) v = y[j] > 0.f ? v : 0.f;
         if (MODE == 4) v = y[j] > 0.f ? v : v * (y[j] + 1.f);
-        split2(v, hi[j], lo[j]);
+        split2<F>(v, hi[j], lo[j]);
     }
     u32x4 h, l;
 #pragma unroll
@@ -68,6 +85,7 @@ __global__ __launch_bounds__(256) void split3_act_kernel(const float* __restrict
 }
 
 // input packing (sl_pack_input for planes): src float[B][t_in][f] -> dst [B][rows][3 * c] at row dst_row0 + t, channels >= f zero
+template <typename F>
 __global__ __launch_bounds__(256) void pack_input3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                           int t_in, int f, int c, int dst_row0, long dst_bs) {
     const int b = blockIdx.y;
@@ -75,7 +93,7 @@ __global__ __launch_bounds__(256) void pack_input3_kernel(const float* __restric
     if (i >= (long)t_in * c) return;
     const int t = (int)(i / c), ch = (int)(i % c);
     unsigned short hi = 0, lo = 0;
-    if (ch < f) split2(src[((long)b * t_in + t) * f + ch], hi, lo);
+    if (ch < f) split2<F>(src[((long)b * t_in + t) * f + ch], hi, lo);
     unsigned short* row = dst + (long)b * dst_bs + (long)(dst_row0 + t) * (3 * c);
     row[ch] = hi;
     row[c + ch] = lo;
@@ -97,8 +115,10 @@ __global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict_
 // + 2 x sl_split3_assemble produce in five: 55 launches per optimisation step for the eleven layers):
 //   w_fwd3 [cout][k][3 cin]   rows [w_hi | w_hi | w_lo] over cin        w_dgrad3 [cin][k-1-tap][3 cout]  likewise over cout
 // with w_hi = bf16(v), w_lo = bf16(v - float(w_hi)).  32 x 32 LDS transpose per tap, as pack_weights_kernel.
+template <typename F>
 __global__ __launch_bounds__(256) void pack_weights3_kernel(const float* __restrict__ wm, unsigned short* __restrict__ wf,
-                                                            unsigned short* __restrict__ wd, int k, int cin, int cout) {
+                                                            unsigned short* __restrict__ wd, int k, int cin, int cout,
+                                                            float scale) {
     __shared__ float tile[32][33];
     const int tap = blockIdx.z;
     const int ci0 = blockIdx.y * 32;
@@ -107,11 +127,11 @@ __global__ __launch_bounds__(256) void pack_weights3_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int ci = ci0 + ty + r * 8;
-        const float v = wm[((long)tap * cin + ci) * cout + co0 + tx];
+        const float v = wm[((long)tap * cin + ci) * cout + co0 + tx] * scale;  // (a power of two: exact)
         tile[ty + r * 8][tx] = v;
         if (wd) {
-            const unsigned short h = f32_to_bf16_bits(v);
-            const unsigned short l = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+            unsigned short h, l;
+            split2<F>(v, h, l);
             unsigned short* o = wd + ((long)ci * k + (k - 1 - tap)) * 3 * cout + co0 + tx;
             o[0] = h;
             o[cout] = h;
@@ -123,8 +143,8 @@ __global__ __launch_bounds__(256) void pack_weights3_kernel(const float* __restr
     for (int r = 0; r < 4; ++r) {
         const int co = co0 + ty + r * 8;
         const float v = tile[tx][ty + r * 8];
-        const unsigned short h = f32_to_bf16_bits(v);
-        const unsigned short l = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+        unsigned short h, l;
+        split2<F>(v, h, l);
         unsigned short* o = wf + ((long)co * k + tap) * 3 * cin + ci0 + tx;
         o[0] = h;
         o[cin] = h;
@@ -153,7 +173,8 @@ __global__ __launch_bounds__(256) void assemble3_kernel(const unsigned short* __
 // row than RA's -- the two hi planes that meet in the middle of a pair row of the striding layer.)
 __global__ __launch_bounds__(256) void wgrad_combine3_kernel(const float* __restrict__ ra, const float* __restrict__ rb,
                                                              float* __restrict__ dw, int taps, int c_in, int c_out,
-                                                             int frames, int fstride, int ra_cin, int rb_cin, int rb_fstride) {
+                                                             int frames, int fstride, int ra_cin, int rb_cin, int rb_fstride,
+                                                             float scale) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= (long)taps * c_in * c_out) return;
     const int co = (int)(i % c_out);
@@ -163,12 +184,13 @@ __global__ __launch_bounds__(256) void wgrad_combine3_kernel(const float* __rest
     const float* a = ra + ((long)tv * ra_cin + f * fstride + ci) * c_out + co;
     const float* b = rb + ((long)tv * rb_cin + f * rb_fstride + ci) * c_out + co;
     const f32x4 hh = *(const f32x4*)a, hl = *(const f32x4*)b, lh = *(const f32x4*)(a + (long)c_in * c_out);
-    *(f32x4*)(dw + i) = (hh + hl) + lh;
+    *(f32x4*)(dw + i) = ((hh + hl) + lh) * scale;  // (scale: 1, or the power of two that undoes the f16x3 gradient scaling)
 }
 
 // db[co] = sum over the valid frames of (g_hi + g_lo), deterministic two-stage: grid (C / 64, BG_CHUNKS) partial sums over
 // interleaved frames (chunk j takes the frames j, j + BG_CHUNKS, ... of every utterance), then a fixed-order sum of the chunks
 constexpr int BG_CHUNKS = 64;
+template <typename F>
 __global__ __launch_bounds__(256) void bias_grad3_partial_kernel(const unsigned short* __restrict__ g, float* __restrict__ part,
                                                                  int batch, int t_out, int c, int row0, long bs) {
     __shared__ float sh[4][64];
@@ -177,19 +199,20 @@ __global__ __launch_bounds__(256) void bias_grad3_partial_kernel(const unsigned 
     for (int b = 0; b < batch; ++b)
         for (int t = blockIdx.y * 4 + sub; t < t_out; t += 4 * BG_CHUNKS) {
             const unsigned short* row = g + (long)b * bs + (long)(row0 + t) * (3 * c);
-            acc += bf16_bits_to_f32(row[ch]) + bf16_bits_to_f32(row[c + ch]);
+            acc += F::dec(row[ch]) + F::dec(row[c + ch]);
         }
     sh[sub][threadIdx.x & 63] = acc;
     __syncthreads();
     if (threadIdx.x < 64)
         part[(long)blockIdx.y * c + ch] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
-__global__ __launch_bounds__(256) void bias_grad3_final_kernel(const float* __restrict__ part, float* __restrict__ db, int c) {
+__global__ __launch_bounds__(256) void bias_grad3_final_kernel(const float* __restrict__ part, float* __restrict__ db, int c,
+                                                               float scale) {
     const int ch = blockIdx.x * 256 + threadIdx.x;
     if (ch >= c) return;
     float s = 0.f;
     for (int j = 0; j < BG_CHUNKS; ++j) s += part[(long)j * c + ch];
-    db[ch] = s;
+    db[ch] = s * scale;
 }
 
 // Dropout on a plane tensor (rows of [hi | lo | hi] over c channels).  The keep decision of the element in row r, channel ch
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(256) void bias_grad3_final_kernel(const float* __re
 //                                                                                post-dropout activation)
 //   MODE 2  ELU bwd:   dst = keep ? (hi + lo) * scale * elu'(z) : 0, elu'(z) = m > 0 ? 1 : m * keep_prob + 1 with m the stored
 //                      post-dropout activation y (planes, same geometry)
-template <int MODE>
+template <int MODE, typename F>
 __global__ __launch_bounds__(256) void split3_dropout_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
                                                              const unsigned short* __restrict__ y, long n, int c,
                                                              unsigned int threshold, float scale, float keep_prob,
@@ -222,18 +245,16 @@ __global__ __launch_bounds__(256) void split3_dropout_kernel(const unsigned shor
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const unsigned hw = sh[j >> 1], lw = sl[j >> 1];
-        float v = (j & 1) ? __uint_as_float(hw & 0xFFFF0000u) + __uint_as_float(lw & 0xFFFF0000u)
-                          : __uint_as_float(hw << 16) + __uint_as_float(lw << 16);
+        float v = (j & 1) ? dec_hi16<F>(hw) + dec_hi16<F>(lw) : dec_lo16<F>(hw) + dec_lo16<F>(lw);
         const bool keep = MODE == 1 || dropout_bits(seed, (unsigned long long)(i + j)) >= threshold;
         float d = scale;
         if (MODE == 2) {
             const unsigned a = yh[j >> 1], b = yl[j >> 1];
-            const float m = (j & 1) ? __uint_as_float(a & 0xFFFF0000u) + __uint_as_float(b & 0xFFFF0000u)
-                                    : __uint_as_float(a << 16) + __uint_as_float(b << 16);
+            const float m = (j & 1) ? dec_hi16<F>(a) + dec_hi16<F>(b) : dec_lo16<F>(a) + dec_lo16<F>(b);
             d = m > 0.f ? scale : scale * (m * keep_prob + 1.f);
         }
         v = keep ? v * d : 0.f;
-        split2(v, hi[j], lo[j]);
+        split2<F>(v, hi[j], lo[j]);
     }
     u32x4 h, l;
 #pragma unroll
@@ -248,18 +269,21 @@ __global__ __launch_bounds__(256) void split3_dropout_kernel(const unsigned shor
 
 }  // namespace
 
-extern "C" int sl_split3_dropout(const void* src, void* dst, const void* y, int64_t rows, int channels, int mode, float rate,
-                                 uint64_t seed, void* stream) {
-    SL_CHECK_ARG(src && dst && rows > 0 && channels > 0 && channels % 8 == 0, "sl_split3_dropout: channels must be a multiple of 8");
-    SL_CHECK_ARG(mode >= 0 && mode <= 2 && (mode != 2 || y), "sl_split3_dropout: mode 0..2, mode 2 needs the stored activation");
-    SL_CHECK_ARG(rate >= 0.f && rate < 1.f, "sl_split3_dropout: rate %f outside [0, 1)", (double)rate);
+// ---- host side.  Every plane entry point exists twice: sl_split3* (bf16 planes) and sl_splitf16* (fp16 planes); the twins that
+// touch scaled quantities (weights, bias gradients) take the power-of-two scale.
+template <typename F>
+static int dropout_impl(const char* who, const void* src, void* dst, const void* y, int64_t rows, int channels, int mode,
+                        float rate, uint64_t seed, void* stream) {
+    SL_CHECK_ARG(src && dst && rows > 0 && channels > 0 && channels % 8 == 0, "%s: channels must be a multiple of 8", who);
+    SL_CHECK_ARG(mode >= 0 && mode <= 2 && (mode != 2 || y), "%s: mode 0..2, mode 2 needs the stored activation", who);
+    SL_CHECK_ARG(rate >= 0.f && rate < 1.f, "%s: rate %f outside [0, 1)", who, (double)rate);
     const unsigned int threshold = (unsigned int)((double)rate * 4294967296.0);
     const float scale = 1.f / (1.f - rate);
     const long n = (long)rows * channels;
     const dim3 grid((unsigned)((n / 8 + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
 #define SL_DROP3(M_)                                                                                                       \
-    hipLaunchKernelGGL(split3_dropout_kernel<M_>, grid, dim3(256), 0, s, (const unsigned short*)src, (unsigned short*)dst, \
+    hipLaunchKernelGGL((split3_dropout_kernel<M_, F>), grid, dim3(256), 0, s, (const unsigned short*)src, (unsigned short*)dst, \
                        (const unsigned short*)y, n, channels, threshold, scale, 1.f - rate, (unsigned long long)seed)
     switch (mode) {
         case 0: SL_DROP3(0); break;
@@ -267,20 +291,29 @@ extern "C" int sl_split3_dropout(const void* src, void* dst, const void* y, int6
         default: SL_DROP3(2); break;
     }
 #undef SL_DROP3
-    return sl_check_launch("sl_split3_dropout");
+    return sl_check_launch(who);
+}
+extern "C" int sl_split3_dropout(const void* src, void* dst, const void* y, int64_t rows, int channels, int mode, float rate,
+                                 uint64_t seed, void* stream) {
+    return dropout_impl<PlaneBf16>("sl_split3_dropout", src, dst, y, rows, channels, mode, rate, seed, stream);
+}
+extern "C" int sl_splitf16_dropout(const void* src, void* dst, const void* y, int64_t rows, int channels, int mode, float rate,
+                                   uint64_t seed, void* stream) {
+    return dropout_impl<PlaneF16>("sl_splitf16_dropout", src, dst, y, rows, channels, mode, rate, seed, stream);
 }
 
-extern "C" int sl_split3(const float* src, void* dst, const void* mask, int batch, int t_out, int channels,
-                         int64_t src_batch_stride, int dst_row0, int64_t dst_batch_stride, int mode, void* stream) {
+template <typename F>
+static int split_impl(const char* who, const float* src, void* dst, const void* mask, int batch, int t_out, int channels,
+                      int64_t src_batch_stride, int dst_row0, int64_t dst_batch_stride, int mode, void* stream) {
     SL_CHECK_ARG(src && dst && batch > 0 && t_out > 0 && channels > 0 && channels % 8 == 0 &&
                      (long)t_out * channels < (1L << 31),
-                 "sl_split3: channels must be a multiple of 8, t_out * channels below 2^31");
-    SL_CHECK_ARG(mode >= 0 && mode <= 4 && (mode < 3 || mask), "sl_split3: mode 0..4, modes 3 / 4 need the mask tensor");
+                 "%s: channels must be a multiple of 8, t_out * channels below 2^31", who);
+    SL_CHECK_ARG(mode >= 0 && mode <= 4 && (mode < 3 || mask), "%s: mode 0..4, modes 3 / 4 need the mask tensor", who);
     const long n8 = ((long)t_out * channels + 7) / 8;
     const dim3 grid((unsigned)((n8 + 255) / 256), batch);
     hipStream_t s = (hipStream_t)stream;
 #define SL_SPLIT3(M_)                                                                                                  \
-    hipLaunchKernelGGL(split3_act_kernel<M_>, grid, dim3(256), 0, s, src, (unsigned short*)dst, (const unsigned short*)mask, \
+    hipLaunchKernelGGL((split3_act_kernel<M_, F>), grid, dim3(256), 0, s, src, (unsigned short*)dst, (const unsigned short*)mask, \
                        t_out, channels, (long)src_batch_stride, dst_row0, (long)dst_batch_stride)
     switch (mode) {
         case 0: SL_SPLIT3(0); break;
@@ -290,16 +323,35 @@ extern "C" int sl_split3(const float* src, void* dst, const void* mask, int batc
         default: SL_SPLIT3(4); break;
     }
 #undef SL_SPLIT3
-    return sl_check_launch("sl_split3");
+    return sl_check_launch(who);
+}
+extern "C" int sl_split3(const float* src, void* dst, const void* mask, int batch, int t_out, int channels,
+                         int64_t src_batch_stride, int dst_row0, int64_t dst_batch_stride, int mode, void* stream) {
+    return split_impl<PlaneBf16>("sl_split3", src, dst, mask, batch, t_out, channels, src_batch_stride, dst_row0,
+                                 dst_batch_stride, mode, stream);
+}
+extern "C" int sl_splitf16(const float* src, void* dst, const void* mask, int batch, int t_out, int channels,
+                           int64_t src_batch_stride, int dst_row0, int64_t dst_batch_stride, int mode, void* stream) {
+    return split_impl<PlaneF16>("sl_splitf16", src, dst, mask, batch, t_out, channels, src_batch_stride, dst_row0,
+                                dst_batch_stride, mode, stream);
 }
 
+template <typename F>
+static int pack_input_impl(const char* who, const float* src, void* dst, int batch, int t_in, int f, int channels, int dst_row0,
+                           int64_t dst_batch_stride, void* stream) {
+    SL_CHECK_ARG(src && dst && batch > 0 && t_in > 0 && f > 0 && channels >= f, "%s: bad arguments", who);
+    const long n = (long)t_in * channels;
+    hipLaunchKernelGGL(pack_input3_kernel<F>, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, src,
+                       (unsigned short*)dst, t_in, f, channels, dst_row0, (long)dst_batch_stride);
+    return sl_check_launch(who);
+}
 extern "C" int sl_split3_pack_input(const float* src, void* dst, int batch, int t_in, int f, int channels, int dst_row0,
                                     int64_t dst_batch_stride, void* stream) {
-    SL_CHECK_ARG(src && dst && batch > 0 && t_in > 0 && f > 0 && channels >= f, "sl_split3_pack_input: bad arguments");
-    const long n = (long)t_in * channels;
-    hipLaunchKernelGGL(pack_input3_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, (hipStream_t)stream, src,
-                       (unsigned short*)dst, t_in, f, channels, dst_row0, (long)dst_batch_stride);
-    return sl_check_launch("sl_split3_pack_input");
+    return pack_input_impl<PlaneBf16>("sl_split3_pack_input", src, dst, batch, t_in, f, channels, dst_row0, dst_batch_stride, stream);
+}
+extern "C" int sl_splitf16_pack_input(const float* src, void* dst, int batch, int t_in, int f, int channels, int dst_row0,
+                                      int64_t dst_batch_stride, void* stream) {
+    return pack_input_impl<PlaneF16>("sl_splitf16_pack_input", src, dst, batch, t_in, f, channels, dst_row0, dst_batch_stride, stream);
 }
 
 extern "C" int sl_split3_weights(const float* v, float* hi, float* lo, size_t n, void* stream) {
@@ -309,13 +361,23 @@ extern "C" int sl_split3_weights(const float* v, float* hi, float* lo, size_t n,
     return sl_check_launch("sl_split3_weights");
 }
 
+template <typename F>
+static int pack_weights_impl(const char* who, const float* w_master, void* w_fwd3, void* w_dgrad3, int k, int cin_pad,
+                             int cout_pad, float scale, void* stream) {
+    SL_CHECK_ARG(w_master && w_fwd3 && k > 0 && cin_pad > 0 && cout_pad > 0 && cin_pad % 32 == 0 && cout_pad % 32 == 0,
+                 "%s: channel counts must be multiples of 32", who);
+    hipLaunchKernelGGL(pack_weights3_kernel<F>, dim3(cout_pad / 32, cin_pad / 32, k), dim3(256), 0, (hipStream_t)stream, w_master,
+                       (unsigned short*)w_fwd3, (unsigned short*)w_dgrad3, k, cin_pad, cout_pad, scale);
+    return sl_check_launch(who);
+}
 extern "C" int sl_split3_pack_weights(const float* w_master, void* w_fwd3, void* w_dgrad3, int k, int cin_pad, int cout_pad,
                                       void* stream) {
-    SL_CHECK_ARG(w_master && w_fwd3 && k > 0 && cin_pad > 0 && cout_pad > 0 && cin_pad % 32 == 0 && cout_pad % 32 == 0,
-                 "sl_split3_pack_weights: channel counts must be multiples of 32");
-    hipLaunchKernelGGL(pack_weights3_kernel, dim3(cout_pad / 32, cin_pad / 32, k), dim3(256), 0, (hipStream_t)stream, w_master,
-                       (unsigned short*)w_fwd3, (unsigned short*)w_dgrad3, k, cin_pad, cout_pad);
-    return sl_check_launch("sl_split3_pack_weights");
+    return pack_weights_impl<PlaneBf16>("sl_split3_pack_weights", w_master, w_fwd3, w_dgrad3, k, cin_pad, cout_pad, 1.f, stream);
+}
+extern "C" int sl_splitf16_pack_weights(const float* w_master, void* w_fwd3, void* w_dgrad3, int k, int cin_pad, int cout_pad,
+                                        float scale, void* stream) {
+    SL_CHECK_ARG(scale > 0.f, "sl_splitf16_pack_weights: scale must be positive (a power of two)");
+    return pack_weights_impl<PlaneF16>("sl_splitf16_pack_weights", w_master, w_fwd3, w_dgrad3, k, cin_pad, cout_pad, scale, stream);
 }
 
 extern "C" int sl_split3_assemble(const void* a, const void* b, void* dst, int64_t rows, int width, void* stream) {
@@ -326,35 +388,51 @@ extern "C" int sl_split3_assemble(const void* a, const void* b, void* dst, int64
     return sl_check_launch("sl_split3_assemble");
 }
 
-extern "C" int sl_split3_wgrad_combine(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out,
-                                       int frames, int fstride, int ra_cin, int rb_cin, int rb_fstride, void* stream) {
+extern "C" int sl_split3_wgrad_combine_scaled(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out,
+                                              int frames, int fstride, int ra_cin, int rb_cin, int rb_fstride, float scale,
+                                              void* stream) {
     SL_CHECK_ARG(ra && rb && dw && taps > 0 && c_in > 0 && c_out > 0 && c_out % 4 == 0 && (frames == 1 || frames == 2) &&
                      taps % frames == 0 && fstride >= 0 && rb_fstride >= 0 && ra_cin >= (frames - 1) * fstride + 2 * c_in &&
-                     rb_cin >= (frames - 1) * rb_fstride + c_in,
+                     rb_cin >= (frames - 1) * rb_fstride + c_in && scale > 0.f,
                  "sl_split3_wgrad_combine: bad arguments");
     const long n4 = (long)taps * c_in * c_out / 4;
     hipLaunchKernelGGL(wgrad_combine3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ra, rb,
-                       dw, taps, c_in, c_out, frames, fstride, ra_cin, rb_cin, rb_fstride);
+                       dw, taps, c_in, c_out, frames, fstride, ra_cin, rb_cin, rb_fstride, scale);
     return sl_check_launch("sl_split3_wgrad_combine");
+}
+extern "C" int sl_split3_wgrad_combine(const float* ra, const float* rb, float* dw, int taps, int c_in, int c_out,
+                                       int frames, int fstride, int ra_cin, int rb_cin, int rb_fstride, void* stream) {
+    return sl_split3_wgrad_combine_scaled(ra, rb, dw, taps, c_in, c_out, frames, fstride, ra_cin, rb_cin, rb_fstride, 1.f, stream);
 }
 
 extern "C" size_t sl_split3_bias_grad_workspace_bytes(int channels) {
     return channels > 0 ? (size_t)BG_CHUNKS * channels * sizeof(float) : 0;
 }
 
-extern "C" int sl_split3_bias_grad(const void* g, float* db, int batch, int t_out, int channels, int g_row0,
-                                   int64_t g_batch_stride, void* workspace, size_t workspace_bytes, void* stream) {
-    SL_CHECK_ARG(g && db && batch > 0 && t_out > 0 && channels > 0 && channels % 64 == 0, "sl_split3_bias_grad: bad arguments");
+template <typename F>
+static int bias_grad_impl(const char* who, const void* g, float* db, int batch, int t_out, int channels, int g_row0,
+                          int64_t g_batch_stride, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    SL_CHECK_ARG(g && db && batch > 0 && t_out > 0 && channels > 0 && channels % 64 == 0 && scale > 0.f, "%s: bad arguments", who);
     if (workspace == nullptr || workspace_bytes < sl_split3_bias_grad_workspace_bytes(channels)) {
-        sl_set_error("sl_split3_bias_grad: workspace too small");
+        sl_set_error("%s: workspace too small", who);
         return SL_ERR_WORKSPACE_TOO_SMALL;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bias_grad3_partial_kernel, dim3(channels / 64, BG_CHUNKS), dim3(256), 0, s, (const unsigned short*)g,
+    hipLaunchKernelGGL(bias_grad3_partial_kernel<F>, dim3(channels / 64, BG_CHUNKS), dim3(256), 0, s, (const unsigned short*)g,
                        (float*)workspace, batch, t_out, channels, g_row0, (long)g_batch_stride);
-    int rc = sl_check_launch("sl_split3_bias_grad(partial)");
+    int rc = sl_check_launch(who);
     if (rc != SL_OK) return rc;
     hipLaunchKernelGGL(bias_grad3_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, s, (const float*)workspace, db,
-                       channels);
-    return sl_check_launch("sl_split3_bias_grad");
+                       channels, scale);
+    return sl_check_launch(who);
+}
+extern "C" int sl_split3_bias_grad(const void* g, float* db, int batch, int t_out, int channels, int g_row0,
+                                   int64_t g_batch_stride, void* workspace, size_t workspace_bytes, void* stream) {
+    return bias_grad_impl<PlaneBf16>("sl_split3_bias_grad", g, db, batch, t_out, channels, g_row0, g_batch_stride, 1.f, workspace,
+                                     workspace_bytes, stream);
+}
+extern "C" int sl_splitf16_bias_grad(const void* g, float* db, int batch, int t_out, int channels, int g_row0,
+                                     int64_t g_batch_stride, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return bias_grad_impl<PlaneF16>("sl_splitf16_bias_grad", g, db, batch, t_out, channels, g_row0, g_batch_stride, scale,
+                                    workspace, workspace_bytes, stream);
 }

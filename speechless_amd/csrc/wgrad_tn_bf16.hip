@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void wgrad_t
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 acc[jh * 2 + j][it] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag8(bl[it], bh[it]), acc[jh * 2 + j][it], 0, 0, 0);
+                    SL_MFMA16(af, frag8(bl[it], bh[it]), acc[jh * 2 + j][it]);
         }
     };
     const std::integral_constant<int, 0> K0{};
@@ -288,8 +288,8 @@ struct TrPhase {
         for (int j = 0; j < 2; ++j) {
             const int m = 2 * Q + j;
             const int jn = m / 8, it = m % 8;
-            acc[jn][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(cur.gl[jn], cur.gh[jn]), frag8(cur.xl[it], cur.xh[it]),
-                                                                  acc[jn][it], 0, 0, 0);
+            acc[jn][it] = SL_MFMA16(frag8(cur.gl[jn], cur.gh[jn]), frag8(cur.xl[it], cur.xh[it]),
+                                                                  acc[jn][it]);
         }
 #else
         asm volatile("" : "+v"(cur.gl[Q % 4]), "+v"(cur.xl[Q % 8]));
@@ -1030,6 +1030,17 @@ WCfg resolve_wcfg(const sl_conv_geom* g, int cfg, int groups) {
 }
 
 }  // namespace
+
+#if defined(SL_ELEM_F16)  // the second translation unit of this file: the same kernels on v_mfma_f32_16x16x32_f16
+#define wgrad_split_count wgrad_split_count_f16
+#define wgrad_reduce wgrad_reduce_f16
+#define wgrad_tn_bf16_workspace_bytes wgrad_tn_f16_workspace_bytes
+#define wgrad_tn_bf16 wgrad_tn_f16
+#define wgrad_multi_bf16_workspace_bytes wgrad_multi_f16_workspace_bytes
+#define wgrad_multi_bf16 wgrad_multi_f16
+#define wgrad_reduce_kernel wgrad_reduce_kernel_f16
+#define wgrad_reduce_grouped_kernel wgrad_reduce_grouped_kernel_f16
+#endif
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n4, int splits,
                                     long split_stride4) {

@@ -50,8 +50,19 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             self.torch_dtype, self.dtype_code = torch.float32, _lib.SL_F32
         elif dtype == "bf16x3":
             self.torch_dtype, self.dtype_code, self.planes = torch.bfloat16, _lib.SL_BF16, 3
+        elif dtype == "f16x3":
+            # the plane scheme on fp16 pairs (round 6; engine_x3.py): 22 operand bits instead of 16-17 at the same three MFMA
+            # terms.  fp16's range is 65504 and its precision below 2^-3 absolute, so weights and back-propagated gradients
+            # are STORED multiplied by powers of two (exact) that bring typical magnitudes to ~1; the kernels divide them
+            # out again (sl_conv_geom.acc_scale, the `scale` arguments of the sl_splitf16* helpers).
+            self.torch_dtype, self.dtype_code, self.planes = torch.float16, _lib.SL_F16, 3
         else:
-            raise ValueError("dtype must be 'bf16', 'f32' or 'bf16x3'")
+            raise ValueError("dtype must be 'bf16', 'f32', 'bf16x3' or 'f16x3'")
+        self.x3_f16 = dtype == "f16x3"
+        # f16x3: operand copies hold w_scale * w (glorot-uniform weights of this stack are 0.01 ... 0.05: x 64 -> ~1; representable
+        # up to |w| < 1000), gradient planes hold g_scale * g (the CTC gradient of a frame is <= 1 / B: x 4096 stays below 2^12)
+        self.w_scale = 64.0 if self.x3_f16 else 1.0
+        self.g_scale = 4096.0 if self.x3_f16 else 1.0
         # Raw-wave input (reference net.py:310-312: `wave_conv`, 250 taps at stride 160 over the samples, in front of
         # striding_conv): the FRONT layer.  It is a GEMM over gathered sample windows (sl_wave_frames: K = 250 * Cin
         # columns per output frame, 3 GFLOP per 32 x 8 s -- nothing next to the stack) whose output lands directly in the
@@ -67,6 +78,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             frozen_layer_count = max(frozen_layer_count - 1, 0)
             if self.front_spec.activation not in ("relu", "elu"):
                 raise NotImplementedError("the raw-wave layer takes a relu / elu activation")
+            if dtype == "f16x3":
+                raise NotImplementedError("raw-wave input runs on 'bf16', 'f32' and 'bf16x3' (f16x3: spectrogram input)")
         self.specs = specs
         self.all_specs = ([self.front_spec] if self.front_spec is not None else []) + list(specs)
         self.grapheme_set_size = grapheme_set_size
@@ -590,7 +603,7 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
         buf = self.buffers(batch, t_in)
         p0 = self.plans[0]
         if self.planes > 1:
-            self._launch("pack_input", "sl_split3_pack_input", src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.cin_pad,
+            self._launch("pack_input", self._x3("sl_split3_pack_input"), src.data_ptr(), buf.x0.data_ptr(), batch, t_in, f, p0.cin_pad,
                          p0.pad_left, buf.rows0 * p0.cin_pad * self.planes, self._stream())
             self.cur = buf
             self._src_keepalive = src
@@ -816,8 +829,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             self._launch("ctc", "sl_ctc_loss_grad", buf.probs.data_ptr(), buf.logq.data_ptr(), buf.labels.data_ptr(),
                          buf.label_len.data_ptr(), buf.input_len.data_ptr(), buf.loss.data_ptr(), buf.stage32.data_ptr(),
                          buf.batch, buf.t_out, self.grapheme_set_size, l_max, 0, cp, buf.tt_pad * cp, _lib.SL_F32,
-                         self.ctc_epsilon, grad_scale, buf.ctc_ws.data_ptr(), buf.ctc_ws.numel(), self._stream())
-            self._launch("split:ctc", "sl_split3", buf.stage32.data_ptr(), buf.g[last].data_ptr(), None, buf.batch, buf.t_out,
+                         self.ctc_epsilon, grad_scale * self.g_scale, buf.ctc_ws.data_ptr(), buf.ctc_ws.numel(), self._stream())
+            self._launch("split:ctc", self._x3("sl_split3"), buf.stage32.data_ptr(), buf.g[last].data_ptr(), None, buf.batch, buf.t_out,
                          cp, buf.tt_pad * cp, HALO, buf.rows * cp * self.planes, 0, self._stream())
             return buf.loss
         self._launch("ctc", "sl_ctc_loss_grad", buf.probs.data_ptr(), buf.logq.data_ptr(), buf.labels.data_ptr(),
@@ -1222,7 +1235,11 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             chunk = layers[lo:lo + 16]
             table = self._adam_table(chunk)
             tag = "adam:{}..{}".format(self.all_plans[chunk[0]].spec.name, self.all_plans[chunk[-1]].spec.name)
-            if self.planes == 3:  # bf16x3: the [w_hi | w_hi | w_lo] operand rows are rewritten in the same pass
+            if self.planes == 3 and self.x3_f16:
+                self._launch(tag, "sl_splitf16_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(),
+                             self.adam_m.data_ptr(), self.adam_v.data_ptr(), table, len(chunk), self.adam_iterations,
+                             self.lr, self.beta_1, self.beta_2, self.adam_epsilon, self.w_scale, st)
+            elif self.planes == 3:  # bf16x3: the [w_hi | w_hi | w_lo] operand rows are rewritten in the same pass
                 self._launch(tag, "sl_split3_adam_pack_layers", self.params.data_ptr(), self.grads.data_ptr(),
                              self.adam_m.data_ptr(), self.adam_v.data_ptr(), table, len(chunk), self.adam_iterations,
                              self.lr, self.beta_1, self.beta_2, self.adam_epsilon, st)
@@ -1294,9 +1311,8 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
                 wv, _ = self.layer_param_views(self.params, p)
                 wd = self.w_dgrad[p.index]
                 pair = wd is not None and p.index == 0 and p is not self.front_plan  # (its pair view: _pack_pair_dgrad_x3)
-                self._launch("pack3:" + p.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
-                             wd.data_ptr() if (wd is not None and not pair) else None, p.spec.kernel_size, p.cin_pad,
-                             p.cout_pad, st)
+                self._pack_weights_x3("pack3:" + p.spec.name, wv, self.w_fwd[p.index], wd if (wd is not None and not pair) else None,
+                                      p.spec.kernel_size, p.cin_pad, p.cout_pad, st)
                 if pair:
                     self._pack_pair_dgrad_x3(st)
             return

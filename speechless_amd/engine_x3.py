@@ -10,6 +10,18 @@ from .plan import HALO
 
 
 class X3Mixin:
+    def _x3(self, name):
+        """the entry point of a plane helper for this engine's plane format: sl_split3* (bf16 pairs) or its fp16 twin"""
+        return name.replace("sl_split3", "sl_splitf16", 1) if self.x3_f16 else name
+
+    def _pack_weights_x3(self, tag, w_master, w_fwd, w_dgrad, k, cin, cout, st):
+        """both operand copies [w_hi | w_hi | w_lo] of one layer from its fp32 master (f16x3: of w_scale * w)"""
+        args = (w_master.data_ptr(), w_fwd.data_ptr(), w_dgrad.data_ptr() if w_dgrad is not None else None, k, cin, cout)
+        if self.x3_f16:
+            self._launch(tag, "sl_splitf16_pack_weights", *args, self.w_scale, st)
+        else:
+            self._launch(tag, "sl_split3_pack_weights", *args, st)
+
     def _repack_weights_x3(self):
         """bf16x3 operand copies: rows [w_hi | w_hi | w_lo] in both operand layouts, w_hi = bf16(w), w_lo = bf16(w - w_hi),
         one launch per layer (sl_split3_pack_weights; the five-launch sequence it replaces -- split, two packs, two
@@ -21,8 +33,7 @@ class X3Mixin:
             if p.index == 0 and p is not self.front_plan:
                 wd = None  # (only there under a front layer, and then in the pair view: _pack_pair_dgrad_x3 below)
             k, cin = self._pack_dims(p)
-            self._launch("pack3:" + p.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self.w_fwd[p.index].data_ptr(),
-                         wd.data_ptr() if wd is not None else None, k, cin, p.cout_pad, st)
+            self._pack_weights_x3("pack3:" + p.spec.name, wv, self.w_fwd[p.index], wd, k, cin, p.cout_pad, st)
         if self.w_dgrad[0] is not None:
             self._pack_pair_dgrad_x3(st)
         self._packed_dirty = False
@@ -36,8 +47,8 @@ class X3Mixin:
         if getattr(self, "_w_fwd0_pair_scratch", None) is None:
             self._w_fwd0_pair_scratch = torch.empty_like(self.w_fwd[0])
         wv, _ = self.layer_param_views(self.params, p0)
-        self._launch("pack3_pair:" + p0.spec.name, "sl_split3_pack_weights", wv.data_ptr(), self._w_fwd0_pair_scratch.data_ptr(),
-                     self.w_dgrad[0].data_ptr(), p0.taps_view, p0.cin_view, p0.cout_pad, st)
+        self._pack_weights_x3("pack3_pair:" + p0.spec.name, wv, self._w_fwd0_pair_scratch, self.w_dgrad[0], p0.taps_view,
+                              p0.cin_view, p0.cout_pad, st)
 
     def _plane_geom(self, buf, kind, i, channels):
         """the NT geometry of layer i (kind 'fwd' / 'dgrad') with its OUTPUT side describing a bf16x3 plane tensor of
@@ -54,7 +65,7 @@ class X3Mixin:
 
     def _dropout_x3(self, tag, src, dst, y, channels, mode, seed, st):
         """sl_split3_dropout over a whole plane tensor (halo rows and padding included: zeros stay zeros)"""
-        self._launch(tag, "sl_split3_dropout", src.data_ptr(), dst.data_ptr(), y.data_ptr() if y is not None else None,
+        self._launch(tag, self._x3("sl_split3_dropout"), src.data_ptr(), dst.data_ptr(), y.data_ptr() if y is not None else None,
                      src.numel() // (self.planes * channels), channels, mode, self.dropout_rate, seed, st)
 
     def _forward_x3(self, buf, st, rate=None):
@@ -100,7 +111,7 @@ class X3Mixin:
                          cfg, buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
             if not last:
                 y = buf.y[p.index]
-                self._launch("split:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), y.data_ptr(), None, buf.batch,
+                self._launch("split:" + p.spec.name, self._x3("sl_split3"), buf.stage32.data_ptr(), y.data_ptr(), None, buf.batch,
                              buf.t_out, p.cout_pad, buf.tt_pad * p.cout_pad, HALO, buf.rows * p.cout_pad * self.planes,
                              2 if p.spec.activation == "elu" else 1, st)
                 drop(p)
@@ -139,9 +150,12 @@ class X3Mixin:
             frames = 2 if p.spec.stride == 2 else 1
             fstride = pl * p.cin_pad if frames == 2 else 0
             window = frames == 2 and buf.x3_window  # RB's x operand was the [hi0 | hi1] window of the pair row
-            self._launch("combine:" + p.spec.name, "sl_split3_wgrad_combine", ra.data_ptr(), rb.data_ptr(), dw.data_ptr(),
-                         p.spec.kernel_size, p.cin_pad, p.cout_pad, frames, fstride,
-                         buf.wgrad_geom[p.index].cin, buf.wgrad_geom_b[p.index].cin, p.cin_pad if window else fstride, st)
+            args = (ra.data_ptr(), rb.data_ptr(), dw.data_ptr(), p.spec.kernel_size, p.cin_pad, p.cout_pad, frames, fstride,
+                    buf.wgrad_geom[p.index].cin, buf.wgrad_geom_b[p.index].cin, p.cin_pad if window else fstride)
+            if self.x3_f16:  # the partial sums are g_scale * dW (the gradient planes are stored scaled)
+                self._launch("combine:" + p.spec.name, "sl_split3_wgrad_combine_scaled", *args, 1.0 / self.g_scale, st)
+            else:
+                self._launch("combine:" + p.spec.name, "sl_split3_wgrad_combine", *args, st)
 
         for p in reversed(self.plans[first:]):
             i = p.index
@@ -166,9 +180,13 @@ class X3Mixin:
                 if self._x3_bias_ws is None:
                     self._x3_bias_ws = torch.empty((self.lib.raw("sl_split3_bias_grad_workspace_bytes")(
                         max(q.cout_pad for q in self.plans)),), dtype=torch.uint8, device=self.device)
-                self._launch("bgrad:" + p.spec.name, "sl_split3_bias_grad", buf.g[i].data_ptr(), db.data_ptr(), buf.batch,
-                             buf.t_out, p.cout_pad, HALO, buf.rows * p.cout_pad * pl, self._x3_bias_ws.data_ptr(),
-                             self._x3_bias_ws.numel(), st)
+                args = (buf.g[i].data_ptr(), db.data_ptr(), buf.batch, buf.t_out, p.cout_pad, HALO, buf.rows * p.cout_pad * pl)
+                if self.x3_f16:
+                    self._launch("bgrad:" + p.spec.name, "sl_splitf16_bias_grad", *args, 1.0 / self.g_scale,
+                                 self._x3_bias_ws.data_ptr(), self._x3_bias_ws.numel(), st)
+                else:
+                    self._launch("bgrad:" + p.spec.name, "sl_split3_bias_grad", *args, self._x3_bias_ws.data_ptr(),
+                                 self._x3_bias_ws.numel(), st)
             if i in bucket_at:
                 b, layers = bucket_at[i]
                 rows = [j for j in layers if j in ones_in]
@@ -184,7 +202,7 @@ class X3Mixin:
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
                              None, buf.stage32.data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_NONE, self.dtype_code, 1,
                              self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-                self._launch("split:dgrad:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
+                self._launch("split:dgrad:" + p.spec.name, self._x3("sl_split3"), buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
                              None, buf.batch, buf.t_out, p.cin_pad, buf.tt_pad * p.cin_pad, HALO,
                              buf.rows * p.cin_pad * pl, 0, st)
                 self._dropout_x3("dropout_elu_bwd:" + p.spec.name, buf.g[i - 1], buf.g[i - 1], buf.y[i - 1], p.cin_pad, 2,
@@ -200,7 +218,7 @@ class X3Mixin:
                 self._launch("dgrad:" + p.spec.name, "sl_conv1d_nt", buf.g[i].data_ptr(), self.w_dgrad[i].data_ptr(), None,
                              None, buf.stage32.data_ptr(), ctypes.byref(buf.dgrad_geom[i]), _lib.EPI_NONE, self.dtype_code, 1,
                              self.nt_cfg.get(("dgrad", p.spec.name), 0), buf.nt_ws.data_ptr(), buf.nt_ws.numel(), st)
-                self._launch("split:dgrad:" + p.spec.name, "sl_split3", buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
+                self._launch("split:dgrad:" + p.spec.name, self._x3("sl_split3"), buf.stage32.data_ptr(), buf.g[i - 1].data_ptr(),
                              buf.y[i - 1].data_ptr(), buf.batch, buf.t_out, p.cin_pad, buf.tt_pad * p.cin_pad, HALO,
                              buf.rows * p.cin_pad * pl, 4 if self.specs[i - 1].activation == "elu" else 3, st)
             if i > first and dropped_in:

@@ -265,13 +265,15 @@ class Wav2Letter:
         self.dropout = dropout
         # Arithmetic (round 6).  The reference has ONE arithmetic -- fp32 (net.py:389,402-406).  Called with
         # the reference's own signature (compute_dtype not given) this class TRAINS on the benchmarked bf16 engine and
-        # EVALUATES -- prediction_batch, predict*, test_and_predict* -- on a second, lazily built `bf16x3` engine (the fast
-        # parity path: greedy decode bit-exact against the fp32 CPU port, loss to 2e-7) that shares the fp32 master weights
-        # in HBM and re-packs its operand copies whenever they changed.  compute_dtype="bf16" / "f32" / "bf16x3" given
+        # EVALUATES -- prediction_batch, predict*, test_and_predict* -- on a second, lazily built engine of a fast PARITY
+        # path (greedy decode bit-exact against the fp32 CPU port, loss to 2e-7) that shares the fp32 master weights in HBM
+        # and re-packs its operand copies whenever they changed: `f16x3` (hi + lo fp16 planes, 22 operand bits; weights
+        # representable up to |w| < 1000 -- eval_engine falls back to bf16x3 beyond that) for spectrogram input, `bf16x3`
+        # (hi + lo bf16 planes, fp32's range) for raw-wave input.  compute_dtype="bf16" / "f32" / "bf16x3" / "f16x3" given
         # explicitly: that one engine does everything (eval_dtype overrides the evaluation side alone).
         self.compute_dtype = compute_dtype if compute_dtype is not None else "bf16"
         if eval_dtype is None:
-            eval_dtype = "bf16x3" if compute_dtype is None else self.compute_dtype
+            eval_dtype = ("bf16x3" if use_raw_wave_input else "f16x3") if compute_dtype is None else self.compute_dtype
         self.eval_dtype = eval_dtype
         compute_dtype = self.compute_dtype
         self.device = device
@@ -456,6 +458,11 @@ class Wav2Letter:
             self._eval_weights_version = None
         ev = self._eval_engine
         if self._eval_weights_version != train.weights_version:
+            if ev.x3_f16 and float(train.params.abs().max().item()) * ev.w_scale >= 6.0e4:
+                # fp16 planes hold w_scale * w: a master beyond +-937 would saturate -- evaluate on bf16 planes instead
+                log("weights beyond the range of the f16x3 evaluation path: evaluating on bf16x3")
+                self.eval_dtype, self._eval_engine = "bf16x3", None
+                return self.eval_engine
             ev._packed_dirty = True  # (its next forward re-packs from the shared masters, on the same stream as the step)
             self._eval_weights_version = train.weights_version
         return ev

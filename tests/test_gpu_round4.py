@@ -68,7 +68,7 @@ def test_parity_triangle_at_the_benchmark_batch():
                     flips=dict(zip(names, _flips(masks, exact["masks"]))))
     report = {"torch_cpu_f32": against_exact(cpu["losses"].astype(np.float64), cpu["grads"], cpu["masks"])}
     yard = report["torch_cpu_f32"]
-    for dtype in ("f32", "bf16x3"):
+    for dtype in ("f32", "bf16x3", "f16x3"):
         got = _hip_step(weights, specs, bench.K_CLASSES, dtype, torch.from_numpy(x).cuda(), labels, lab_len, pred_len)
         report[dtype] = against_exact(got["losses"], got["grads"], got["masks"])
         report[dtype]["flips_vs_torch_cpu"] = dict(zip(names, _flips(got["masks"], cpu["masks"])))
@@ -76,10 +76,11 @@ def test_parity_triangle_at_the_benchmark_batch():
     report["decisions_per_layer"] = {n: int(m.numel()) for n, m in zip(names, exact["masks"])}
     _report("parity_triangle_batch32", report)
     assert yard["loss"] < 1e-5
-    for dtype in ("f32", "bf16x3"):
+    for dtype in ("f32", "bf16x3", "f16x3"):
         r = report[dtype]
         assert r["loss"] < 1e-5, (dtype, r["loss"])
-        slack, flip_slack = (1.5, 2) if dtype == "f32" else (3.0, 20)
+        # (f16x3, round 6: fp16 planes carry 22 operand bits -- held to the exact-fp32 path's bars, not to bf16x3's)
+        slack, flip_slack = (3.0, 20) if dtype == "bf16x3" else (1.5, 2)
         for n in names:
             for kind in ("dw", "db"):
                 bound = max(1e-3, slack * yard[kind][n])

@@ -24,13 +24,13 @@ def test_reference_signature_decodes_config2_bit_exactly_against_the_cpu_port():
     configuration.py:106,168 calls it -- decodes BASELINE config 2 (32 x 128 mel x 1000 frames, random init) bit-exactly
     against the torch-CPU fp32 port of the reference's arithmetic: every forward-only entry point (prediction_batch,
     predict_batch_greedily, test_and_predict_batch; net.py:350-357, 461-498) runs the bf16x3 parity engine over the fp32
-    masters the bf16 training engine updates.  Also: the per-utterance losses of test_and_predict_batch against the CPU
+    masters the bf16 training engine updates (f16x3 since the fp16 planes exist; bf16x3 for raw-wave input or out-of-range weights).  Also: the per-utterance losses of test_and_predict_batch against the CPU
     port (1e-5), and that evaluation follows a training step (the shared masters are re-packed, not a stale copy)."""
     import torch
     from oracle import w2l_torch_cpu as tc
     from speechless_amd import Wav2Letter, english_frequent_characters
     net = Wav2Letter(128, english_frequent_characters)
-    assert net.compute_dtype == "bf16" and net.eval_dtype == "bf16x3"   # training: the benchmarked path; evaluation: parity
+    assert net.compute_dtype == "bf16" and net.eval_dtype == "f16x3"    # training: the benchmarked path; evaluation: parity
     rng = np.random.RandomState(0)
     x = rng.randn(32, 1000, 128).astype(np.float32)
     ospecs = o.layer_specs(128, 29)
@@ -79,7 +79,7 @@ def test_eval_engine_shares_the_masters_and_has_no_optimizer_state():
     small = dict(main_filter_count=20, out_filter_count=40, inner_count=1)
     net = Wav2Letter(128, english_frequent_characters, seed=4, layer_sizes=small)
     ev = net.eval_engine
-    assert ev is not net.engine and ev.dtype == "bf16x3" and ev.forward_only
+    assert ev is not net.engine and ev.dtype == "f16x3" and ev.forward_only
     assert ev.params.data_ptr() == net.engine.params.data_ptr() and ev.grads is None and ev.adam_m is None
     with pytest.raises(RuntimeError):
         ev.adam_step()
@@ -94,6 +94,17 @@ def test_eval_engine_shares_the_masters_and_has_no_optimizer_state():
     ref, _, _ = o.forward_stack(o.layer_specs(128, 29, **small), [(a.astype(np.float64), b.astype(np.float64)) for a, b in w],
                                 x.astype(np.float64), keep=True)
     assert np.abs(p1 - ref).max() < 2e-5
+    # weights beyond what fp16 planes hold (w_scale * |w| < 65504): the evaluation engine becomes the bf16x3 one, results stay right
+    w[0] = (w[0][0] * 0 + 1500.0 * np.sign(w[0][0] + 1e-30), w[0][1])
+    net.predictive_net.set_weights(w)
+    p2 = net.prediction_batch(x)
+    assert net.eval_dtype == "bf16x3" and net.eval_engine.dtype == "bf16x3" and np.isfinite(p2).all()
+    ref2, _, _ = o.forward_stack(o.layer_specs(128, 29, **small), [(a.astype(np.float64), b.astype(np.float64)) for a, b in w],
+                                 x.astype(np.float64), keep=True)
+    assert np.abs(p2 - ref2).max() < 1e-3
+    # raw-wave nets evaluate on bf16x3 from the start (the front layer has no fp16-plane form)
+    assert Wav2Letter(1, english_frequent_characters, use_raw_wave_input=True, seed=1,
+                      layer_sizes=dict(main_filter_count=250, out_filter_count=256, inner_count=1)).eval_dtype == "bf16x3"
 
 
 # ------------------------------------------------------------------------------------------ stride-1 first layer on bf16x3
@@ -195,3 +206,95 @@ def test_first_dp_run_matrix_control_flow(tmp_path):
         assert dp["sharded_optimizer"] == ("shard" in tag) and len(dp["bucket_bytes"]) == (4 if "split1" in tag else 3), tag
     table = (out / "table.txt").read_text()
     assert "FAILED" not in table and table.count("identical True") == 9 and "single GPU" in table
+
+
+# ------------------------------------------------------------------------------------------ f16x3: the plane scheme on fp16 pairs
+@pytest.mark.parametrize("t", [64, 77])
+def test_f16x3_loss_and_gradients_against_the_float64_oracle(t):
+    """Engine(dtype='f16x3'): every value as hi + lo FP16 planes -- 22 significand bits instead of bf16x3's
+    16-17, same three MFMA terms (v_mfma_f32_16x16x32_f16), weights stored x 2^6 and gradients x 2^12 (exact powers of two,
+    divided out by sl_conv_geom.acc_scale / the combine) -- against the float64 oracle: loss and every gradient tensor at the
+    exact-fp32 path's level, an order of magnitude inside bf16x3's bounds (5e-3 in tests/test_gpu_round3.py)."""
+    import torch
+    case = make_case(b=3, t=t, seed=3)
+    ref = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), case["labels"],
+                               case["prediction_lengths"], case["label_lengths"])
+    eng = make_engine(case, "f16x3")
+    eng.load_input(case["x"])
+    eng.set_labels(case["labels"], np.array(case["label_lengths"]), np.array(case["prediction_lengths"]))
+    eng.forward()
+    losses = eng.ctc().cpu().numpy()
+    eng.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses, ref["losses"], rtol=1e-5)
+    report = {}
+    for spec, (dw, db), (rw, rb) in zip(case["specs"], eng.get_gradients(), ref["grads"]):
+        report[spec.name] = [rel_l2(dw, rw), rel_l2(db, rb)]
+    _report("grads_f16x3_rel_l2_t{}".format(t), report)
+    for name, (ew, eb) in report.items():
+        # (striding_conv's dW: where a single ReLU decision that differs from float64 shows, DESIGN.md section 1)
+        assert ew < (2e-3 if name == "striding_conv" else 5e-4) and eb < 5e-4, (name, ew, eb)
+    decoded, _ = eng.greedy_decode(case["prediction_lengths"])
+    assert decoded == o.greedy_decode_indices(ref["probs"], case["prediction_lengths"])
+    # optimisation steps through the scaled plane operands: the loss goes down, padded lanes stay zero, and the operand copies
+    # ARE w_scale * w in two fp16 planes
+    for _ in range(6):
+        eng.train_step_resident()
+    torch.cuda.synchronize()
+    assert float(eng.cur.loss.mean().item()) < float(np.mean(losses))
+    p1 = eng.plans[1]
+    full = eng.layer_param_views(eng.params, p1)[0]
+    assert not full[:, 250:255, :].any() and not full[:, :, 250:].any()
+    wf = eng.w_fwd[1].float()                                       # [cout][k][3 cin]: [w_hi | w_hi | w_lo]
+    c = p1.cin_pad
+    recon = (wf[:, :, :c] + wf[:, :, 2 * c:]) / eng.w_scale
+    want = full.permute(2, 0, 1)
+    assert torch.equal(wf[:, :, :c], wf[:, :, c:2 * c])
+    assert float((recon - want).abs().max()) <= 2.0 ** -22 * float(want.abs().max())
+
+
+def test_f16x3_config2_greedy_decode_bit_exact_at_batch_32():
+    """BASELINE config 2 on the f16x3 path: frame argmax and decoded indices bit-exact against the torch-CPU fp32 port,
+    probabilities within 2e-6 (bf16x3: 2e-5)."""
+    import torch
+    from oracle import w2l_torch_cpu as tc
+    case = make_case(b=32, t=1000, seed=2)
+    pred_len = [500] * 32
+    with torch.no_grad():
+        ref_probs = tc.forward_probs(case["ospecs"], tc.to_torch_weights(case["weights"], requires_grad=False),
+                                     torch.from_numpy(case["x"])).numpy()
+    eng = make_engine(case, "f16x3")
+    probs = eng.forward(case["x"]).cpu().numpy()
+    decoded, frame_argmax = eng.greedy_decode(pred_len)
+    _report("config2_b32_f16x3_max_abs_prob_error", float(np.abs(probs - ref_probs).max()))
+    assert np.abs(probs - ref_probs).max() < 2e-6
+    assert np.array_equal(frame_argmax, ref_probs.argmax(axis=2))
+    assert decoded == o.greedy_decode_indices(ref_probs, pred_len)
+
+
+@pytest.mark.parametrize("activation", ["relu", "elu"])
+def test_f16x3_dropout_and_elu_against_the_f32_path(activation):
+    """f16x3 through its other helpers: ELU layers (fp32 staging + sl_splitf16 modes 2 / 4) and dropout on fp16 planes
+    (sl_splitf16_dropout: the same (seed, element) keep decisions as every other path) -- one training step against the
+    exact-fp32 path with the same seed."""
+    import torch
+    sizes = dict(main_filter_count=250, out_filter_count=256, inner_count=2)
+    case = make_case(b=3, t=90, seed=21, sizes=sizes)
+    for specs in (case["specs"], case["ospecs"]):
+        for sp in specs[:-1]:
+            sp.activation = activation
+    out = {}
+    for dtype in ("f16x3", "f32"):
+        eng = make_engine(case, dtype)
+        eng.dropout_rate, eng.dropout_seed = 0.2, 77
+        eng.load_input(case["x"])
+        eng.set_labels(case["labels"], np.array(case["label_lengths"]), np.array(case["prediction_lengths"]))
+        eng.forward(training=True)
+        losses = eng.ctc().cpu().numpy().copy()
+        eng.backward()
+        torch.cuda.synchronize()
+        out[dtype] = (losses, eng.get_gradients())
+    np.testing.assert_allclose(out["f16x3"][0], out["f32"][0], rtol=2e-5)
+    errs = [max(rel_l2(a, c), rel_l2(b, d)) for (a, b), (c, d) in zip(out["f16x3"][1], out["f32"][1])]
+    _report("f16x3_dropout_{}_vs_f32".format(activation), errs)
+    assert max(errs) < (2e-4 if activation == "elu" else 5e-3), errs   # (ReLU: a flipped decision next to a dropout mask)

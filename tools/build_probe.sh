@@ -12,6 +12,7 @@ OBJS=""
 for f in capi conv_nt_bf16 wgrad_tn_bf16 conv_f32 ctc misc spectrogram conv_chain_bf16 conv1x1_bwd_bf16 split3; do
   [ "$f.hip" = "$SRC" ] || OBJS="$OBJS $f.o"
 done
+OBJS="$OBJS conv_nt_f16.o wgrad_tn_f16.o"  # (the -DSL_ELEM_F16 translation units of the last regular build, as they are)
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $flags -c $SRC -o /tmp/probe_$name.o && \
