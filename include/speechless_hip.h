@@ -296,7 +296,9 @@ int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* label
 /* Measurement / test hook: which lattice sl_ctc_loss_grad runs.  0 (default) = as described above, 1 = log-domain lattice
  * only; probability-domain lattice in doubles: 2 = without the repair pass, 3 = and then EVERY utterance redone by the
  * repair pass, 4 = + repair; in floats (faster, but the repair pass is needed in some regimes: ctc.hip:WaveReal): 6 / 7 / 5
- * likewise.  Process-wide; not for concurrent use with sl_ctc_loss_grad. */
+ * likewise; 8 / 9 (round 6) = the double lattice on a PAIR of waves per utterance and direction (four states per lane, the
+ * boundary state handed over through an LDS mailbox, the downstream wave half a block behind) with / without the repair
+ * pass.  Process-wide; not for concurrent use with sl_ctc_loss_grad. */
 int sl_ctc_select(int variant);
 
 /* ---- greedy decode (net.py:452-454 tf.nn.ctc_greedy_decoder, merge_repeated=True; numpy twin

@@ -319,7 +319,8 @@ __device__ void repair_lattices(const float* __restrict__ lq_b, const int* s_lab
 // LIN: the lattice comes from ctc_lattice_wave_kernel (doubles in linear units with one exponent per frame, emissions
 // u = p + eps instead of q) and is brought to log2 units on the fly; the sum of a frame's state posteriors must then be
 // 1 -- if the linear lattice lost mass to underflow it is not, and the utterance is flagged for the log-domain repair.
-template <int NJ, int LIN>  // LIN: 0 = log-domain rows; 1 = linear rows in doubles (exponent blocks of 16); 2 = in floats (of 8)
+template <int NJ, int LIN>  // LIN: 0 = log-domain rows; 1 = linear rows in doubles (exponent blocks of 16); 2 = in floats (of 8);
+                            // 3 = doubles from the wave-PAIR lattice (one exponent per FOUR states: 128 per block of 16)
 __device__ __forceinline__ void ctc_grad_frames(
     const float* __restrict__ probs, const float* __restrict__ logq, const void* __restrict__ alpha_v,
     const void* __restrict__ beta_v, const int32_t* __restrict__ ea, const int32_t* __restrict__ eb,
@@ -354,7 +355,7 @@ __device__ __forceinline__ void ctc_grad_frames(
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {  // only the live part of the row was written: s < S rounded up to 8
                         const bool in = lane + 64 * j < ((S + 7) & ~7);
-                        if (LIN == 1) {  // the high words of the doubles (wave_lattice_run)
+                        if (LIN == 1 || LIN == 3) {  // the high words of the doubles (wave_lattice_run / pair_lattice_run)
                             ad[j] = in ? (RT)__hiloint2double(((const int*)alpha_v)[fidx * sp + lane + 64 * j], 0) : (RT)0;
                             bd[j] = in ? (RT)__hiloint2double(((const int*)beta_v)[fidx * sp + lane + 64 * j], 0) : (RT)0;
                         } else {
@@ -368,12 +369,14 @@ __device__ __forceinline__ void ctc_grad_frames(
                     // summed exactly, only the mantissa logarithms go through fp32.
                     // (one exponent per lattice lane = 8 states and block of 16 steps of the respective direction)
                     constexpr int RBS = LIN == 2 ? 3 : 4;  // log2 of the frames per exponent block
-                    const int32_t* eap = ea + ((long)b * ((t_out >> RBS) + 1) + (t >> RBS)) * 64;
-                    const int32_t* ebp = eb + ((long)b * ((t_out >> RBS) + 1) + ((T - 1 - t) >> RBS)) * 64;
+                    constexpr int ELANES = LIN == 3 ? 128 : 64;  // exponents per block
+                    constexpr int WSH = LIN == 3 ? 2 : 3;        // log2 of the states that share one
+                    const int32_t* eap = ea + ((long)b * ((t_out >> RBS) + 1) + (t >> RBS)) * ELANES;
+                    const int32_t* ebp = eb + ((long)b * ((t_out >> RBS) + 1) + ((T - 1 - t) >> RBS)) * ELANES;
                     const int zi = zint[b];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        const int wl = (lane + 64 * j) >> 3;
+                        const int wl = (lane + 64 * j) >> WSH;
                         const int eab = eap[wl] + ebp[wl] - zi;
                         // a state the other direction cannot reach has posterior 0 whatever this direction holds
                         const bool dead = !(ad[j] > (RT)0 && bd[j] > (RT)0 && ad[j] < (RT)INFINITY && bd[j] < (RT)INFINITY);
@@ -599,14 +602,16 @@ constexpr int WRESCALE = 16;   // frames of one straight-line block (two prefetc
 
 __device__ __forceinline__ double dpp_from_lower_lane(double v) {  // lane l <- lane l-1, lane 0 <- 0
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    // bound_ctrl: the lane without a source reads 0 -- no initialisation of the destination (two v_mov per shifted double and
+    // frame of a lone wave that issues one instruction every ~6 cycles; round 6)
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double dpp_from_upper_lane(double v) {  // lane l <- lane l+1, lane 63 <- 0
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);  // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float dpp_from_lower_lane(float v) {
@@ -895,6 +900,339 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
     *e_final = E;
 }
 
+// ---- the same lattice on a PAIR of waves per (utterance, direction) (round 6) -----------------------------------------------
+// The lone wave is latency-bound: 265 cycles per frame, of which the 20 dependent double operations of a lane's eight states
+// are 125 and the two 1 KB row stores 68 (0.10 ms of the config-3 step, 0.39 ms at config 5, nothing
+// beside it).  Here a lane owns FOUR states (lane gl of 128 owns states 4 gl .. 4 gl + 3, label positions 2 gl, 2 gl + 1): half
+// the arithmetic, one row store and three emission reads per wave and frame.  The recursion moves mass in ONE direction across
+// the wave boundary (alpha: from wave 0's lane 63 up into wave 1's lane 0; beta: from wave 1's lane 0 down into wave 0's lane
+// 63), so the upstream wave never waits: it writes its boundary state(s) of every row into an LDS mailbox (one slot per row)
+// and raises a progress counter three times per block of 16 frames -- after the block's rescale (with the boundary lane's
+// new exponent and its empty flag) and after each half of 8 frames -- and the downstream wave, which needs row t - 1 for row t,
+// runs half a block behind: it polls the counter once per half block, fetches the half block's eight boundary values in one
+// go and otherwise executes exactly the single-wave recursion.  A wave's LDS operations execute in order and LDS has no
+// caches, so "data written before the counter, counter read before the data" needs no fence.  Block floating point as in
+// wave_lattice_run; the boundary lane of the downstream wave sees the upstream boundary lane's FINAL exponent of the block in
+// every adoption round (a valid assignment like any other: exponents only re-express the values).
+constexpr int PNS = 4;            // states per lane
+constexpr int PLANES = 128;       // lanes per direction
+constexpr int PAIR_EMIS = 8 * 64 + 64;
+
+struct PairShared {
+    double* mbox;     // [T + 1][2]: boundary state(s) of row r at slot r + 1 (slot 0 = the zeros in front of row 0)
+    double* mdump;    // [128][2]: where the lanes that are not at the wave boundary put their (unused) copy -- unconditional stores
+    int* ebox;        // [blocks + 1][2]: exponent and empty flag of the upstream boundary lane after the block's rescale
+    int* progress;    // events the upstream wave has completed (3 per block)
+    double* emis;     // [2 waves][2][PAIR_EMIS]
+};
+
+// The hand-over is built from PLAIN LDS accesses in program order, a compiler barrier and relaxed work-group atomics on the
+// counter: `volatile` (or acquire / release) accesses make the memory legaliser put s_waitcnt lgkmcnt(0) -- or vmcnt(0): the
+// row stores' round trip -- behind every one of them, per frame (the first version of this kernel: 730 cycles per frame).
+template <int DIR>
+__device__ __forceinline__ void pair_lattice_run(const float* __restrict__ pr, const int32_t* __restrict__ lab,
+                                                 uint32_t* __restrict__ rows, uint32_t* __restrict__ dump,
+                                                 int32_t* __restrict__ eout, const PairShared sh, int wv, int lane, int L,
+                                                 int S, int T, int k, int blank, float eps, double* a, int* e_final) {
+    typedef double R;
+    constexpr int RB = 16;
+    constexpr int ZERO_SLOT = 63;
+    constexpr int FLOOR = WaveReal<double>::FLOOR, SHIFT_MAX = WaveReal<double>::SHIFT_MAX, TARGET = WaveReal<double>::TARGET;
+    const int gl = wv * 64 + lane;                 // lane of the direction: states 4 gl .. 4 gl + 3
+    const bool upstream = DIR == 0 ? wv == 0 : wv == 1;
+    // the lane whose neighbour lives in the other wave (downstream side) / the lane the other wave reads (upstream side)
+    const bool edge_lane = DIR == 0 ? (upstream ? lane == 63 : lane == 0) : (upstream ? lane == 0 : lane == 63);
+    const bool from_other = !upstream && edge_lane;
+    int col[2];
+    R sk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pos = 2 * gl + i;
+        const bool slot_live = pos < L;
+        const int me = slot_live ? lab[pos] : blank;
+        col[i] = slot_live ? me : ZERO_SLOT;
+        bool skip;
+        if (DIR == 0)
+            skip = slot_live && pos >= 1 && lab[pos - 1] != me;
+        else
+            skip = pos + 1 < L && lab[pos + 1] != me;
+        sk[i] = skip ? (R)1 : (R)0;
+    }
+    const int tstart = DIR == 0 ? 0 : T - 1;
+    const int tstep = DIR == 0 ? 1 : -1;
+    const bool lane_live = PNS * gl < S;
+    uint32_t* rowp = lane_live ? rows + (long)tstart * 512 + PNS * gl : dump + PNS * gl;
+    const long row_inc = lane_live ? (long)tstep * 512 : 0;
+    // mailbox store address of this lane: the real slot for the upstream boundary lane (advancing by a row per frame), a
+    // private dump slot (stride 0) for everybody else -- every lane stores, no exec mask, no branch
+    const bool poster = upstream && edge_lane;
+    double* mslot = poster ? sh.mbox : sh.mdump + 2 * gl;   // slot of row -1
+    const int mslot_inc = poster ? 2 : 0;
+
+    R* emis0 = sh.emis + (wv * 2 + 0) * PAIR_EMIS;
+    R* emis1 = sh.emis + (wv * 2 + 1) * PAIR_EMIS;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        emis0[j * 64 + lane] = (R)0;
+        emis1[j * 64 + lane] = (R)0;
+    }
+    int st_idx[4], ld_jf[4], ld_c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = lane + 64 * r;
+        const int jf = idx / k;
+        ld_c[r] = idx - jf * k;
+        ld_jf[r] = jf < 8 ? jf : 7;
+        st_idx[r] = jf < 8 ? jf * 64 + ld_c[r] : 8 * 64 + lane;
+    }
+    const float* chunk0 = pr + (long)tstart * k;
+    const int kstep = tstep * k;
+    auto fetch_chunk = [&](int base, float* e4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e4[r] = chunk0[min(base + ld_jf[r], T - 1) * kstep + ld_c[r]];
+    };
+    auto stage_chunk = [&](R* buf, const float* e4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[st_idx[r]] = (R)(e4[r] + eps);
+    };
+    float e4[4];
+    fetch_chunk(0, e4);
+    stage_chunk(emis0, e4);
+#pragma unroll
+    for (int j = 0; j < PNS; ++j) a[j] = (R)0;
+    int E = 0;
+    bool lane_zero = true;
+    R fscale = (R)1;
+    int events = 0;  // upstream: events published; downstream: events consumed
+    int mbase = 0;   // (partial last block: first mailbox slot of the half being run)
+
+    auto publish = [&]() {  // upstream: everything this wave wrote to the mailbox so far precedes this store in LDS order
+        if (upstream) {
+            ++events;
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(sh.progress, events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto await = [&]() {    // downstream: the upstream wave has completed the event of the same number
+        if (!upstream) {
+            ++events;
+            // (bounded: the upstream wave never waits, so this ends within a block's time; should that ever fail the wave goes
+            // on with what the mailbox holds instead of hanging -- the gradient kernel's sum check then flags the utterance)
+            for (int spins = 0; spins < (1 << 22); ++spins) {
+                if (__hip_atomic_load(sh.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= events) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        }
+    };
+    // boundary values of the row this wave's registers hold, into the slot `mslot` points at (then on to the next row's)
+    auto post_row = [&]() {
+        mslot += mslot_inc;
+        if (DIR == 0) {
+            mslot[0] = a[PNS - 1];
+        } else {
+            *(double2*)mslot = make_double2(a[0], a[1]);
+        }
+    };
+
+    auto rescale = [&](int base) {
+        const int tp = tstart + tstep * (base - 1);
+        const int lo_edge = DIR == 0 ? S - 2 * (T - tp) : 0;
+        const int hi_edge = DIR == 0 ? S : 2 * tp + 1;
+        eout[max(base / RB - 1, 0) * PLANES + gl] = E;
+        R m = (R)0;
+#pragma unroll
+        for (int j = 0; j < PNS; ++j) {
+            const int st = PNS * gl + j;
+            a[j] = (st < lo_edge || st > hi_edge) ? (R)0 : a[j];
+            m = wave_max2(m, a[j]);
+        }
+        lane_zero = !(m > (R)0);
+        const int shift = lane_zero ? 0 : TARGET - wave_frexp_exp(m);
+#pragma unroll
+        for (int j = 0; j < PNS; ++j) a[j] = wave_ldexp(a[j], shift);
+        E -= shift;
+        // the neighbour's values of the lane at the wave boundary: from the other wave (downstream side)
+        int x_e = E, x_zero = 1;
+        if (!upstream) {
+            x_e = sh.ebox[2 * (base / RB)];
+            x_zero = sh.ebox[2 * (base / RB) + 1];
+        }
+        const int e_own = E;
+        int zsrc = DIR == 0 ? dpp_int_from_lower_lane(lane_zero ? 1 : 0, 1) : dpp_int_from_upper_lane(lane_zero ? 1 : 0, 1);
+        zsrc = from_other ? x_zero : zsrc;
+        // in 16 frames mass moves at most 32 states = 8 lanes of four: nine rounds of "empty lane <- neighbour"
+#pragma unroll
+        for (int round = 0; round < RB / 2 + 1; ++round) {
+            int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
+            en = from_other ? x_e : en;
+            E = lane_zero ? en : (zsrc ? E : max(E, en - FLOOR));
+        }
+        const int lift = lane_zero ? 0 : E - e_own;
+#pragma unroll
+        for (int j = 0; j < PNS; ++j) a[j] = wave_ldexp(a[j], -lift);
+        int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
+        en = from_other ? x_e : en;
+        fscale = wave_ldexp((R)1, max(min(en - E, SHIFT_MAX), -4 * SHIFT_MAX));
+        // upstream: the boundary lane's exponent and empty flag of this block, and row base - 1 AS RESCALED (the row the
+        // downstream wave's first frame of the block reads): the slot written last is written again
+        if (poster) {
+            sh.ebox[2 * (base / RB)] = E;
+            sh.ebox[2 * (base / RB) + 1] = lane_zero ? 1 : 0;
+        }
+        mslot -= mslot_inc;
+        post_row();
+    };
+    // x0 / x1: the boundary value(s) of the previous row from the other wave (used by the downstream edge lane only)
+    auto frame_core = [&](const bool first, const R ub, const R (&uq)[2], const R x0, const R x1) {
+        R n[PNS];
+        if (DIR == 0) {
+            R below = dpp_from_lower_lane(a[PNS - 1]);
+            below = (from_other ? x0 : below) * fscale;
+            n[0] = a[0] + below;
+#pragma unroll
+            for (int i = 1; i < PNS; ++i) n[i] = a[i] + a[i - 1];
+            asm volatile("" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]));
+            n[1] = fma(sk[0], below, n[1]);
+            n[3] = fma(sk[1], a[1], n[3]);
+        } else {
+            R up0 = dpp_from_upper_lane(a[0]);
+            R up1 = dpp_from_upper_lane(a[1]);
+            up0 = (from_other ? x0 : up0) * fscale;
+            up1 = (from_other ? x1 : up1) * fscale;
+            n[PNS - 1] = a[PNS - 1] + up0;
+#pragma unroll
+            for (int i = 0; i < PNS - 1; ++i) n[i] = a[i] + a[i + 1];
+            asm volatile("" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]));
+            n[3] = fma(sk[1], up1, n[3]);
+            n[1] = fma(sk[0], a[3], n[1]);
+        }
+        asm volatile("" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            n[2 * i] *= ub;
+            n[2 * i + 1] *= uq[i];
+        }
+        // step 0 (branch-free: selects; `first` is false at compile time for every frame but the first of a half block): the
+        // recursion above ran on zeros, only the entry states are set
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bool blank_entry, label_entry;
+            if (DIR == 0) {
+                blank_entry = gl == 0 && i == 0;
+                label_entry = gl == 0 && i == 0;
+            } else {
+                blank_entry = PNS * gl + 2 * i == S - 1;
+                label_entry = L > 0 && PNS * gl + 2 * i + 1 == S - 2;
+            }
+            n[2 * i] = first ? (blank_entry ? ub : (R)0) : n[2 * i];
+            n[2 * i + 1] = first ? (label_entry ? uq[i] : (R)0) : n[2 * i + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < PNS; ++i) a[i] = n[i];
+        *(int4*)rowp = make_int4(__double2hiint(a[0]), __double2hiint(a[1]), __double2hiint(a[2]), __double2hiint(a[3]));
+        rowp += row_inc;
+    };
+    // the boundary values of rows base - 1 .. base + 6 for a half block (downstream; everything else gets zeros it never uses)
+    R x0[8], x1[8];
+    auto preload = [&](int base, int count) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x0[j] = (R)0;
+            x1[j] = (R)0;
+        }
+        if (!upstream) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < count) {
+                    if (DIR == 0) {
+                        x0[j] = sh.mbox[2 * (base + j)];  // slot of row base + j - 1
+                    } else {
+                        const double2 v = *(const double2*)(sh.mbox + 2 * (base + j));
+                        x0[j] = v.x;
+                        x1[j] = v.y;
+                    }
+                }
+            }
+        }
+    };
+    // eight frames, straight-line (no branch between a chunk's prefetch loads and their use: the waitcnt pass counts the
+    // row stores in between exactly -- see wave_lattice_run)
+    auto frames8 = [&](const bool entry, const R* erow0) {
+        // a frame's three emission reads are issued ONE FRAME AHEAD: a frame of four states per lane is ~35 instructions, and
+        // an LDS read issued inside it was what it waited for (lgkmcnt in front of the products: 106 us per call at 32 x 500)
+        R ub = erow0[blank];
+        R uq[2] = {erow0[col[0]], erow0[col[1]]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            R nub = ub, nuq[2] = {uq[0], uq[1]};
+            if (j < 7) {
+                const R* erow = erow0 + (j + 1) * 64;
+                nub = erow[blank];
+                nuq[0] = erow[col[0]];
+                nuq[1] = erow[col[1]];
+            }
+            frame_core(j == 0 && entry, ub, uq, x0[j], x1[j]);
+            post_row();
+            ub = nub;
+            uq[0] = nuq[0];
+            uq[1] = nuq[1];
+        }
+    };
+    auto frames_some = [&](int count, const bool entry, const R* erow0) {  // (the last, partial block)
+        for (int j = 0; j < count; ++j) {
+            const R* erow = erow0 + j * 64;
+            const R ub = erow[blank];
+            R uq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) uq[i] = erow[col[i]];
+            R xa = (R)0, xb = (R)0;
+            if (!upstream) {
+                xa = sh.mbox[2 * (mbase + j)];
+                xb = sh.mbox[2 * (mbase + j) + 1];
+            }
+            frame_core(j == 0 && entry, ub, uq, xa, xb);
+            post_row();
+        }
+    };
+
+    int base = 0;
+    for (; base + RB <= T; base += RB) {
+        await();  // (downstream: the upstream rescale of this block)
+        rescale(base);
+        publish();
+        await();  // (downstream: the upstream wave's first half of this block)
+        preload(base, 8);
+        fetch_chunk(base + 8, e4);
+        frames8(base == 0, emis0);
+        stage_chunk(emis1, e4);
+        publish();
+        await();
+        preload(base + 8, 8);
+        fetch_chunk(base + 16, e4);
+        frames8(false, emis1);
+        stage_chunk(emis0, e4);
+        publish();
+    }
+    if (base < T) {  // fewer than 16 steps left: the same three events
+        await();
+        rescale(base);
+        publish();
+        await();
+        fetch_chunk(base + 8, e4);
+        mbase = base;
+        frames_some(min(8, T - base), base == 0, emis0);
+        stage_chunk(emis1, e4);
+        publish();
+        await();
+        mbase = base + 8;
+        frames_some(max(0, min(8, T - base - 8)), false, emis1);
+        publish();
+    }
+    eout[((T - 1) / RB) * PLANES + gl] = E;
+    *e_final = E;
+}
+
 // workspace: alpha, beta R[B][T][512] (+ one dump row per utterance and direction); ea, eb int32[B][T/RB+1][64], RB =
 // WaveReal<R>::RESCALE; logz2 float[B]; cls as for the log-domain kernel
 template <typename R>
@@ -1019,6 +1357,141 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
     }
 }
 
+// dynamic LDS of ctc_lattice_pair_kernel (bytes): fin 32 | progress 32 | ebox | mbox | emis   (dir 2: the list builder's ints)
+__host__ __device__ inline size_t pair_lds_ebox(int t_out) { return (size_t)2 * (t_out / 16 + 2) * sizeof(int); }
+__host__ __device__ inline size_t pair_lds_mbox(int t_out) { return (size_t)2 * (t_out + 2) * sizeof(double); }
+__host__ inline size_t pair_lds_bytes(int t_out, int l_max, int k) {
+    size_t lattice = 64 + ((pair_lds_ebox(t_out) + 15) / 16) * 16 + pair_lds_mbox(t_out) + (size_t)2 * PLANES * sizeof(double) +
+                     (size_t)4 * PAIR_EMIS * sizeof(double);
+    const size_t lists = (size_t)(l_max + k + 1) * sizeof(int);
+    return lattice > lists ? lattice : lists;
+}
+
+// grid (B, 3), 128 threads: y = 0 alpha, 1 beta (two waves each, pair_lattice_run), 2 the per-class position lists (wave 0)
+__global__ __launch_bounds__(128) void ctc_lattice_pair_kernel(const float* __restrict__ probs, const float* __restrict__ logq,
+                                                               const int32_t* __restrict__ labels,
+                                                               const int32_t* __restrict__ label_len,
+                                                               const int32_t* __restrict__ input_len,
+                                                               uint32_t* __restrict__ alpha, uint32_t* __restrict__ beta,
+                                                               uint32_t* __restrict__ dump, int32_t* __restrict__ ea,
+                                                               int32_t* __restrict__ eb, float* __restrict__ logz2,
+                                                               int32_t* __restrict__ zint, float* __restrict__ loss,
+                                                               int32_t* __restrict__ cls, int32_t* __restrict__ flags,
+                                                               int32_t* __restrict__ tickets, int grad_wgs, int t_out, int k,
+                                                               int l_max, int blank, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char pl_lds[];
+    const int b = blockIdx.x;
+    const int dir = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int L = label_len[b];
+    if (dir == 2) {
+        if (wv != 0) return;  // (the list builder's barriers below are reached by wave 0 only: wave-level ordering suffices)
+        for (int i = lane; i < grad_wgs; i += 64) tickets[(long)b * grad_wgs + i] = 0;
+        int* s_lab = (int*)pl_lds;
+        int* s_start = s_lab + l_max;
+        int32_t* pos_out = cls + (long)b * (l_max + k + 1);
+        int32_t* start_out = pos_out + l_max;
+        for (int i = lane; i < L; i += 64) s_lab[i] = labels[(long)b * l_max + i];
+        for (int i = lane; i <= k; i += 64) s_start[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int ranks[8];
+        int nmine = 0;
+        for (int i = lane; i < L; i += 64) {
+            const int c = s_lab[i];
+            int r = 0;
+            for (int j = 0; j < i; ++j) r += (s_lab[j] == c);
+            ranks[nmine++] = r;
+            atomicAdd(&s_start[c + 1], 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0)
+            for (int c = 0; c < k; ++c) s_start[c + 1] += s_start[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        nmine = 0;
+        for (int i = lane; i < L; i += 64) pos_out[s_start[s_lab[i]] + ranks[nmine++]] = i;
+        for (int i = lane; i <= k; i += 64) start_out[i] = s_start[i];
+        return;
+    }
+    const int S = 2 * L + 1;
+    int T = input_len[b];
+    if (T > t_out) T = t_out;
+    if (T <= 0) {
+        if (dir == 0 && threadIdx.x == 0) {
+            loss[b] = INFINITY;
+            logz2[b] = 0.f;
+            zint[b] = 0;
+            flags[b] = 0;
+        }
+        return;
+    }
+    double* fin = (double*)pl_lds;
+    int* fin_e = (int*)(fin + 2);
+    PairShared sh;
+    sh.progress = (int*)(pl_lds + 32);
+    sh.ebox = (int*)(pl_lds + 64);
+    sh.mbox = (double*)(pl_lds + 64 + ((pair_lds_ebox(t_out) + 15) / 16) * 16);
+    sh.mdump = (double*)((char*)sh.mbox + pair_lds_mbox(t_out));
+    sh.emis = sh.mdump + 2 * PLANES;
+    if (threadIdx.x == 0) *sh.progress = 0;
+    __syncthreads();
+    const int32_t* lab = labels + (long)b * l_max;
+    const float* pr = probs + (long)b * t_out * k;
+    double a[PNS];
+    int E;
+    const int gl = wv * 64 + lane;
+    if (dir == 0) {
+        // sum over the scored frames of ln c_t and the repeat count (see ctc_lattice_wave_kernel): by the DOWNSTREAM wave, which
+        // has half a block to wait for its first boundary values anyway
+        float csum = 0.f;
+        int repeats = 0;
+        if (wv == 1) {
+            for (int t = lane; t < T; t += 64)
+                csum += logq[((long)b * t_out + t) * k + blank] - logf(pr[(long)t * k + blank] + eps);
+            csum = wave_sum(csum);
+            float repeats_f = 0.f;
+            for (int i = lane + 1; i < L; i += 64) repeats_f += lab[i] == lab[i - 1] ? 1.f : 0.f;
+            repeats = (int)wave_sum(repeats_f);
+        }
+        pair_lattice_run<0>(pr, lab, alpha + (long)b * t_out * 512, dump + (long)(2 * b) * 512,
+                            ea + (long)b * (t_out / 16 + 1) * PLANES, sh, wv, lane, L, S, T, k, blank, eps, a, &E);
+#pragma unroll
+        for (int i = 0; i < PNS; ++i) {
+            if (PNS * gl + i == S - 1) {
+                fin[0] = a[i];
+                fin_e[0] = E;
+            }
+            if (PNS * gl + i == S - 2) {
+                fin[1] = a[i];
+                fin_e[1] = E;
+            }
+        }
+        __syncthreads();
+        if (wv == 1 && lane == 0) {
+            const double z1 = fin[0], z2 = S >= 2 ? fin[1] : 0.0;
+            const int e1 = fin_e[0], e2 = S >= 2 ? fin_e[1] : e1;
+            const int ez = (z2 > 0.0 && (z1 == 0.0 || e2 > e1)) ? e2 : e1;
+            const double z = ldexp(z1, max(e1 - ez, -2000)) + ldexp(z2, max(e2 - ez, -2000));
+            int xz = 0;
+            const double mz = frexp(z > 0.0 ? z : 1.0, &xz);
+            const float frac = __builtin_amdgcn_logf((float)mz);
+            logz2[b] = frac;
+            zint[b] = xz + ez;
+            loss[b] = z > 0.0 ? (float)(-((double)(xz + ez) + (double)frac) * 0.6931471805599453 - (double)csum) : INFINITY;
+            flags[b] = (z > 0.0 && z < INFINITY) ? 0 : (z == 0.0 && L + repeats > T ? 0 : 1);
+        }
+    } else {
+        pair_lattice_run<1>(pr, lab, beta + (long)b * t_out * 512, dump + (long)(2 * b + 1) * 512,
+                            eb + (long)b * (t_out / 16 + 1) * PLANES, sh, wv, lane, L, S, T, k, blank, eps, a, &E);
+    }
+}
+
 __global__ __launch_bounds__(256) void greedy_decode_kernel(const float* __restrict__ probs,
                                                             const int32_t* __restrict__ input_len,
                                                             int32_t* __restrict__ out, int32_t* __restrict__ out_len,
@@ -1090,6 +1563,9 @@ __host__ int lattice_sp(int l_max) { return ((2 * l_max + 1) + 63) / 64 * 64; }
 // the repair pass (tests); 4 = double wave lattice + repair; 5 / 6 / 7 = the FLOAT wave lattice with repair / without /
 // with forced repair (measurement: 87 / 463 us, but see WaveReal)
 int g_ctc_variant = 0;
+#ifndef SL_CTC_DEFAULT_WAVE
+#define SL_CTC_DEFAULT_WAVE 4  // sl_ctc_select(0): 4 = one wave per direction, 8 = the wave pair (A/B builds: -DSL_CTC_DEFAULT_WAVE=8)
+#endif
 
 struct CtcLayout {
     size_t log_alpha, log_beta, cls, lin_alpha, lin_beta, dump, ea, eb, logz2, zint, flags, tickets, total;
@@ -1110,7 +1586,8 @@ __host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
     w.lin_alpha = take(wave ? rows * 64 * WNS * sizeof(uint32_t) : 0);  // a float, or the high word of a double, per state
     w.lin_beta = take(wave ? rows * 64 * WNS * sizeof(uint32_t) : 0);
     w.dump = take(wave ? (size_t)2 * batch * 64 * WNS * sizeof(uint32_t) : 0);
-    const size_t eblocks = (size_t)batch * (t_out / 8 + 1) * 64;  // one exponent per lane and block of 16 (double) / 8 (float) steps
+    // one exponent per lane and block of 16 (double) / 8 (float) steps; the pair lattice: 128 per block of 16
+    const size_t eblocks = (size_t)batch * (t_out / 8 + 2) * 64;
     w.ea = take(wave ? eblocks * sizeof(int32_t) : 0);
     w.eb = take(wave ? eblocks * sizeof(int32_t) : 0);
     w.logz2 = take((size_t)batch * sizeof(float));
@@ -1124,7 +1601,7 @@ __host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
 }  // namespace
 
 extern "C" int sl_ctc_select(int variant) {
-    SL_CHECK_ARG(variant >= 0 && variant <= 7, "sl_ctc_select: variant %d outside 0..7", variant);
+    SL_CHECK_ARG(variant >= 0 && variant <= 9, "sl_ctc_select: variant %d outside 0..9", variant);
     g_ctc_variant = variant;
     return SL_OK;
 }
@@ -1180,11 +1657,17 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
     // which lattice: see sl_ctc_select
     const bool fits = 2 * l_max + 1 <= 64 * WNS && k <= 63;
     int v = g_ctc_variant;
-    if (v == 0) v = fits ? 4 : 1;
+    // 8 (round 6): the double lattice on a PAIR of waves per direction (pair_lattice_run); its LDS mailbox holds a slot per
+    // frame, so very long utterances (T' > 8000) stay on the single wave
+    const bool pair_fits = fits && pair_lds_bytes(t_out, l_max, k) <= 150 * 1024;
+    if (v == 0) v = fits ? (pair_fits ? SL_CTC_DEFAULT_WAVE : 4) : 1;
     if (v != 1 && !fits) v = 1;
+    if (v == 8 && !pair_fits) v = 4;
+    if (v == 9 && !pair_fits) v = 2;
     const bool wave = v != 1;
-    const bool wave_f32 = v >= 5;
-    const bool repair = wave && v != 2 && v != 6;
+    const bool pair = v == 8 || v == 9;
+    const bool wave_f32 = v >= 5 && v <= 7;
+    const bool repair = wave && v != 2 && v != 6 && v != 9;
     const bool force_repair = v == 3 || v == 7;
     const int frames_per_wg = 8;  // two frames per wave: 16000 frames -> 8000 waves in flight
     const size_t lds2 = (size_t)(2 * l_max + (k + 1)) * sizeof(int) + (size_t)(4 * 64 + 4 * l_max) * sizeof(float);
@@ -1201,7 +1684,18 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
         int32_t* tickets = (int32_t*)(base + w.tickets);
         size_t lds = (size_t)(l_max + k + 1) * sizeof(int);
         if (lds < 2 * sizeof(double) + 2 * sizeof(int)) lds = 2 * sizeof(double) + 2 * sizeof(int);
-        if (wave_f32)
+        if (pair) {
+            const size_t plds = pair_lds_bytes(t_out, l_max, k);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)ctc_lattice_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(ctc_lattice_pair_kernel, dim3(batch, 3), dim3(128), plds, s, probs, logq, labels, label_len,
+                               input_len, (uint32_t*)la, (uint32_t*)lb, (uint32_t*)(base + w.dump), ea, eb, logz2, zint, loss,
+                               cls, flags, tickets, (int)grid.x, t_out, k, l_max, k - 1, eps);
+        } else if (wave_f32)
             hipLaunchKernelGGL(ctc_lattice_wave_kernel<float>, dim3(batch, 3), dim3(64), lds, s, probs, logq, labels,
                                label_len, input_len, (uint32_t*)la, (uint32_t*)lb, (uint32_t*)(base + w.dump), ea, eb, logz2, zint,
                                loss, cls, flags, tickets, (int)grid.x, t_out, k, l_max, k - 1, eps);
@@ -1218,7 +1712,12 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
         // rows are 512 values wide; the kernel reads 8 columns per lane.  The repair pass is the tail of this launch
         // (ctc_grad_kernel: the work-group that finishes an utterance last redoes it if it was flagged).
         int32_t* rep_tickets = repair ? tickets : nullptr;
-        if (wave_f32)
+        if (pair)
+            hipLaunchKernelGGL((ctc_grad_kernel<8, 3>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
+                               input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
+                               l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
+                               eps, grad_scale, flags, rep_tickets, alpha, beta, sp);
+        else if (wave_f32)
             hipLaunchKernelGGL((ctc_grad_kernel<8, 2>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
                                input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
                                l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,

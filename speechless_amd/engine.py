@@ -1066,8 +1066,9 @@ class Engine(X3Mixin, SplitTopMixin, FrontLayerMixin):
             buf.multi_tables[key] = table
             need = self._wgrad_multi_workspace_need(table, len(layers))
             if buf.wgrad_multi_ws is None or buf.wgrad_multi_ws.numel() < need:
+                if buf.wgrad_multi_ws is not None:
+                    buf.launch_lists = {}  # (a recorded list may hold the pointer that is freed here)
                 buf.wgrad_multi_ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=self.device)
-                buf.launch_lists = {}
         return table
 
     def _launch_wgrad_multi(self, buf, layers, st):
