@@ -210,15 +210,17 @@ def test_bf16x3_dropout_training_step_with_recomputed_masks(activation):
     assert np.array_equal(eng.forward(case["x"]).cpu().numpy(), probs_eval)
 
 
-def test_bf16x3_training_steps_through_recorded_launch_lists_equal_eager_steps():
-    """bf16x3 with recorded launch lists (round 4; they were switched off for this path) against SL_LAUNCH_LISTS=0: three
-    optimisation steps on batches of two different lengths in one buffer set, bit-identical weights and losses."""
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
+def test_bf16x3_training_steps_through_recorded_launch_lists_equal_eager_steps(dtype):
+    """bf16x3 (f16x3: round 6) with recorded launch lists (round 4; they were switched off for this path) against
+    SL_LAUNCH_LISTS=0: three optimisation steps on batches of two different lengths in one buffer set, bit-identical weights
+    and losses."""
     import torch
     case = make_case(b=3, t=140, seed=3)
     short = case["x"][:, :120].copy()
     finals = []
     for lists in (True, False):
-        eng = make_engine(case, "bf16x3")
+        eng = make_engine(case, dtype)
         eng.use_launch_lists = lists
         losses = []
         for step in range(4):
@@ -234,8 +236,9 @@ def test_bf16x3_training_steps_through_recorded_launch_lists_equal_eager_steps()
     assert np.isfinite(finals[0][0]).all()
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("shard_optimizer", [False, True])
-def test_bf16x3_data_parallel_step_through_rccl_single_rank(shard_optimizer):
+def test_bf16x3_data_parallel_step_through_rccl_single_rank(shard_optimizer, dtype):
     """The data-parallel hooks of the bf16x3 path: the bucketed exchange through the real RCCL backend on
     one rank is the identity, so weights and losses must equal the plain step bit for bit -- and every bucket is announced
     exactly once, in bucket_plan()'s order."""
@@ -252,7 +255,7 @@ def test_bf16x3_data_parallel_step_through_rccl_single_rank(shard_optimizer):
         dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         for use_reducer in (False, True):
-            eng = make_engine(case, "bf16x3")
+            eng = make_engine(case, dtype)
             reducer = None
             announced = []
             if use_reducer:

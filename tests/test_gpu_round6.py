@@ -214,7 +214,8 @@ def test_f16x3_loss_and_gradients_against_the_float64_oracle(t):
     """Engine(dtype='f16x3'): every value as hi + lo FP16 planes -- 22 significand bits instead of bf16x3's
     16-17, same three MFMA terms (v_mfma_f32_16x16x32_f16), weights stored x 2^6 and gradients x 2^12 (exact powers of two,
     divided out by sl_conv_geom.acc_scale / the combine) -- against the float64 oracle: loss and every gradient tensor at the
-    exact-fp32 path's level, an order of magnitude inside bf16x3's bounds (5e-3 in tests/test_gpu_round3.py)."""
+    exact-fp32 path's level: north_star's 1e-3 on every tensor (2e-3 on striding_conv's dW, where a single ReLU decision that
+    differs from float64 shows in a batch of three short utterances); bf16x3's bounds in tests/test_gpu_round3.py are 5e-3."""
     import torch
     case = make_case(b=3, t=t, seed=3)
     ref = o.loss_and_gradients(case["ospecs"], weights64(case), case["x"].astype(np.float64), case["labels"],
@@ -233,7 +234,7 @@ def test_f16x3_loss_and_gradients_against_the_float64_oracle(t):
     _report("grads_f16x3_rel_l2_t{}".format(t), report)
     for name, (ew, eb) in report.items():
         # (striding_conv's dW: where a single ReLU decision that differs from float64 shows)
-        assert ew < (2e-3 if name == "striding_conv" else 5e-4) and eb < 5e-4, (name, ew, eb)
+        assert ew < (2e-3 if name == "striding_conv" else 1e-3) and eb < 1e-3, (name, ew, eb)  # north_star's bar
     decoded, _ = eng.greedy_decode(case["prediction_lengths"])
     assert decoded == o.greedy_decode_indices(ref["probs"], case["prediction_lengths"])
     # optimisation steps through the scaled plane operands: the loss goes down, padded lanes stay zero, and the operand copies

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--bins", type=int, default=128, help="input bins (257: the long-form configuration)")
     ap.add_argument("--max-frames", type=int, default=1400)
     ap.add_argument("--max-batch", type=int, default=6)
-    ap.add_argument("--x3", action="store_true", help="also the bf16x3 path (loss within 2e-6 of fp32)")
+    ap.add_argument("--x3", action="store_true", help="also the bf16x3 and f16x3 paths (loss within 2e-6 of fp32)")
     ap.add_argument("--split", action="store_true",
                     help="also the bf16 path with Engine.split_top forced on every batch of >= 2 utterances, in a random split "
                          "a + (B - a) (the CTC of one part under the top layers of the other): loss within 2e-5 of the "
@@ -42,7 +42,7 @@ def main():
         specs = wav2letter_layer_specs(args.bins, 29)
     weights = Wav2Letter._glorot_uniform(specs, 2)
     engines = {}
-    for dtype in ("bf16", "f32") + (("bf16x3",) if args.x3 else ()):
+    for dtype in ("bf16", "f32") + (("bf16x3",) if args.x3 else ()) + (("f16x3",) if (args.x3 and not args.wave) else ()):
         eng = engines[dtype] = Engine(specs, 29, dtype=dtype)
         eng.max_cached_shapes = 4
     rng = np.random.RandomState(args.seed)
@@ -104,8 +104,10 @@ def main():
         worst = max(worst, rel)
         assert rel < 2e-3, (b, t, pred_len, lab_len, out)
         if args.x3:
-            rel3 = float(np.max(np.abs(out["bf16x3"] - out["f32"]) / np.maximum(np.abs(out["f32"]), 1.0)))
-            assert rel3 < 2e-6, (b, t, rel3, out)
+            for x3 in ("bf16x3", "f16x3"):
+                if x3 in out:
+                    rel3 = float(np.max(np.abs(out[x3] - out["f32"]) / np.maximum(np.abs(out["f32"]), 1.0)))
+                    assert rel3 < 2e-6, (x3, b, t, rel3, out)
         print("case %3d  b %d  t %4d  labels %s  loss %s  bf16 vs f32 %.1e" % (
             case, b, t, lab_len.tolist(), np.round(out["f32"], 2).tolist(), rel), flush=True)
     print("all %d cases passed; worst bf16-vs-f32 loss difference %.2e" % (args.cases, worst))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Resident training step (config 3 batch: 32 x 1000 frames, labels U{20..200}) and forward + decode (config 2) per storage
-scheme: bf16 (benchmarked), bf16x3 (hi + lo planes, three bf16 MFMA terms: the fast parity path), f32 (exact-fp32 MFMA).
+scheme: bf16 (benchmarked), bf16x3 / f16x3 (hi + lo bf16 / fp16 planes, three MFMA terms: the fast parity paths), f32 (exact-fp32
+MFMA).
 
     python tools/step_time_by_dtype.py [--steps 10]
 """
@@ -24,7 +25,7 @@ def main():
     specs = wav2letter_layer_specs(bench.MEL, bench.K_CLASSES)
     weights = Wav2Letter._glorot_uniform(specs, 2)
     x, labels, lab_len, pred_len = bench.synthetic_batch(0, bench.BATCH_PER_GPU)
-    for dtype in ("bf16", "bf16x3", "f32"):
+    for dtype in ("bf16", "bf16x3", "f16x3", "f32"):
         eng = Engine(specs, bench.K_CLASSES, dtype=dtype)
         eng.set_weights(weights)
         eng.load_input(torch.from_numpy(x).cuda())
