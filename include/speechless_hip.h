@@ -298,7 +298,9 @@ int sl_ctc_loss_grad(const float* probs, const float* logq, const int32_t* label
  * repair pass, 4 = + repair; in floats (faster, but the repair pass is needed in some regimes: ctc.hip:WaveReal): 6 / 7 / 5
  * likewise; 8 / 9 (round 6) = the double lattice on a PAIR of waves per utterance and direction (four states per lane, the
  * boundary state handed over through an LDS mailbox, the downstream wave half a block behind) with / without the repair
- * pass.  Process-wide; not for concurrent use with sl_ctc_loss_grad. */
+ * pass; 10 / 11 (round 6) = the lone double lattice wave with a HELPER wave beside it that fetches the probabilities and gathers
+ * every lattice lane's emissions into 48 contiguous bytes of LDS per frame (three wide LDS reads per frame instead of five, no
+ * staging work in the lattice wave) with / without the repair pass.  Process-wide; not for concurrent use with sl_ctc_loss_grad. */
 int sl_ctc_select(int variant);
 
 /* ---- greedy decode (net.py:452-454 tf.nn.ctc_greedy_decoder, merge_repeated=True; numpy twin

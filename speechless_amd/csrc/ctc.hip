@@ -642,14 +642,32 @@ __device__ __forceinline__ int dpp_int_from_upper_lane(int v, int lane63_value) 
     return __builtin_amdgcn_update_dpp(lane63_value, v, 0x130, 0xf, 0xf, false);
 }
 
+// {high word of x, high word of y} in ONE instruction (v_pk_mov_b32 with op_sel:[1,1]: tools/pk_mov_probe.hip): a row store packs
+// the high words of a lane's doubles, and four v_mov per int4 were 8 of a beta frame's 41 instructions (round 6)
+__device__ __forceinline__ unsigned long long pk_high_words(double x, double y) {
+    unsigned long long r;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 // The recursion of one direction (compile-time DIR: 0 = alpha, forwards; 1 = beta, backwards).  Every store is
 // unconditional (dead lanes write their row slice to a dump row with stride 0, every lane writes the frame's exponent to
 // the same word): an exec-masked store between a prefetch load and its use would force s_waitcnt vmcnt(0) per frame.
-template <int DIR, typename R>
+// HELP (round 6): a second wave of the work-group (lattice_helper) fetches the probabilities and GATHERS, per frame and lattice
+// lane, the lane's four label emissions and the blank's into 48 contiguous bytes of LDS -- the lattice wave then reads a frame's
+// emissions with three ds_read_b128 instead of five ds_read_b64 and does no staging of its own (4 loads, 4 conversions, 4 LDS
+// writes and their address arithmetic per 8 frames).  A lone wave's frame time is its instruction count (section 6 of DESIGN.md).
+struct HelpShared {
+    double* gath;    // [2][8 frames][64 lanes][6]: {uq0, uq1, uq2, uq3, ub, -}
+    int* progress;   // chunks (of 8 frames) the helper has published
+    int* consumed;   // chunks the lattice wave has finished reading
+};
+template <int DIR, typename R, bool HELP = false>
 __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, const int32_t* __restrict__ lab,
                                                  uint32_t* __restrict__ rows, uint32_t* __restrict__ dump,
                                                  int32_t* __restrict__ eout, int lane, int L, int S, int T, int k,
-                                                 int blank, float eps, R* a, int* e_final) {
+                                                 int blank, float eps, R* a, int* e_final,
+                                                 const HelpShared hs = HelpShared()) {
     constexpr int RB = WaveReal<R>::RESCALE;  // frames between rescales = frames per stored exponent
     constexpr int ZERO_SLOT = 63;             // emission slot of the dead label positions (k <= 63)
     // label slots of this lane: position 4 * lane + i sits in state 8 * lane + 2 * i + 1
@@ -681,11 +699,13 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
     // trip (~1.5 us) is what paced the first version of this kernel (0.235 us per frame).  The LDS copy holds u = p + eps
     // already in the lattice's number type (the conversions and the five adds per frame were a third of a frame's time:
     // s_memtime probe, 473 -> 324 ticks without them) and a zero in slot 63 for the dead label positions.
-    __shared__ R emis[2][8 * 64 + 64];  // (+ 64: where the lanes beyond 8 * k of a chunk put their value)
+    __shared__ R emis[HELP ? 1 : 2][HELP ? 1 : 8 * 64 + 64];  // (+ 64: where the lanes beyond 8 * k of a chunk put their value)
+    if (!HELP) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        emis[0][j * 64 + lane] = (R)0;
-        emis[1][j * 64 + lane] = (R)0;
+        for (int j = 0; j < 8; ++j) {
+            emis[0][j * 64 + lane] = (R)0;
+            emis[HELP ? 0 : 1][j * 64 + lane] = (R)0;
+        }
     }
     // per-lane constants of the chunk transfer (k is not a compile-time constant: no division inside the loop); frames
     // past the end of the utterance re-read its last frame (their results are never used)
@@ -701,16 +721,37 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
     const float* chunk0 = pr + (long)tstart * k;
     const int kstep = tstep * k;
     auto fetch_chunk = [&](int base, float* e4) {
+        if (HELP) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) e4[r] = chunk0[min(base + ld_jf[r], T - 1) * kstep + ld_c[r]];
     };
     auto stage_chunk = [&](int buf, const float* e4) {
+        if (HELP) return;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) emis[buf][st_idx[r]] = (R)(e4[r] + eps);
+        for (int r = 0; r < 4; ++r) emis[HELP ? 0 : buf][st_idx[r]] = (R)(e4[r] + eps);
     };
-    float e4[4];
+    float e4[4] = {0.f, 0.f, 0.f, 0.f};
     fetch_chunk(0, e4);
     stage_chunk(0, e4);
+    // HELP: hand-over with the helper wave per chunk of 8 frames (plain LDS accesses in program order, relaxed work-group
+    // atomics on the counters: see pair_lattice_run)
+    int chunks_done = 0;
+    auto await_chunk = [&]() {  // the helper has published chunk `chunks_done`
+        if (HELP) {
+            for (int spins = 0; spins < (1 << 22); ++spins) {
+                if (__hip_atomic_load(hs.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > chunks_done) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        }
+    };
+    auto release_chunk = [&]() {  // (every lane stores the same value to the same word: no exec mask)
+        if (HELP) {
+            ++chunks_done;
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(hs.consumed, chunks_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
 #pragma unroll
     for (int j = 0; j < WNS; ++j) a[j] = (R)0;
     int E = 0;              // this lane's exponent: true value = stored value * 2^E
@@ -831,8 +872,8 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
             // gradient kernel reads a state as (high word, 0): truncated by < 2^-20, a posterior by < 1e-6 relative.
 #pragma unroll
             for (int i = 0; i < WNS; i += 4)
-                *(int4*)(rowp + i) = make_int4(__double2hiint((double)a[i]), __double2hiint((double)a[i + 1]),
-                                               __double2hiint((double)a[i + 2]), __double2hiint((double)a[i + 3]));
+                *(ulonglong2*)(rowp + i) = make_ulonglong2(pk_high_words((double)a[i], (double)a[i + 1]),
+                                                           pk_high_words((double)a[i + 2], (double)a[i + 3]));
         } else {
 #pragma unroll
             for (int i = 0; i < WNS; i += 4)
@@ -845,6 +886,15 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
     // nothing: the reads are not what a frame waits for.  A frame is 47 instructions of a lone wave, ~7 cycles each.)
     auto frame = [&](bool first, const R* erow) {
         R uq[4];
+        if constexpr (HELP) {  // erow: this lane's {uq0, uq1, uq2, uq3, ub, -} of the frame
+            const double2 q01 = ((const double2*)erow)[0], q23 = ((const double2*)erow)[1], qb = ((const double2*)erow)[2];
+            uq[0] = (R)q01.x;
+            uq[1] = (R)q01.y;
+            uq[2] = (R)q23.x;
+            uq[3] = (R)q23.y;
+            frame_core(first, (R)qb.x, uq);
+            return;
+        }
 #if defined(SL_PROBE_CTC_NOEMIS)  // timing probe (wrong results): no emission reads
         const R ub = (R)0.03;
 #pragma unroll
@@ -857,44 +907,62 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
         frame_core(first, ub, uq);
     };
 
+    // a frame's emission source: row j of staging buffer `buf` (by class), or -- HELP -- this lane's gathered 48 bytes
+    auto erow_of = [&](int buf, int j) -> const R* {
+        if constexpr (HELP)
+            return (const R*)(hs.gath + ((long)(buf * 8 + j) * 64 + lane) * 6);
+        else
+            return &emis[buf][j * 64];
+    };
     // Full blocks of 16 steps run as straight-line code: the waitcnt pass can then count the stores that are
     // younger than a chunk's prefetch loads exactly (with a branch per frame it assumed none and waited for the stores'
     // round trip once per chunk).
     int base = 0;
     if (T >= WRESCALE) {
         rescale(0);
+        await_chunk();
         fetch_chunk(8, e4);
-        frame(true, &emis[0][0]);  // (peeled: the only frame with the entry-state special case)
+        frame(true, erow_of(0, 0));  // (peeled: the only frame with the entry-state special case)
 #pragma unroll
-        for (int j = 1; j < 8; ++j) frame(false, &emis[0][j * 64]);
+        for (int j = 1; j < 8; ++j) frame(false, erow_of(0, j));
         stage_chunk(1, e4);
+        release_chunk();
+        await_chunk();
         fetch_chunk(16, e4);
         if (RB == 8) rescale(8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) frame(false, &emis[1][j * 64]);
+        for (int j = 0; j < 8; ++j) frame(false, erow_of(1, j));
         stage_chunk(0, e4);
+        release_chunk();
         base = WRESCALE;
     }
     for (; base + WRESCALE <= T; base += WRESCALE) {
         rescale(base);
+        await_chunk();
         fetch_chunk(base + 8, e4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) frame(false, &emis[0][j * 64]);
+        for (int j = 0; j < 8; ++j) frame(false, erow_of(0, j));
         stage_chunk(1, e4);
+        release_chunk();
+        await_chunk();
         fetch_chunk(base + 16, e4);
         if (RB == 8) rescale(base + 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) frame(false, &emis[1][j * 64]);
+        for (int j = 0; j < 8; ++j) frame(false, erow_of(1, j));
         stage_chunk(0, e4);
+        release_chunk();
     }
     // tail: fewer than 16 steps left (the next chunk is already staged in buffer 0)
     if (base < T) {
         rescale(base);
+        await_chunk();
         fetch_chunk(base + 8, e4);
-        for (int j = 0; j < 8 && base + j < T; ++j) frame(base + j == 0, &emis[0][j * 64]);
+        for (int j = 0; j < 8 && base + j < T; ++j) frame(base + j == 0, erow_of(0, j));
         stage_chunk(1, e4);
+        release_chunk();
+        if (base + 8 < T) await_chunk();
         if (RB == 8 && base + 8 < T) rescale(base + 8);
-        for (int j = 0; j < 8 && base + 8 + j < T; ++j) frame(false, &emis[1][j * 64]);
+        for (int j = 0; j < 8 && base + 8 + j < T; ++j) frame(false, erow_of(1, j));
     }
     eout[((T - 1) / RB) * 64 + lane] = E;  // the last (possibly partial) block
     *e_final = E;
@@ -1130,7 +1198,7 @@ __device__ __forceinline__ void pair_lattice_run(const float* __restrict__ pr, c
         }
 #pragma unroll
         for (int i = 0; i < PNS; ++i) a[i] = n[i];
-        *(int4*)rowp = make_int4(__double2hiint(a[0]), __double2hiint(a[1]), __double2hiint(a[2]), __double2hiint(a[3]));
+        *(ulonglong2*)rowp = make_ulonglong2(pk_high_words(a[0], a[1]), pk_high_words(a[2], a[3]));
         rowp += row_inc;
     };
     // the boundary values of rows base - 1 .. base + 6 for a half block (downstream; everything else gets zeros it never uses)
@@ -1357,6 +1425,225 @@ __global__ __launch_bounds__(64) void ctc_lattice_wave_kernel(const float* __res
     }
 }
 
+// ---- the helper wave of wave_lattice_run<DIR, double, true> ----------------------------------------------------------------
+// Fetches the probabilities of a chunk of 8 frames with four coalesced loads per lane (one chunk ahead), stages u = p + eps by
+// class in its own LDS area, gathers for every lattice lane the emissions of its four label slots and of the blank, and writes
+// them lane-major (48 bytes per lane and frame: ds_write_b128 x 3, bank-conflict-free at that stride) into the two-deep ring the
+// lattice wave reads.  It runs a chunk ahead of the lattice wave and waits only when both ring slots are still unread.
+template <int DIR>
+__device__ __forceinline__ void lattice_helper(const float* __restrict__ pr, const int32_t* __restrict__ lab, const HelpShared hs,
+                                               double* __restrict__ raw, int lane, int L, int T, int k, int blank, float eps) {
+    constexpr int ZERO_SLOT = 63;
+    int col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pos = 4 * lane + i;
+        col[i] = pos < L ? lab[pos] : ZERO_SLOT;  // dead label slots: u = 0
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j * 64 + lane] = 0.0;  // (slot 63 of every frame stays zero: k <= 63 classes)
+    int st_idx[4], ld_jf[4], ld_c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = lane + 64 * r;
+        const int jf = idx / k;
+        ld_c[r] = idx - jf * k;
+        ld_jf[r] = jf < 8 ? jf : 7;
+        st_idx[r] = jf < 8 ? jf * 64 + ld_c[r] : 8 * 64 + lane;
+    }
+    const int tstart = DIR == 0 ? 0 : T - 1;
+    const int tstep = DIR == 0 ? 1 : -1;
+    const float* chunk0 = pr + (long)tstart * k;
+    const int kstep = tstep * k;
+    float e4[4];
+    auto fetch = [&](int base) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e4[r] = chunk0[min(base + ld_jf[r], T - 1) * kstep + ld_c[r]];
+    };
+    const int nchunks = (T + 7) / 8;
+    fetch(0);
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) raw[st_idx[r]] = (double)(e4[r] + eps);
+        fetch(8 * (c + 1));  // (the next chunk's loads fly during this chunk's gather; past the end: the last frame again)
+        // ring slot c & 1 was last used by chunk c - 2: free once the lattice wave has released it
+        for (int spins = 0; spins < (1 << 22); ++spins) {
+            if (__hip_atomic_load(hs.consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= c - 1) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        double* dst = hs.gath + ((long)((c & 1) * 8) * 64 + lane) * 6;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double* row = raw + j * 64;
+            const double2 q01 = make_double2(row[col[0]], row[col[1]]);
+            const double2 q23 = make_double2(row[col[2]], row[col[3]]);
+            const double2 qb = make_double2(row[blank], 0.0);
+            double2* d = (double2*)(dst + (long)j * 64 * 6);
+            d[0] = q01;
+            d[1] = q23;
+            d[2] = qb;
+        }
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(hs.progress, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (all lanes, same value)
+    }
+}
+
+// per-class position lists for the gradient kernel, by ONE wave (the y = 2 work-groups of the pair / helped lattice kernels)
+__device__ __forceinline__ void build_class_lists_wave(int* s_lab, int lane, const int32_t* __restrict__ labels,
+                                                       int32_t* __restrict__ cls, int32_t* __restrict__ tickets, int b, int L,
+                                                       int grad_wgs, int k, int l_max) {
+    for (int i = lane; i < grad_wgs; i += 64) tickets[(long)b * grad_wgs + i] = 0;
+    int* s_start = s_lab + l_max;
+    int32_t* pos_out = cls + (long)b * (l_max + k + 1);
+    int32_t* start_out = pos_out + l_max;
+    for (int i = lane; i < L; i += 64) s_lab[i] = labels[(long)b * l_max + i];
+    for (int i = lane; i <= k; i += 64) s_start[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int ranks[8];
+    int nmine = 0;
+    for (int i = lane; i < L; i += 64) {
+        const int c = s_lab[i];
+        int r = 0;
+        for (int j = 0; j < i; ++j) r += (s_lab[j] == c);
+        ranks[nmine++] = r;
+        atomicAdd(&s_start[c + 1], 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0)
+        for (int c = 0; c < k; ++c) s_start[c + 1] += s_start[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    nmine = 0;
+    for (int i = lane; i < L; i += 64) pos_out[s_start[s_lab[i]] + ranks[nmine++]] = i;
+    for (int i = lane; i <= k; i += 64) start_out[i] = s_start[i];
+}
+
+// dynamic LDS of ctc_lattice_helped_kernel: fin 32 | csum 16 | counters 16 | raw (8 * 64 + 64) doubles | gath 2 * 8 * 64 * 6 doubles
+constexpr int HELP_RAW = 8 * 64 + 64;
+constexpr size_t HELP_LDS_BYTES = 64 + (size_t)HELP_RAW * sizeof(double) + (size_t)2 * 8 * 64 * 6 * sizeof(double);
+__host__ inline size_t helped_lds_bytes(int l_max, int k) {
+    const size_t lists = (size_t)(l_max + k + 1) * sizeof(int);
+    return HELP_LDS_BYTES > lists ? HELP_LDS_BYTES : lists;
+}
+
+// grid (B, 3), 128 threads: y = 0 alpha, 1 beta -- wave 0 the lattice (wave_lattice_run<.., true>), wave 1 its helper; y = 2 the
+// class lists (wave 0)
+__global__ __launch_bounds__(128) void ctc_lattice_helped_kernel(const float* __restrict__ probs, const float* __restrict__ logq,
+                                                                 const int32_t* __restrict__ labels,
+                                                                 const int32_t* __restrict__ label_len,
+                                                                 const int32_t* __restrict__ input_len,
+                                                                 uint32_t* __restrict__ alpha, uint32_t* __restrict__ beta,
+                                                                 uint32_t* __restrict__ dump, int32_t* __restrict__ ea,
+                                                                 int32_t* __restrict__ eb, float* __restrict__ logz2,
+                                                                 int32_t* __restrict__ zint, float* __restrict__ loss,
+                                                                 int32_t* __restrict__ cls, int32_t* __restrict__ flags,
+                                                                 int32_t* __restrict__ tickets, int grad_wgs, int t_out, int k,
+                                                                 int l_max, int blank, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char hl_lds[];
+    const int b = blockIdx.x;
+    const int dir = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int L = label_len[b];
+    if (dir == 2) {
+        if (wv == 0) build_class_lists_wave((int*)hl_lds, lane, labels, cls, tickets, b, L, grad_wgs, k, l_max);
+        return;
+    }
+    const int S = 2 * L + 1;
+    int T = input_len[b];
+    if (T > t_out) T = t_out;
+    if (T <= 0) {
+        if (dir == 0 && threadIdx.x == 0) {
+            loss[b] = INFINITY;
+            logz2[b] = 0.f;
+            zint[b] = 0;
+            flags[b] = 0;
+        }
+        return;
+    }
+    double* fin = (double*)hl_lds;
+    int* fin_e = (int*)(fin + 2);
+    float* csum_s = (float*)(hl_lds + 32);
+    int* repeats_s = (int*)(hl_lds + 36);
+    HelpShared hs;
+    hs.progress = (int*)(hl_lds + 48);
+    hs.consumed = (int*)(hl_lds + 52);
+    double* raw = (double*)(hl_lds + 64);
+    hs.gath = raw + HELP_RAW;
+    if (threadIdx.x == 0) {
+        *hs.progress = 0;
+        *hs.consumed = 0;
+    }
+    __syncthreads();
+    const int32_t* lab = labels + (long)b * l_max;
+    const float* pr = probs + (long)b * t_out * k;
+    if (wv == 1) {
+        if (dir == 0)
+            lattice_helper<0>(pr, lab, hs, raw, lane, L, T, k, blank, eps);
+        else
+            lattice_helper<1>(pr, lab, hs, raw, lane, L, T, k, blank, eps);
+        if (dir == 0) {
+            // sum over the scored frames of ln c_t and the repeat count (see ctc_lattice_wave_kernel): the helper has the slack
+            float csum = 0.f;
+            for (int t = lane; t < T; t += 64)
+                csum += logq[((long)b * t_out + t) * k + blank] - logf(pr[(long)t * k + blank] + eps);
+            csum = wave_sum(csum);
+            float repeats_f = 0.f;
+            for (int i = lane + 1; i < L; i += 64) repeats_f += lab[i] == lab[i - 1] ? 1.f : 0.f;
+            const int repeats = (int)wave_sum(repeats_f);
+            if (lane == 0) {
+                *csum_s = csum;
+                *repeats_s = repeats;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    double a[WNS];
+    int E;
+    if (dir == 0) {
+        wave_lattice_run<0, double, true>(pr, lab, alpha + (long)b * t_out * (64 * WNS), dump + (long)(2 * b) * (64 * WNS),
+                                          ea + (long)b * (t_out / 16 + 1) * 64, lane, L, S, T, k, blank, eps, a, &E, hs);
+#pragma unroll
+        for (int i = 0; i < WNS; ++i) {
+            if (WNS * lane + i == S - 1) {
+                fin[0] = a[i];
+                fin_e[0] = E;
+            }
+            if (WNS * lane + i == S - 2) {
+                fin[1] = a[i];
+                fin_e[1] = E;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const float csum = *csum_s;
+            const int repeats = *repeats_s;
+            const double z1 = fin[0], z2 = S >= 2 ? fin[1] : 0.0;
+            const int e1 = fin_e[0], e2 = S >= 2 ? fin_e[1] : e1;
+            const int ez = (z2 > 0.0 && (z1 == 0.0 || e2 > e1)) ? e2 : e1;
+            const double z = ldexp(z1, max(e1 - ez, -2000)) + ldexp(z2, max(e2 - ez, -2000));
+            int xz = 0;
+            const double mz = frexp(z > 0.0 ? z : 1.0, &xz);
+            const float frac = __builtin_amdgcn_logf((float)mz);
+            logz2[b] = frac;
+            zint[b] = xz + ez;
+            loss[b] = z > 0.0 ? (float)(-((double)(xz + ez) + (double)frac) * 0.6931471805599453 - (double)csum) : INFINITY;
+            flags[b] = (z > 0.0 && z < INFINITY) ? 0 : (z == 0.0 && L + repeats > T ? 0 : 1);
+        }
+    } else {
+        wave_lattice_run<1, double, true>(pr, lab, beta + (long)b * t_out * (64 * WNS), dump + (long)(2 * b + 1) * (64 * WNS),
+                                          eb + (long)b * (t_out / 16 + 1) * 64, lane, L, S, T, k, blank, eps, a, &E, hs);
+        __syncthreads();
+    }
+}
+
 // dynamic LDS of ctc_lattice_pair_kernel (bytes): fin 32 | progress 32 | ebox | mbox | emis   (dir 2: the list builder's ints)
 __host__ __device__ inline size_t pair_lds_ebox(int t_out) { return (size_t)2 * (t_out / 16 + 2) * sizeof(int); }
 __host__ __device__ inline size_t pair_lds_mbox(int t_out) { return (size_t)2 * (t_out + 2) * sizeof(double); }
@@ -1386,37 +1673,7 @@ __global__ __launch_bounds__(128) void ctc_lattice_pair_kernel(const float* __re
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int L = label_len[b];
     if (dir == 2) {
-        if (wv != 0) return;  // (the list builder's barriers below are reached by wave 0 only: wave-level ordering suffices)
-        for (int i = lane; i < grad_wgs; i += 64) tickets[(long)b * grad_wgs + i] = 0;
-        int* s_lab = (int*)pl_lds;
-        int* s_start = s_lab + l_max;
-        int32_t* pos_out = cls + (long)b * (l_max + k + 1);
-        int32_t* start_out = pos_out + l_max;
-        for (int i = lane; i < L; i += 64) s_lab[i] = labels[(long)b * l_max + i];
-        for (int i = lane; i <= k; i += 64) s_start[i] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        int ranks[8];
-        int nmine = 0;
-        for (int i = lane; i < L; i += 64) {
-            const int c = s_lab[i];
-            int r = 0;
-            for (int j = 0; j < i; ++j) r += (s_lab[j] == c);
-            ranks[nmine++] = r;
-            atomicAdd(&s_start[c + 1], 1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane == 0)
-            for (int c = 0; c < k; ++c) s_start[c + 1] += s_start[c];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        nmine = 0;
-        for (int i = lane; i < L; i += 64) pos_out[s_start[s_lab[i]] + ranks[nmine++]] = i;
-        for (int i = lane; i <= k; i += 64) start_out[i] = s_start[i];
+        if (wv == 0) build_class_lists_wave((int*)pl_lds, lane, labels, cls, tickets, b, L, grad_wgs, k, l_max);
         return;
     }
     const int S = 2 * L + 1;
@@ -1564,7 +1821,9 @@ __host__ int lattice_sp(int l_max) { return ((2 * l_max + 1) + 63) / 64 * 64; }
 // with forced repair (measurement: 87 / 463 us, but see WaveReal)
 int g_ctc_variant = 0;
 #ifndef SL_CTC_DEFAULT_WAVE
-#define SL_CTC_DEFAULT_WAVE 4  // sl_ctc_select(0): 4 = one wave per direction, 8 = the wave pair (A/B builds: -DSL_CTC_DEFAULT_WAVE=8)
+// sl_ctc_select(0): 10 = the lattice wave with its helper wave (round 6: 92.4 -> 88.0 us per call at 32 x 500, 502 -> 471 us at
+// 8 x 4000, bit-identical results), 4 = the lone wave, 8 = the wave pair (A/B builds: -DSL_CTC_DEFAULT_WAVE=4)
+#define SL_CTC_DEFAULT_WAVE 10
 #endif
 
 struct CtcLayout {
@@ -1601,7 +1860,7 @@ __host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
 }  // namespace
 
 extern "C" int sl_ctc_select(int variant) {
-    SL_CHECK_ARG(variant >= 0 && variant <= 9, "sl_ctc_select: variant %d outside 0..9", variant);
+    SL_CHECK_ARG(variant >= 0 && variant <= 11, "sl_ctc_select: variant %d outside 0..11", variant);
     g_ctc_variant = variant;
     return SL_OK;
 }
@@ -1660,14 +1919,16 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
     // 8 (round 6): the double lattice on a PAIR of waves per direction (pair_lattice_run); its LDS mailbox holds a slot per
     // frame, so very long utterances (T' > 8000) stay on the single wave
     const bool pair_fits = fits && pair_lds_bytes(t_out, l_max, k) <= 150 * 1024;
-    if (v == 0) v = fits ? (pair_fits ? SL_CTC_DEFAULT_WAVE : 4) : 1;
+    if (v == 0) v = fits ? ((SL_CTC_DEFAULT_WAVE != 8 || pair_fits) ? SL_CTC_DEFAULT_WAVE : 4) : 1;
     if (v != 1 && !fits) v = 1;
     if (v == 8 && !pair_fits) v = 4;
     if (v == 9 && !pair_fits) v = 2;
+    if ((v == 10 || v == 11) && !fits) v = 1;
     const bool wave = v != 1;
     const bool pair = v == 8 || v == 9;
+    const bool helped = v == 10 || v == 11;  // 10 / 11 (round 6): the lone lattice wave + a helper wave that gathers its emissions
     const bool wave_f32 = v >= 5 && v <= 7;
-    const bool repair = wave && v != 2 && v != 6 && v != 9;
+    const bool repair = wave && v != 2 && v != 6 && v != 9 && v != 11;
     const bool force_repair = v == 3 || v == 7;
     const int frames_per_wg = 8;  // two frames per wave: 16000 frames -> 8000 waves in flight
     const size_t lds2 = (size_t)(2 * l_max + (k + 1)) * sizeof(int) + (size_t)(4 * 64 + 4 * l_max) * sizeof(float);
@@ -1684,7 +1945,18 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
         int32_t* tickets = (int32_t*)(base + w.tickets);
         size_t lds = (size_t)(l_max + k + 1) * sizeof(int);
         if (lds < 2 * sizeof(double) + 2 * sizeof(int)) lds = 2 * sizeof(double) + 2 * sizeof(int);
-        if (pair) {
+        if (helped) {
+            const size_t hlds = helped_lds_bytes(l_max, k);
+            static bool attr_set_h = false;
+            if (!attr_set_h) {
+                (void)hipFuncSetAttribute((const void*)ctc_lattice_helped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024);
+                attr_set_h = true;
+            }
+            hipLaunchKernelGGL(ctc_lattice_helped_kernel, dim3(batch, 3), dim3(128), hlds, s, probs, logq, labels, label_len,
+                               input_len, (uint32_t*)la, (uint32_t*)lb, (uint32_t*)(base + w.dump), ea, eb, logz2, zint, loss,
+                               cls, flags, tickets, (int)grid.x, t_out, k, l_max, k - 1, eps);
+        } else if (pair) {
             const size_t plds = pair_lds_bytes(t_out, l_max, k);
             static bool attr_set = false;
             if (!attr_set) {

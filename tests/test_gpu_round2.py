@@ -600,7 +600,7 @@ def _ctc_variant(hip_lib, variant):
     hip_lib.call("sl_ctc_select", variant)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_ctc_lattice_variants_against_the_oracle(hip_lib, variant):
     """sl_ctc_loss_grad's lattices -- probability domain, one wave per utterance and direction, in doubles with an exponent
     per lane and 16 frames (variants 2, 3, 4 and the default) or in floats with one per 8 frames (5, 6, 7) -- and log domain (variant 1; also the repair pass that variants 3 and 7 force for every utterance) -- on the

@@ -298,13 +298,13 @@ def test_ctc_wave_lattice_needs_no_repair_once_the_net_has_learnt_its_labels(hip
     assert np.isfinite(ref_loss).all()
     results = {}
     try:
-        for variant in (2, 0, 1, 9):
+        for variant in (2, 0, 1, 9, 11):
             hip_lib.call("sl_ctc_select", variant)
             _, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
             results[variant] = (loss.copy(), dl.copy())
     finally:
         hip_lib.call("sl_ctc_select", 0)
-    for variant in (2, 0, 9):  # (9: the wave-pair lattice of round 6, without the repair pass)
+    for variant in (2, 0, 9, 11):  # (9 / 11: the wave-pair and the helped lattice of round 6, without the repair pass)
         loss, dl = results[variant]
         assert np.isfinite(loss).all(), (variant, loss)
         # the loss itself is ~1e-4 here -- the sum of 500 per-frame terms of O(1e-7) each, kept in fp32 as TensorFlow's own

@@ -78,7 +78,8 @@ def main():
     for variant, name in ((1, "log-domain lattice"), (2, "wave lattice (double), no repair pass"),
                           (4, "wave lattice (double) + repair pass"), (6, "wave lattice (float), no repair pass"),
                           (5, "wave lattice (float) + repair pass"), (9, "wave PAIR lattice (double), no repair pass"),
-                          (8, "wave PAIR lattice (double) + repair pass"), (0, "automatic (bf16 output)")):
+                          (8, "wave PAIR lattice (double) + repair pass"), (11, "wave lattice + HELPER wave, no repair pass"),
+                          (10, "wave lattice + HELPER wave + repair pass"), (0, "automatic (bf16 output)")):
         lib.call("sl_ctc_select", variant)
 
         def run():

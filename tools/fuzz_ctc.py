@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pair", action="store_true", help="the wave-PAIR lattice (sl_ctc_select 8 / 9) instead of the default one")
+    ap.add_argument("--helped", action="store_true", help="the lattice wave with a helper wave (sl_ctc_select 10 / 11)")
     args = ap.parse_args()
     from oracle import w2l_oracle as o
     from speechless_amd import _lib
@@ -84,9 +85,9 @@ def main():
         ref_p = o.softmax(logits.astype(np.float64))
         ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
         ref_dl = o.softmax_backward(ref_p, ref_dp)
-        lib.call("sl_ctc_select", 8 if args.pair else 0)
+        lib.call("sl_ctc_select", 10 if args.helped else (8 if args.pair else 0))
         _, loss, dl = run_ctc_kernel(lib, logits, labels, lab_len, input_len)
-        lib.call("sl_ctc_select", 9 if args.pair else 2)
+        lib.call("sl_ctc_select", 11 if args.helped else (9 if args.pair else 2))
         _, loss2, dl2 = run_ctc_kernel(lib, logits, labels, lab_len, input_len)
         lib.call("sl_ctc_select", 0)
         needed_repair = not (np.array_equal(loss, loss2, equal_nan=True) and np.array_equal(dl, dl2, equal_nan=True))
