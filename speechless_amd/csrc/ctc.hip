@@ -342,6 +342,9 @@ __device__ __forceinline__ void ctc_grad_frames(
         if (t >= t_out) break;
         const long fidx = (long)b * t_out + t;
         float dz = 0.f;
+#if defined(SL_PROBE_CTC_TOTALS)
+        float probe_total = 0.f, probe_na = 0.f, probe_nb = 0.f, probe_nab = 0.f;
+#endif
         if (t < T) {
             const float lqv = lane < k ? logq[fidx * k + lane] : 0.f;
             const float pk = lane < k ? probs[fidx * k + lane] : 0.f;
@@ -380,6 +383,11 @@ __device__ __forceinline__ void ctc_grad_frames(
                         const int eab = eap[wl] + ebp[wl] - zi;
                         // a state the other direction cannot reach has posterior 0 whatever this direction holds
                         const bool dead = !(ad[j] > (RT)0 && bd[j] > (RT)0 && ad[j] < (RT)INFINITY && bd[j] < (RT)INFINITY);
+#if defined(SL_PROBE_CTC_TOTALS)
+                        probe_na += (lane + 64 * j < S && ad[j] > (RT)0) ? 1.f : 0.f;
+                        probe_nb += (lane + 64 * j < S && bd[j] > (RT)0) ? 1.f : 0.f;
+                        probe_nab += (lane + 64 * j < S && !dead) ? 1.f : 0.f;
+#endif
                         int xa, xb;
                         const RT ma = frexp(dead ? (RT)1 : ad[j], &xa), mb = frexp(dead ? (RT)1 : bd[j], &xb);
                         av[j] = dead ? -INFINITY : __builtin_amdgcn_logf((float)ma) + __builtin_amdgcn_logf((float)mb);
@@ -424,6 +432,9 @@ __device__ __forceinline__ void ctc_grad_frames(
                     }
                 }
                 blank_part = wave_sum(blank_part);
+#if defined(SL_PROBE_CTC_TOTALS)  // diagnosis: the frame's posterior total - 1 instead of class 0's gradient (wrong results)
+                probe_total = blank_part + wave_sum(label_part) - 1.f;
+#endif
                 if (LIN && flags != nullptr) {
                     const float total = blank_part + wave_sum(label_part);
                     if (lane == 0 && !(fabsf(total - 1.f) < 4e-3f))
@@ -448,6 +459,15 @@ __device__ __forceinline__ void ctc_grad_frames(
             if (lane < k) dp = (expf(lqv) - occ) / (pk + eps);
             const float inner = wave_sum(pk * dp);
             dz = pk * (dp - inner) * grad_scale;
+#if defined(SL_PROBE_CTC_TOTALS)
+            {
+                const float na = wave_sum(probe_na), nb = wave_sum(probe_nb), nab = wave_sum(probe_nab);
+                if (lane == 0) dz = probe_total;
+                if (lane == 1) dz = na;
+                if (lane == 2) dz = nb;
+                if (lane == 3) dz = nab;
+            }
+#endif
         }
         if (lane < k) {
             const long gi = (long)b * g_bs + (long)(g_row0 + t) * g_rs + lane;
@@ -805,6 +825,19 @@ __device__ __forceinline__ void wave_lattice_run(const float* __restrict__ pr, c
             E = lane_zero ? en : (zsrc ? E : max(E, en - WaveReal<R>::FLOOR));
         }
         if (WaveReal<R>::FLOOR < (1 << 19)) {
+            // Round 6 (tools/fuzz_ctc.py seed 64, case 136: 250 labels in 299 frames, a learnt alignment followed by a blank
+            // collapse).  The chain of lifts above reaches RB / 4 + 1 lanes per rescale; a lane one further on kept its own
+            // stale mass (thousands of binades below the front), and at the NEXT rescale its source neighbour -- flushed to zero
+            // by its own lift, holding the front's exponent -- no longer "held mass", so the lane was not lifted then either:
+            // the front's mass crossed into it under the SHIFT_MAX clamp of fscale, i.e. was crushed (beta of the first four
+            // frames lost, posteriors 0, the utterance through the repair pass).  A lane that holds something but sits more
+            // than 2^SHIFT_MAX below a source neighbour that is still in play (zero or not: a zero lane carries the exponent it
+            // adopted from ITS source) is lifted like the others; what it held is > 2^(SHIFT_MAX - FLOOR) below what is about
+            // to arrive.  Neighbours the recursion has left behind for good (beyond lo_edge / hi_edge) keep stale exponents
+            // from long ago and set no level, as before.
+            const int en_r = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
+            const bool src_gone = DIR == 0 ? (WNS * lane - 1 < lo_edge) : (WNS * (lane + 1) > min(hi_edge, S - 1));  // (lanes beyond S never held anything)
+            E = (!lane_zero && !src_gone && en_r - E > WaveReal<R>::SHIFT_MAX) ? en_r - WaveReal<R>::FLOOR : E;
             const int lift = lane_zero ? 0 : E - e_own;  // >= 0
 #pragma unroll
             for (int j = 0; j < WNS; ++j) a[j] = wave_ldexp(a[j], -lift);
@@ -1135,6 +1168,12 @@ __device__ __forceinline__ void pair_lattice_run(const float* __restrict__ pr, c
             int en = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
             en = from_other ? x_e : en;
             E = lane_zero ? en : (zsrc ? E : max(E, en - FLOOR));
+        }
+        {   // (the rule of wave_lattice_run's rescale: a lane more than 2^SHIFT_MAX below a source neighbour still in play)
+            int en_r = DIR == 0 ? dpp_int_from_lower_lane(E, E) : dpp_int_from_upper_lane(E, E);
+            en_r = from_other ? x_e : en_r;
+            const bool src_gone = DIR == 0 ? (PNS * gl - 1 < lo_edge) : (PNS * (gl + 1) > min(hi_edge, S - 1));
+            E = (!lane_zero && !src_gone && en_r - E > SHIFT_MAX) ? en_r - FLOOR : E;
         }
         const int lift = lane_zero ? 0 : E - e_own;
 #pragma unroll

@@ -299,3 +299,39 @@ def test_f16x3_dropout_and_elu_against_the_f32_path(activation):
     errs = [max(rel_l2(a, c), rel_l2(b, d)) for (a, b), (c, d) in zip(out["f16x3"][1], out["f32"][1])]
     _report("f16x3_dropout_{}_vs_f32".format(activation), errs)
     assert max(errs) < (2e-4 if activation == "elu" else 5e-3), errs   # (ReLU: a flipped decision next to a dropout mask)
+
+
+# ------------------------------------------------------------------------------------------ CTC: the lane that missed its lift
+def test_ctc_tight_alignment_behind_a_blank_collapse_needs_no_repair(hip_lib):
+    """Found by `tools/fuzz_ctc.py --seed 64` (case 136) at the end of round 6: 250 labels in 299 frames, the first half a learnt
+    alignment, the second a blank collapse.  The probability-domain lattice lifts lanes that hold stale mass thousands of binades
+    below the approaching front, five lanes per rescale; the lane one further on was skipped, and at the next rescale its source
+    neighbour -- flushed to zero by its own lift -- no longer counted as holding mass: beta's front crossed into lane 0 under the
+    clamp of the exponent difference and was crushed (posteriors of frames 0..3 zero; the utterance went through the repair pass:
+    correct to the log-domain lattice's 6e-4 instead of 2e-6, at 0.7 ms per call).  With the lift also applied against a source
+    neighbour that is zero but still in play (ctc.hip, rescale) the lattice needs no repair: results with and without the repair
+    pass are bit-identical and within 1e-5 of the float64 oracle."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    from fuzz_ctc import replay_case
+    from test_gpu_parity import run_ctc_kernel
+    k, t, input_len, lab_len, labels_list, logits, desc = replay_case(64, 136)
+    assert lab_len[1] == 250 and input_len[1] == 299 and desc[1] == "learnt|collapse"
+    labels = o.pack_label_batch([l if l else [-1] for l in labels_list])
+    ref_p = o.softmax(logits.astype(np.float64))
+    ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
+    ref_dl = o.softmax_backward(ref_p, ref_dp)
+    results = {}
+    try:
+        for variant in (0, 11, 4, 2):   # default (helper wave + repair), helper wave alone, lone wave + repair, lone wave alone
+            hip_lib.call("sl_ctc_select", variant)
+            _, loss, dl = run_ctc_kernel(hip_lib, logits, labels, lab_len, input_len)
+            results[variant] = (loss, dl)
+    finally:
+        hip_lib.call("sl_ctc_select", 0)
+    loss, dl = results[0]
+    for variant in (11, 4, 2):
+        assert np.array_equal(loss, results[variant][0]) and np.array_equal(dl, results[variant][1]), variant
+    np.testing.assert_allclose(loss, ref_loss, rtol=2e-6)
+    assert np.abs(dl - ref_dl).max() < 1e-5

@@ -46,6 +46,40 @@ def regime_logits(rng, label, t, k, kind):
     return lg
 
 
+def draw_case(rng, kinds=("uniform", "sharp", "collapse", "learnt", "wrong")):
+    """the next case of the stream: (k, t, input_len, lab_len, labels_list, logits, regime names)"""
+    kinds = list(kinds)
+    k = int(rng.choice([5, 12, 29]))
+    t = int(rng.choice([rng.randint(20, 60), rng.randint(60, 300), rng.randint(300, 700)]))
+    b = int(rng.randint(1, 5))
+    input_len = [int(rng.randint(max(2, t // 2), t + 1)) for _ in range(b)]
+    lab_len = [int(rng.randint(0, min(200, il) + 1)) if rng.rand() < 0.9 else int(min(250, il + rng.randint(1, 10)))
+               for il in input_len]
+    labels_list = [list(rng.randint(0, k - 1, size=n)) for n in lab_len]
+    logits = np.zeros((b, t, k), dtype=np.float32)
+    desc = []
+    for i in range(b):
+        a, c = rng.choice(kinds), rng.choice(kinds)
+        la = regime_logits(rng, labels_list[i], input_len[i], k, a)
+        if rng.rand() < 0.4:
+            lc = regime_logits(rng, labels_list[i], input_len[i], k, c)
+            h = input_len[i] // 2
+            la[h:] = lc[h:]
+            a = a + "|" + c
+        logits[i, :input_len[i]] = la
+        desc.append(a)
+    return k, t, input_len, lab_len, labels_list, logits, desc
+
+
+def replay_case(seed, index):
+    """case `index` of `python tools/fuzz_ctc.py --seed <seed>` (the stream is replayed on the host up to it)"""
+    rng = np.random.RandomState(seed)
+    case = None
+    for _ in range(index + 1):
+        case = draw_case(rng)
+    return case
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
@@ -62,25 +96,8 @@ def main():
     repaired = 0
     worst_loss = worst_grad = 0.0
     for case in range(args.cases):
-        k = int(rng.choice([5, 12, 29]))
-        t = int(rng.choice([rng.randint(20, 60), rng.randint(60, 300), rng.randint(300, 700)]))
-        b = int(rng.randint(1, 5))
-        input_len = [int(rng.randint(max(2, t // 2), t + 1)) for _ in range(b)]
-        lab_len = [int(rng.randint(0, min(200, il) + 1)) if rng.rand() < 0.9 else int(min(250, il + rng.randint(1, 10)))
-                   for il in input_len]
-        labels_list = [list(rng.randint(0, k - 1, size=n)) for n in lab_len]
-        logits = np.zeros((b, t, k), dtype=np.float32)
-        desc = []
-        for i in range(b):
-            a, c = rng.choice(kinds), rng.choice(kinds)
-            la = regime_logits(rng, labels_list[i], input_len[i], k, a)
-            if rng.rand() < 0.4:
-                lc = regime_logits(rng, labels_list[i], input_len[i], k, c)
-                h = input_len[i] // 2
-                la[h:] = lc[h:]
-                a = a + "|" + c
-            logits[i, :input_len[i]] = la
-            desc.append(a)
+        k, t, input_len, lab_len, labels_list, logits, desc = draw_case(rng, kinds)
+        b = logits.shape[0]
         labels = o.pack_label_batch([l if l else [-1] for l in labels_list])
         ref_p = o.softmax(logits.astype(np.float64))
         ref_loss, ref_dp = o.ctc_batch_cost(ref_p, labels, input_len, lab_len)
