@@ -38,6 +38,14 @@ __device__ __forceinline__ float lse3_2(float a, float b, float c) {
                                      __builtin_amdgcn_exp2f(c - m));
 }
 
+// the same in doubles (repair pass, round 6: log values of magnitude 2^12 carry 2.4e-4 in fp32 -- a repaired utterance came
+// back at 6e-4 ... 2e-3 of the float64 oracle; in doubles at 1e-6.  Rare path: the library exp2 / log2 cost does not matter)
+__device__ __forceinline__ double lse3_2d(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + log2(exp2(a - m) + exp2(b - m) + exp2(c - m));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
@@ -233,13 +241,14 @@ __device__ __forceinline__ float log2_of_double(double x) {
 // u = p + eps instead of q) and is brought to log2 units on the fly; the sum of a frame's state posteriors must then be
 // ---- repair of one utterance inside the gradient kernel (see ctc_grad_kernel) ------------------------------------------
 // Log-domain alpha and beta lattices of utterance b by ONE work-group of 256 threads (S <= 512): the
-// recursion of ctc_lattice_kernel, operation for operation (same results), without its tuning -- this runs only for an
-// utterance whose linear lattice lost mass, and then on one work-group while the rest of the chip goes on.
+// recursion of ctc_lattice_kernel without its tuning, IN DOUBLES since round 6 (the fp32 log values of a 500-frame utterance
+// carry 2.4e-4 each; a repaired utterance is now as accurate as an unrepaired one) -- this runs only for an utterance whose
+// linear lattice lost mass, and then on one work-group while the rest of the chip goes on.
 // Both directions at once: threads 0..127 run alpha, threads 128..255 beta (up to four states per thread, one barrier per
 // frame for both).
 __device__ void repair_lattices(const float* __restrict__ lq_b, const int* s_lab, int L, int S, int T, int k, int blank,
-                                int sp, float* __restrict__ out_alpha, float* __restrict__ out_beta, float* rows,
-                                float* loss_b) {
+                                int sp, double* __restrict__ out_alpha, double* __restrict__ out_beta, double* rows,
+                                float* loss_b, float* logz2_b, int32_t* zint_b) {
     constexpr int RS = 512 + 4;  // row stride in LDS: index s + 2, two pads either side; rows: [direction][2][RS]
     const int tid = threadIdx.x;
     const int dir = tid >> 7;    // wave-uniform
@@ -261,11 +270,11 @@ __device__ void repair_lattices(const float* __restrict__ lq_b, const int* s_lab
                 skip[i] = (st + 2 < S) && (s_lab[(st >> 1) + 1] != my[i]);
         }
     }
-    for (int i = tid; i < 4 * RS; i += 256) rows[i] = -INFINITY;
+    for (int i = tid; i < 4 * RS; i += 256) rows[i] = -(double)INFINITY;
     __syncthreads();
-    float* prev = rows + dir * 2 * RS;
-    float* cur = prev + RS;
-    float* out = dir == 0 ? out_alpha : out_beta;
+    double* prev = rows + dir * 2 * RS;
+    double* cur = prev + RS;
+    double* out = dir == 0 ? out_alpha : out_beta;
     const int tstart = dir == 0 ? 0 : T - 1;
     const int tstep = dir == 0 ? 1 : -1;
     const int nb = dir == 0 ? -1 : 1;
@@ -281,16 +290,16 @@ __device__ void repair_lattices(const float* __restrict__ lq_b, const int* s_lab
         for (int i = 0; i < 4; ++i) {
             const int st = ht + 128 * i;
             if (mine[i]) {
-                float v;
+                double v;
                 if (step == 0) {
                     const bool init = dir == 0 ? (st <= 1) : (st >= S - 2);
-                    v = (live[i] && init) ? e[i] * LOG2E : -INFINITY;
+                    v = (live[i] && init) ? (double)e[i] * 1.4426950408889634 : -(double)INFINITY;
                 } else {
-                    const float a0 = prev[st + 2];
-                    const float a1 = prev[st + 2 + nb];
-                    const float a2 = skip[i] ? prev[st + 2 + 2 * nb] : -INFINITY;
-                    v = fmaf(e[i], LOG2E, lse3_2(a0, a1, a2));
-                    if (!live[i]) v = -INFINITY;
+                    const double a0 = prev[st + 2];
+                    const double a1 = prev[st + 2 + nb];
+                    const double a2 = skip[i] ? prev[st + 2 + 2 * nb] : -(double)INFINITY;
+                    v = fma((double)e[i], 1.4426950408889634, lse3_2d(a0, a1, a2));
+                    if (!live[i]) v = -(double)INFINITY;
                 }
                 cur[st + 2] = v;
                 out[(long)t * sp + st] = v;
@@ -298,16 +307,20 @@ __device__ void repair_lattices(const float* __restrict__ lq_b, const int* s_lab
             e[i] = en[i];
         }
         __syncthreads();
-        float* tmp = prev;
+        double* tmp = prev;
         prev = cur;
         cur = tmp;
     }
     if (tid == 0) {  // (dir 0: prev is alpha's last row)
-        const float last = prev[S - 1 + 2];
-        const float last2 = S >= 2 ? prev[S - 2 + 2] : -INFINITY;
-        const float m = fmaxf(last, last2);
-        const float lp2 = (m == -INFINITY) ? -INFINITY : m + log2f(exp2f(last - m) + exp2f(last2 - m));
-        *loss_b = -lp2 * LN2;
+        const double last = prev[S - 1 + 2];
+        const double last2 = S >= 2 ? prev[S - 2 + 2] : -(double)INFINITY;
+        const double m = fmax(last, last2);
+        const double lp2 = (m == -INFINITY) ? -(double)INFINITY : m + log2(exp2(last - m) + exp2(last2 - m));
+        *loss_b = (float)(-lp2 * 0.6931471805599453);
+        // log2 Z for the gradient pass: integer part and fraction apart, as the linear lattice hands it over
+        const double fl = (m == -INFINITY) ? 0.0 : floor(lp2);
+        *zint_b = (int32_t)fl;
+        *logz2_b = (m == -INFINITY) ? -INFINITY : (float)(lp2 - fl);
     }
     __syncthreads();
 }
@@ -334,7 +347,8 @@ __device__ __forceinline__ void ctc_grad_frames(
     // LIN: log2 of the partition sum in u units = zint[b] + logz2[b], integer part and fraction kept apart
     // (loss[b] = -ln Z_u - sum_t ln c_t was written by the lattice wave)
     const bool feasible = nll < INFINITY;
-    const float log_p = LIN ? logz2[b] : -nll * LOG2E;  // lattice units are log2
+    // lattice units are log2 (LIN == 4: the fraction of the REPAIRED lattice's log2 Z, just written by this work-group)
+    const float log_p = LIN == 4 ? *(const volatile float*)&logz2[b] : (LIN ? logz2[b] : -nll * LOG2E);
     float* gam = s_gam + wave * l_max;
     float* wlq = s_lq + wave * 64;
     for (int tt = wave; tt < frames_per_wg; tt += 4) {
@@ -352,7 +366,21 @@ __device__ __forceinline__ void ctc_grad_frames(
             if (feasible) {
                 float av[NJ], bv[NJ];  // LIN: av = fractional part (log2 of the two mantissas), bv unused, ai = integer part
                 int ai[NJ];
-                if (LIN) {
+                if (LIN == 4) {
+                    // log-domain rows in DOUBLES (the repair pass): alpha + beta - floor(log2 Z) in doubles, the small rest in fp32
+                    const double* al = (const double*)alpha_v + fidx * sp;
+                    const double* be = (const double*)beta_v + fidx * sp;
+                    const double zi = (double)*(const volatile int32_t*)&zint[b];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const bool in = 64 * j < sp;
+                        const double ad = in ? al[lane + 64 * j] : -(double)INFINITY;
+                        const double bd = in ? be[lane + 64 * j] : -(double)INFINITY;
+                        av[j] = (ad == -INFINITY || bd == -INFINITY) ? -INFINITY : (float)((ad + bd) - zi);
+                        bv[j] = 0.f;
+                        ai[j] = 0;
+                    }
+                } else if (LIN) {
                     typedef typename std::conditional<LIN == 2, float, double>::type RT;
                     RT ad[NJ], bd[NJ];
 #pragma unroll
@@ -406,7 +434,7 @@ __device__ __forceinline__ void ctc_grad_frames(
                     }
                 }
                 // emission in lattice units: log2 q (log-domain lattice) or log2 (p + eps) (linear lattice)
-                wlq[lane] = LIN ? __builtin_amdgcn_logf(pk + eps) : lqv * LOG2E;
+                wlq[lane] = (LIN && LIN != 4) ? __builtin_amdgcn_logf(pk + eps) : lqv * LOG2E;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -503,8 +531,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                        int t_out, int k, int l_max, int sp, int blank, int frames_per_wg,
                                                        int g_row0, int g_rs, long g_bs, int out_f32, float eps,
                                                        float grad_scale, int32_t* __restrict__ flags,
-                                                       int32_t* __restrict__ tickets, float* __restrict__ rep_alpha,
-                                                       float* __restrict__ rep_beta, int rep_sp) {
+                                                       int32_t* __restrict__ tickets, double* __restrict__ rep_alpha,
+                                                       double* __restrict__ rep_beta, int rep_sp) {
     // LDS: labels[l_max] | class_pos[l_max] | class_start[k+1] | lq[4][64] | gamma[4][l_max]
     extern __shared__ int lds_i[];
     int* s_lab = lds_i;
@@ -532,7 +560,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     if constexpr (LIN != 0) {
         if (tickets == nullptr) return;
         __shared__ int s_flag;
-        __shared__ float s_rows[4 * (512 + 4)];
+        __shared__ double s_rows[4 * (512 + 4)];
         // No fence, no shared counter and nobody waiting in the common path.  The gradient rows are device-scope stores and
         // the flag updates device-scope atomics, complete once acknowledged: every wave waits for its own, then one
         // thread of the work-group raises the work-group's OWN done slot (a device-scope release here writes back the
@@ -573,12 +601,15 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         }
         __threadfence();
         const float* lq_b = logq + (long)b * t_out * k;
+        // (log2 Z of the repaired lattice replaces the linear lattice's in logz2 / zint: written through a non-const alias,
+        // read back by ctc_grad_frames<., 4> with volatile loads -- the kernel's own pointers are const __restrict__)
         repair_lattices(lq_b, s_lab, L, S, T, k, blank, rep_sp, rep_alpha + (long)b * t_out * rep_sp,
-                        rep_beta + (long)b * t_out * rep_sp, s_rows, &loss[b]);
-        __threadfence();  // the lattice rows and the loss, written by other threads of this work-group
+                        rep_beta + (long)b * t_out * rep_sp, s_rows, &loss[b], const_cast<float*>(logz2) + b,
+                        const_cast<int32_t*>(zint) + b);
+        __threadfence();  // the lattice rows, the loss and log2 Z, written by other threads of this work-group
         __syncthreads();
         const float nll = *(volatile float*)&loss[b];
-        ctc_grad_frames<8, 0>(probs, logq, rep_alpha, rep_beta, nullptr, nullptr, nullptr, nullptr, nll, dlogits, s_lab,
+        ctc_grad_frames<8, 4>(probs, logq, rep_alpha, rep_beta, nullptr, nullptr, logz2, zint, nll, dlogits, s_lab,
                               s_pos, s_start, s_lq, s_gam, b, S, T, t_out, k, l_max, rep_sp, blank, 0, t_out, g_row0, g_rs,
                               g_bs, out_f32, eps, grad_scale, nullptr);
     }
@@ -1877,8 +1908,9 @@ __host__ CtcLayout ctc_layout(int batch, int t_out, int l_max) {
         off += (bytes + 255) / 256 * 256;
         return at;
     };
-    w.log_alpha = take(rows * lattice_sp(l_max) * sizeof(float));
-    w.log_beta = take(rows * lattice_sp(l_max) * sizeof(float));
+    // log-domain rows: floats for the labels the wave lattice does not take (variant 1), DOUBLES for the repair pass (round 6)
+    w.log_alpha = take(rows * lattice_sp(l_max) * sizeof(double));
+    w.log_beta = take(rows * lattice_sp(l_max) * sizeof(double));
     w.cls = take((size_t)batch * (l_max + 65) * sizeof(int32_t));
     const bool wave = 2 * l_max + 1 <= 64 * WNS;
     w.lin_alpha = take(wave ? rows * 64 * WNS * sizeof(uint32_t) : 0);  // a float, or the high word of a double, per state
@@ -2027,17 +2059,17 @@ extern "C" int sl_ctc_loss_grad(const float* probs, const float* logq, const int
             hipLaunchKernelGGL((ctc_grad_kernel<8, 3>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
                                input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
                                l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
-                               eps, grad_scale, flags, rep_tickets, alpha, beta, sp);
+                               eps, grad_scale, flags, rep_tickets, (double*)alpha, (double*)beta, sp);
         else if (wave_f32)
             hipLaunchKernelGGL((ctc_grad_kernel<8, 2>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
                                input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
                                l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
-                               eps, grad_scale, flags, rep_tickets, alpha, beta, sp);
+                               eps, grad_scale, flags, rep_tickets, (double*)alpha, (double*)beta, sp);
         else
             hipLaunchKernelGGL((ctc_grad_kernel<8, 1>), grid, dim3(256), lds2, s, probs, logq, labels, label_len,
                                input_len, (const void*)la, (const void*)lb, ea, eb, logz2, zint, loss, cls, dlogits, t_out, k,
                                l_max, 64 * WNS, k - 1, frames_per_wg, g_row0, g_row_stride, (long)g_batch_stride, out_f32,
-                               eps, grad_scale, flags, rep_tickets, alpha, beta, sp);
+                               eps, grad_scale, flags, rep_tickets, (double*)alpha, (double*)beta, sp);
         return sl_check_launch("sl_ctc_loss_grad(grad)");
     }
     // labels beyond the wave lattice: the log-domain lattice for every utterance

@@ -46,22 +46,27 @@ def regime_logits(rng, label, t, k, kind):
     return lg
 
 
-def draw_case(rng, kinds=("uniform", "sharp", "collapse", "learnt", "wrong")):
-    """the next case of the stream: (k, t, input_len, lab_len, labels_list, logits, regime names)"""
+def draw_case(rng, kinds=("uniform", "sharp", "collapse", "learnt", "wrong"), tight=False):
+    """the next case of the stream: (k, t, input_len, lab_len, labels_list, logits, regime names).  tight: labels that fill
+    60 .. 100 % of the frames (up to 255 graphemes) -- alignments with next to no slack, the regime of the lane that missed its
+    lift (round 6); always with a second regime in the other half of the utterance"""
     kinds = list(kinds)
     k = int(rng.choice([5, 12, 29]))
     t = int(rng.choice([rng.randint(20, 60), rng.randint(60, 300), rng.randint(300, 700)]))
     b = int(rng.randint(1, 5))
     input_len = [int(rng.randint(max(2, t // 2), t + 1)) for _ in range(b)]
-    lab_len = [int(rng.randint(0, min(200, il) + 1)) if rng.rand() < 0.9 else int(min(250, il + rng.randint(1, 10)))
-               for il in input_len]
+    if tight:
+        lab_len = [int(min(255, rng.randint(int(0.6 * il), il + 1))) for il in input_len]
+    else:
+        lab_len = [int(rng.randint(0, min(200, il) + 1)) if rng.rand() < 0.9 else int(min(250, il + rng.randint(1, 10)))
+                   for il in input_len]
     labels_list = [list(rng.randint(0, k - 1, size=n)) for n in lab_len]
     logits = np.zeros((b, t, k), dtype=np.float32)
     desc = []
     for i in range(b):
         a, c = rng.choice(kinds), rng.choice(kinds)
         la = regime_logits(rng, labels_list[i], input_len[i], k, a)
-        if rng.rand() < 0.4:
+        if rng.rand() < (1.0 if tight else 0.4):
             lc = regime_logits(rng, labels_list[i], input_len[i], k, c)
             h = input_len[i] // 2
             la[h:] = lc[h:]
@@ -85,6 +90,7 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pair", action="store_true", help="the wave-PAIR lattice (sl_ctc_select 8 / 9) instead of the default one")
+    ap.add_argument("--tight", action="store_true", help="labels filling 60 .. 100 %% of the frames, two regimes per utterance")
     ap.add_argument("--helped", action="store_true", help="the lattice wave with a helper wave (sl_ctc_select 10 / 11)")
     args = ap.parse_args()
     from oracle import w2l_oracle as o
@@ -96,7 +102,7 @@ def main():
     repaired = 0
     worst_loss = worst_grad = 0.0
     for case in range(args.cases):
-        k, t, input_len, lab_len, labels_list, logits, desc = draw_case(rng, kinds)
+        k, t, input_len, lab_len, labels_list, logits, desc = draw_case(rng, kinds, tight=args.tight)
         b = logits.shape[0]
         labels = o.pack_label_batch([l if l else [-1] for l in labels_list])
         ref_p = o.softmax(logits.astype(np.float64))
