@@ -56,7 +56,7 @@ sp = ((2 * l_max + 1) + 63) // 64 * 64
 rows = bb * tt
 off = {}
 o_ = 0
-for name, size in (("log_alpha", rows * sp * 4), ("log_beta", rows * sp * 4), ("cls", bb * (l_max + 65) * 4),
+for name, size in (("log_alpha", rows * sp * 8), ("log_beta", rows * sp * 8), ("cls", bb * (l_max + 65) * 4),
                    ("lin_alpha", rows * 512 * 4), ("lin_beta", rows * 512 * 4), ("dump", 2 * bb * 512 * 4),
                    ("ea", bb * (tt // 8 + 2) * 64 * 4), ("eb", bb * (tt // 8 + 2) * 64 * 4)):
     off[name] = o_; o_ += up(size)
@@ -85,10 +85,13 @@ la = view("lin_alpha", np.uint32, rows * 512).reshape(bb, tt, 512)[u]
 lb = view("lin_beta", np.uint32, rows * 512).reshape(bb, tt, 512)[u]
 def hi2d(x): return (x.astype(np.uint64) << np.uint64(32)).view(np.float64)
 print("T", T, "blocks", (T - 1) // 16)
-print("eb blocks 15..18, lanes 0..5:\n", eb[15:19, :6])
-print("ea blocks 0..2, lanes 0..5:\n", ea[0:3, :6])
-for f in (0, 1, 3, 4, 5, 10, 11, 12):
-    print("frame", f, "step", T - 1 - f, "beta s0..15 log2:", np.round(np.log2(np.maximum(hi2d(lb[f, :16]), 1e-320)), 1))
-for f in (0, 3, 4):
-    print("frame", f, "alpha s0..15 log2:", np.round(np.log2(np.maximum(hi2d(la[f, :16]), 1e-320)), 1))
-print("logz2 / loss", loss_t.cpu().numpy()[u], ref_loss[u] / np.log(2))
+frames = [int(x) for x in os.environ.get("FRAMES", "0,1,3,4,5,10,11,12").split(",")]
+s0, s1 = [int(x) for x in os.environ.get("STATES", "0,16").split(",")]
+lanes = slice(s0 // 8, (s1 + 7) // 8)
+np.set_printoptions(linewidth=200)
+for f in frames:
+    ba, bb_ = f // 16, (T - 1 - f) // 16
+    print("frame", f, "alpha block", ba, "exponents", ea[ba, lanes], " beta step", T - 1 - f, "block", bb_, "exponents", eb[bb_, lanes])
+    print("   alpha log2:", np.round(np.log2(np.maximum(hi2d(la[f, s0:s1]), 1e-320)), 1))
+    print("   beta  log2:", np.round(np.log2(np.maximum(hi2d(lb[f, s0:s1]), 1e-320)), 1))
+print("loss", loss_t.cpu().numpy()[u], "log2 Z", -ref_loss[u] / np.log(2))
