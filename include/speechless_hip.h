@@ -281,9 +281,10 @@ int sl_output_softmax(const void* x, const void* w, const float* bias, float* pr
  * Two lattice kernels: with labels of up to 255 graphemes and k <= 63 a probability-domain one (one wave per utterance
  * and direction, eight lattice states per lane, block floating point with one exponent per lane and 8 / 16 frames, no
  * transcendental, no LDS exchange and no barrier on the T'-long sequential path) in doubles; the gradient kernel then
- * checks every frame's posteriors against 1, and an utterance that lost mass to underflow is redone in the log domain by
- * the last work-group of the same launch (no further launches; none of the regimes of a training run -- near-uniform
- * start, blank collapse, a net that has learnt its labels -- needs it).  Labels beyond 255 graphemes go through the
+ * checks every frame's posteriors against 1, and an utterance that lost mass to underflow is redone in the log domain --
+ * in doubles since round 6: as accurate as the lattice it replaces -- by the last work-group of the same launch (no further
+ * launches; none of the regimes of a training run -- near-uniform start, blank collapse, a net that has learnt its labels
+ * -- needs it; alignments with next to no slack, labels filling > 90 % of the frames, can).  Labels beyond 255 graphemes go through the
  * log-domain lattice kernel (one thread per lattice state, LDS row exchange + barrier per frame).  Results agree to fp32
  * round-off.
  */
